@@ -1,0 +1,775 @@
+// harmonic_gpu.hip -- host drivers of the GPU half of the libepic C-ABI, HIP runtime on MI355X.
+//
+// Replaces libepic/src/harmonic/harmonic_gpu.cu:156-434 (solver drivers), harmonic_model_gpu.cu:34-204
+// (device-state lifecycle) and harmonic_utilities_gpu.cu:66-138 (sparse edits) with the same exported names,
+// validation, return codes and "Error[<function>]: <text>" stderr lines, over a different device design:
+//
+//  * device state lives in a library-side context keyed by the caller's Harmonic* (the 80-byte struct has no
+//    room for a second ping-pong buffer, a stream or pinned readback memory).  The struct's d_* fields are
+//    still set non-null / nulled exactly where the reference does, because callers and the library itself
+//    null-test them (harmonic_gpu.cu:208, :232-235; harmonic_model_gpu.cu:174-176);
+//  * u is kept pitched (row length padded to 64 floats) in two buffers; d_u points at the current one;
+//  * locked is kept bit-packed (d_locked points at the packed words);
+//  * sweeps are enqueued on one non-blocking stream; only the check sweeps, the readbacks and the edits
+//    synchronise (the reference synchronises the whole device after every kernel).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <unordered_map>
+
+#include "../../include/epic/epic_abi.h"
+#include "../../include/epic_hip.h"
+#include "kernels.h"
+
+using epic::Harmonic;
+
+namespace {
+
+struct Ctx {
+    int n = 0;
+    int m[3] = {0, 0, 0};   // as given by the caller
+    int rows = 0;           // 2-D: m[0];            3-D: m[0] * m[1] (rows of length m[2])
+    int cols = 0;           // last dimension
+    int pitch = 0;          // floats per row on the device
+    float *buf[2] = {nullptr, nullptr};
+    int cur = 0;
+    uint32_t *maskw = nullptr;
+    unsigned *d_m = nullptr;
+    unsigned *d_delta = nullptr;   // float bits of max |du|
+    float *h_delta = nullptr;      // pinned
+    hipStream_t stream = nullptr;
+    int rows_per_task = 0;         // 0 = automatic
+    size_t u_bytes() const { return (size_t)rows * pitch * sizeof(float); }
+    size_t mask_bytes() const
+    {
+        return sizeof(uint32_t) * (n == 2 ? epic_hip::mask_words_2d(rows, pitch) : epic_hip::mask_words_3d(m[0], m[1], pitch));
+    }
+};
+
+std::mutex g_mu;
+std::unordered_map<Harmonic *, Ctx *> g_ctx;
+
+void report(const char *fn, const char *msg) { fprintf(stderr, "Error[%s]: %s\n", fn, msg); }
+
+Ctx *find_ctx(Harmonic *h)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_ctx.find(h);
+    return it == g_ctx.end() ? nullptr : it->second;
+}
+
+bool dims_from(const Harmonic *h, Ctx *c)
+{
+    if (h->n != 2 && h->n != 3) return false;
+    for (unsigned i = 0; i < h->n; i++)
+        if (h->m[i] < 3 || h->m[i] > (1u << 30)) return false;
+    c->n = (int)h->n;
+    for (unsigned i = 0; i < 3; i++) c->m[i] = i < h->n ? (int)h->m[i] : 0;
+    c->cols = c->m[c->n - 1];
+    const long long rows = c->n == 2 ? (long long)c->m[0] : (long long)c->m[0] * c->m[1];
+    if (rows > 0x7fffffffLL) return false;
+    c->rows = (int)rows;
+    c->pitch = epic_hip::pitch_for_cols(c->cols);
+    return true;
+}
+
+bool same_dims(const Harmonic *h, const Ctx *c)
+{
+    if ((int)h->n != c->n) return false;
+    for (unsigned i = 0; i < h->n; i++)
+        if ((int)h->m[i] != c->m[i]) return false;
+    return true;
+}
+
+// Create (or fetch) the context of this Harmonic; sets up the stream and the pinned readback word.
+Ctx *get_ctx(Harmonic *h, bool create)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_ctx.find(h);
+    if (it != g_ctx.end()) {
+        Ctx *c = it->second;
+        // A Harmonic whose fields are all null but which we still track was freed and re-created by the
+        // caller without uninitialize: drop the stale device state.
+        if (h->d_m == nullptr && h->d_u == nullptr && h->d_locked == nullptr && h->d_delta == nullptr &&
+            (c->buf[0] || c->maskw || c->d_m || c->d_delta)) {
+            for (float *&b : c->buf) { if (b) (void)hipFree(b); b = nullptr; }
+            if (c->maskw) (void)hipFree(c->maskw);
+            if (c->d_m) (void)hipFree(c->d_m);
+            if (c->d_delta) (void)hipFree(c->d_delta);
+            c->maskw = nullptr; c->d_m = nullptr; c->d_delta = nullptr;
+        }
+        return c;
+    }
+    if (!create) return nullptr;
+    Ctx *c = new Ctx();
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        delete c;
+        return nullptr;
+    }
+    if (hipHostMalloc((void **)&c->h_delta, 64, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return nullptr;
+    }
+    const char *e = getenv("EPIC_HIP_ROWS_PER_TASK");
+    if (e) c->rows_per_task = atoi(e);
+    g_ctx[h] = c;
+    return c;
+}
+
+void drop_ctx_if_empty(Harmonic *h)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_ctx.find(h);
+    if (it == g_ctx.end()) return;
+    Ctx *c = it->second;
+    if (c->buf[0] || c->maskw || c->d_m || c->d_delta) return;
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->h_delta) (void)hipHostFree(c->h_delta);
+    delete c;
+    g_ctx.erase(it);
+}
+
+int auto_rows_per_task(const Ctx *c)
+{
+    if (c->rows_per_task > 0) return c->rows_per_task;
+    const long long nstrips = (c->pitch + 255) / 256;
+    long long r = (long long)c->rows * nstrips / 4096;   // aim at >= 4096 wave-tasks (16 per CU)
+    r = (r + 7) / 8 * 8;
+    return (int)std::min<long long>(64, std::max<long long>(8, r));
+}
+
+bool ready(const Harmonic *h, const Ctx *c)
+{
+    return c && c->buf[0] && c->buf[1] && c->maskw && h->d_u && h->d_locked;
+}
+
+// One Jacobi sweep, enqueued.  check != 0 also zeroes and fills the device delta word.
+hipError_t enqueue_sweep(Ctx *c, bool check)
+{
+    hipError_t e;
+    if (check) {
+        e = hipMemsetAsync(c->d_delta, 0, sizeof(unsigned), c->stream);
+        if (e != hipSuccess) return e;
+    }
+    const float *in = c->buf[c->cur];
+    float *out = c->buf[c->cur ^ 1];
+    if (c->n == 2)
+        e = epic_hip::launch_sweep_2d(in, out, c->maskw, c->rows, c->pitch, 0, c->rows, auto_rows_per_task(c),
+                                      check ? c->d_delta : nullptr, c->stream);
+    else
+        e = epic_hip::launch_sweep_3d(in, out, c->maskw, c->m[0], c->m[1], c->pitch, 0, c->m[0],
+                                      check ? c->d_delta : nullptr, c->stream);
+    if (e == hipSuccess) c->cur ^= 1;
+    return e;
+}
+
+int read_delta(Harmonic *h, Ctx *c, const char *fn)
+{
+    if (hipMemcpyAsync(c->h_delta, c->d_delta, sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
+        report(fn, "Failed to copy memory from device to host for the max delta.");
+        return EPIC_ERROR_MEMCPY_TO_HOST;
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) {
+        report(fn, "Failed to synchronize the device after the 'update and check' kernel.");
+        return EPIC_ERROR_DEVICE_SYNCHRONIZE;
+    }
+    h->delta = *c->h_delta;
+    return EPIC_SUCCESS;
+}
+
+int upload_u(Harmonic *h, Ctx *c, const char *fn)
+{
+    // padding columns hold the obstacle seed; both buffers, so that whichever is read first is complete
+    if (c->pitch != c->cols) {
+        for (int b = 0; b < 2; b++)
+            if (epic_hip::launch_fill(c->buf[b], (size_t)c->rows * c->pitch, -1e6f, c->stream) != hipSuccess) {
+                report(fn, "Failed to initialise device-side memory for the potential values.");
+                return EPIC_ERROR_KERNEL_EXECUTION;
+            }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return EPIC_ERROR_DEVICE_SYNCHRONIZE;
+    }
+    c->cur = 0;
+    if (hipMemcpy2D(c->buf[0], (size_t)c->pitch * sizeof(float), h->u, (size_t)c->cols * sizeof(float),
+                    (size_t)c->cols * sizeof(float), (size_t)c->rows, hipMemcpyHostToDevice) != hipSuccess) {
+        report(fn, "Failed to copy memory from host to device for the potential values.");
+        return EPIC_ERROR_MEMCPY_TO_DEVICE;
+    }
+    h->d_u = c->buf[0];
+    return EPIC_SUCCESS;
+}
+
+int upload_locked(Harmonic *h, Ctx *c, const char *fn)
+{
+    const size_t cells = (size_t)c->rows * c->cols;
+    uint32_t *tmp = nullptr;
+    if (hipMalloc((void **)&tmp, cells * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        report(fn, "Failed to allocate device-side staging memory for the locked cells.");
+        return EPIC_ERROR_DEVICE_MALLOC;
+    }
+    int rc = EPIC_SUCCESS;
+    if (hipMemcpy(tmp, h->locked, cells * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+        report(fn, "Failed to copy memory from host to device for the locked cells.");
+        rc = EPIC_ERROR_MEMCPY_TO_DEVICE;
+    } else {
+        hipError_t e = c->n == 2
+                           ? epic_hip::launch_pack_mask_2d(tmp, c->rows, c->cols, c->pitch, 0, 0, c->maskw, c->stream)
+                           : epic_hip::launch_pack_mask_3d(tmp, c->m[0], c->m[1], c->m[2], c->pitch, c->maskw, c->stream);
+        if (e != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+            report(fn, "Failed to execute the 'pack mask' kernel.");
+            rc = EPIC_ERROR_KERNEL_EXECUTION;
+        }
+    }
+    (void)hipFree(tmp);
+    return rc;
+}
+
+}  // namespace
+
+namespace epic {
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------------------
+// device-state lifecycle (reference: libepic/src/harmonic/harmonic_model_gpu.cu)
+// ---------------------------------------------------------------------------------------------------------
+
+int harmonic_initialize_dimension_size_gpu(Harmonic *harmonic)  // harmonic_model_gpu.cu:34-59
+{
+    static const char *fn = "harmonic_initialize_dimension_size_gpu";
+    if (harmonic == nullptr || harmonic->n == 0 || harmonic->m == nullptr) {
+        report(fn, "Invalid input.");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    Ctx *c = get_ctx(harmonic, true);
+    if (c == nullptr) {
+        report(fn, "Failed to allocate device-side memory for the dimension size.");
+        return EPIC_ERROR_DEVICE_MALLOC;
+    }
+    if (c->d_m) { (void)hipFree(c->d_m); c->d_m = nullptr; }  // re-initialise without uninitialise (harmonic.py:67-71 then harmonic_gpu.cu:172)
+    if (hipMalloc((void **)&c->d_m, harmonic->n * sizeof(unsigned)) != hipSuccess) {
+        (void)hipGetLastError();
+        report(fn, "Failed to allocate device-side memory for the dimension size.");
+        drop_ctx_if_empty(harmonic);
+        return EPIC_ERROR_DEVICE_MALLOC;
+    }
+    if (hipMemcpy(c->d_m, harmonic->m, harmonic->n * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) {
+        report(fn, "Failed to copy memory from host to device for the dimension size.");
+        return EPIC_ERROR_MEMCPY_TO_DEVICE;
+    }
+    harmonic->d_m = c->d_m;
+    return EPIC_SUCCESS;
+}
+
+int harmonic_uninitialize_dimension_size_gpu(Harmonic *harmonic)  // harmonic_model_gpu.cu:62-75
+{
+    if (harmonic == nullptr) return EPIC_ERROR_INVALID_DATA;
+    int rc = EPIC_SUCCESS;
+    Ctx *c = find_ctx(harmonic);
+    if (c && c->d_m) {
+        if (hipFree(c->d_m) != hipSuccess) {
+            report("harmonic_uninitialize_dimension_size_gpu", "Failed to free device-side memory for the dimension size.");
+            rc = EPIC_ERROR_DEVICE_FREE;
+        }
+        c->d_m = nullptr;
+    }
+    harmonic->d_m = nullptr;
+    drop_ctx_if_empty(harmonic);
+    return rc;
+}
+
+int harmonic_initialize_potential_values_gpu(Harmonic *harmonic)  // harmonic_model_gpu.cu:78-110
+{
+    static const char *fn = "harmonic_initialize_potential_values_gpu";
+    if (harmonic == nullptr || harmonic->n == 0 || harmonic->m == nullptr || harmonic->u == nullptr) {
+        report(fn, "Invalid input.");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    Ctx probe;
+    if (!dims_from(harmonic, &probe)) {
+        report(fn, "Invalid input (only n = 2 and n = 3 with every m[i] >= 3 are supported).");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    Ctx *c = get_ctx(harmonic, true);
+    if (c == nullptr) {
+        report(fn, "Failed to allocate device-side memory for the potential values.");
+        return EPIC_ERROR_DEVICE_MALLOC;
+    }
+    if (c->maskw && !same_dims(harmonic, c)) {
+        report(fn, "Invalid input (dimensions differ from the locked cells already on the device).");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    for (float *&b : c->buf) { if (b) (void)hipFree(b); b = nullptr; }
+    dims_from(harmonic, c);
+    for (int b = 0; b < 2; b++) {
+        if (hipMalloc((void **)&c->buf[b], c->u_bytes()) != hipSuccess) {
+            (void)hipGetLastError();
+            report(fn, "Failed to allocate device-side memory for the potential values.");
+            for (float *&bb : c->buf) { if (bb) (void)hipFree(bb); bb = nullptr; }
+            harmonic->d_u = nullptr;
+            drop_ctx_if_empty(harmonic);
+            return EPIC_ERROR_DEVICE_MALLOC;
+        }
+    }
+    return upload_u(harmonic, c, fn);
+}
+
+int harmonic_uninitialize_potential_values_gpu(Harmonic *harmonic)  // harmonic_model_gpu.cu:113-126
+{
+    if (harmonic == nullptr) return EPIC_ERROR_INVALID_DATA;
+    int rc = EPIC_SUCCESS;
+    Ctx *c = find_ctx(harmonic);
+    if (c) {
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        for (float *&b : c->buf) {
+            if (b && hipFree(b) != hipSuccess) {
+                report("harmonic_uninitialize_potential_values_gpu", "Failed to free device-side memory for the potential values.");
+                rc = EPIC_ERROR_DEVICE_FREE;
+            }
+            b = nullptr;
+        }
+    }
+    harmonic->d_u = nullptr;
+    drop_ctx_if_empty(harmonic);
+    return rc;
+}
+
+int harmonic_initialize_locked_gpu(Harmonic *harmonic)  // harmonic_model_gpu.cu:129-161
+{
+    static const char *fn = "harmonic_initialize_locked_gpu";
+    if (harmonic == nullptr || harmonic->n == 0 || harmonic->m == nullptr || harmonic->locked == nullptr) {
+        report(fn, "Invalid input.");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    Ctx probe;
+    if (!dims_from(harmonic, &probe)) {
+        report(fn, "Invalid input (only n = 2 and n = 3 with every m[i] >= 3 are supported).");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    Ctx *c = get_ctx(harmonic, true);
+    if (c == nullptr) {
+        report(fn, "Failed to allocate device-side memory for the locked cells.");
+        return EPIC_ERROR_DEVICE_MALLOC;
+    }
+    if (c->buf[0] && !same_dims(harmonic, c)) {
+        report(fn, "Invalid input (dimensions differ from the potential values already on the device).");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    if (c->maskw) { (void)hipFree(c->maskw); c->maskw = nullptr; }
+    dims_from(harmonic, c);
+    if (hipMalloc((void **)&c->maskw, c->mask_bytes()) != hipSuccess) {
+        (void)hipGetLastError();
+        report(fn, "Failed to allocate device-side memory for the locked cells.");
+        harmonic->d_locked = nullptr;
+        drop_ctx_if_empty(harmonic);
+        return EPIC_ERROR_DEVICE_MALLOC;
+    }
+    int rc = upload_locked(harmonic, c, fn);
+    if (rc == EPIC_SUCCESS) harmonic->d_locked = c->maskw;
+    return rc;
+}
+
+int harmonic_uninitialize_locked_gpu(Harmonic *harmonic)  // harmonic_model_gpu.cu:164-177
+{
+    if (harmonic == nullptr) return EPIC_ERROR_INVALID_DATA;
+    int rc = EPIC_SUCCESS;
+    Ctx *c = find_ctx(harmonic);
+    if (c && c->maskw) {
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        if (hipFree(c->maskw) != hipSuccess) {
+            report("harmonic_uninitialize_locked_gpu", "Failed to free device-side memory for the locked cells.");
+            rc = EPIC_ERROR_DEVICE_FREE;
+        }
+        c->maskw = nullptr;
+    }
+    harmonic->d_locked = nullptr;
+    drop_ctx_if_empty(harmonic);
+    return rc;
+}
+
+int harmonic_update_model_gpu(Harmonic *harmonic)  // harmonic_model_gpu.cu:172-204
+{
+    static const char *fn = "harmonic_update_model_gpu";
+    if (harmonic == nullptr || harmonic->n == 0 || harmonic->m == nullptr || harmonic->u == nullptr ||
+        harmonic->d_u == nullptr || harmonic->locked == nullptr || harmonic->d_locked == nullptr) {
+        report(fn, "Invalid data.");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    Ctx *c = find_ctx(harmonic);
+    if (!ready(harmonic, c) || !same_dims(harmonic, c)) {
+        report(fn, "Invalid data.");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return EPIC_ERROR_DEVICE_SYNCHRONIZE;
+    int rc = upload_u(harmonic, c, fn);
+    if (rc != EPIC_SUCCESS) return rc;
+    return upload_locked(harmonic, c, fn);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// solver drivers (reference: libepic/src/harmonic/harmonic_gpu.cu)
+// ---------------------------------------------------------------------------------------------------------
+
+int harmonic_initialize_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmonic_gpu.cu:204-223
+{
+    static const char *fn = "harmonic_initialize_gpu";
+    (void)numThreads;
+    if (harmonic == nullptr || harmonic->n == 0 || harmonic->m == nullptr || harmonic->d_delta != nullptr) {
+        report(fn, "Invalid input.");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    Ctx *c = get_ctx(harmonic, true);
+    if (c == nullptr) {
+        report(fn, "Failed to allocate device-side memory for delta.");
+        return EPIC_ERROR_DEVICE_MALLOC;
+    }
+    if (c->d_delta) { (void)hipFree(c->d_delta); c->d_delta = nullptr; }
+    if (hipMalloc((void **)&c->d_delta, 64) != hipSuccess) {
+        (void)hipGetLastError();
+        report(fn, "Failed to allocate device-side memory for delta.");
+        drop_ctx_if_empty(harmonic);
+        return EPIC_ERROR_DEVICE_MALLOC;
+    }
+    harmonic->d_delta = reinterpret_cast<float *>(c->d_delta);
+    return EPIC_SUCCESS;
+}
+
+int harmonic_uninitialize_gpu(Harmonic *harmonic)  // harmonic_gpu.cu:307-324
+{
+    if (harmonic == nullptr) return EPIC_ERROR_INVALID_DATA;
+    int rc = EPIC_SUCCESS;
+    Ctx *c = find_ctx(harmonic);
+    if (c && c->d_delta) {
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        if (hipFree(c->d_delta) != hipSuccess) {
+            report("harmonic_uninitialize_gpu", "Failed to free device-side memory for delta.");
+            rc = EPIC_ERROR_DEVICE_FREE;
+        }
+        c->d_delta = nullptr;
+    }
+    harmonic->d_delta = nullptr;
+    drop_ctx_if_empty(harmonic);
+    return rc;
+}
+
+int harmonic_update_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmonic_gpu.cu:327-350
+{
+    static const char *fn = "harmonic_update_gpu";
+    (void)numThreads;
+    Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
+    if (!harmonic || !ready(harmonic, c)) {
+        report(fn, "Invalid data.");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    if (enqueue_sweep(c, false) != hipSuccess) {
+        report(fn, "Failed to execute the 'Jacobi update' kernel.");
+        return EPIC_ERROR_KERNEL_EXECUTION;
+    }
+    harmonic->d_u = c->buf[c->cur];
+    harmonic->currentIteration++;
+    return EPIC_SUCCESS;
+}
+
+int harmonic_update_and_check_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmonic_gpu.cu:353-415
+{
+    static const char *fn = "harmonic_update_and_check_gpu";
+    (void)numThreads;
+    Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
+    if (!harmonic || !ready(harmonic, c) || c->d_delta == nullptr || harmonic->d_delta == nullptr) {
+        report(fn, "Invalid data.");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    if (enqueue_sweep(c, true) != hipSuccess) {
+        report(fn, "Failed to execute the 'Jacobi update and check' kernel.");
+        return EPIC_ERROR_KERNEL_EXECUTION;
+    }
+    harmonic->d_u = c->buf[c->cur];
+    int rc = read_delta(harmonic, c, fn);
+    if (rc != EPIC_SUCCESS) return rc;
+    harmonic->currentIteration++;
+    return harmonic->delta < harmonic->epsilon ? EPIC_SUCCESS_AND_CONVERGED : EPIC_SUCCESS;
+}
+
+int harmonic_get_potential_values_gpu(Harmonic *harmonic)  // harmonic_gpu.cu:418-434
+{
+    static const char *fn = "harmonic_get_potential_values_gpu";
+    Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
+    if (!harmonic || harmonic->u == nullptr || !c || !c->buf[0] || harmonic->d_u == nullptr) {
+        report(fn, "Invalid data.");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) {
+        report(fn, "Failed to synchronize the device before reading the potential values.");
+        return EPIC_ERROR_DEVICE_SYNCHRONIZE;
+    }
+    if (hipMemcpy2D(harmonic->u, (size_t)c->cols * sizeof(float), c->buf[c->cur], (size_t)c->pitch * sizeof(float),
+                    (size_t)c->cols * sizeof(float), (size_t)c->rows, hipMemcpyDeviceToHost) != hipSuccess) {
+        report(fn, "Failed to copy memory from device to host for the potential values.");
+        return EPIC_ERROR_MEMCPY_TO_HOST;
+    }
+    return EPIC_SUCCESS;
+}
+
+int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmonic_gpu.cu:226-304
+{
+    static const char *fn = "harmonic_execute_gpu";
+    if (harmonic == nullptr || harmonic->m == nullptr || harmonic->u == nullptr || harmonic->locked == nullptr ||
+        harmonic->epsilon <= 0.0 || harmonic->d_m == nullptr || harmonic->d_u == nullptr ||
+        harmonic->d_locked == nullptr) {
+        report(fn, "Invalid data.");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    if (numThreads % 32 != 0) {
+        report(fn, "Must specficy a number of threads divisible by 32 (the number of threads in a warp).");
+        return EPIC_ERROR_INVALID_CUDA_PARAM;
+    }
+    if (harmonic->numIterationsToStaggerCheck == 0) {  // the reference divides by zero here (harmonic_gpu.cu:268)
+        report(fn, "Invalid data (numIterationsToStaggerCheck must be positive).");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    Ctx *c = find_ctx(harmonic);
+    if (!ready(harmonic, c)) {
+        report(fn, "Invalid data.");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+
+    harmonic->currentIteration = 0;
+    int result = harmonic_initialize_gpu(harmonic, numThreads);
+    if (result != EPIC_SUCCESS) {
+        report(fn, "Failed to initialize GPU variables.");
+        return result;
+    }
+
+    unsigned int mMax = 0;
+    for (unsigned int i = 0; i < harmonic->n; i++) mMax = std::max(mMax, harmonic->m[i]);
+    harmonic->delta = harmonic->epsilon + 1.0f;
+
+    // The reference's loop (harmonic_gpu.cu:266-290): a sweep with currentIteration % stagger == 0 is a check
+    // sweep; a plain sweep resets "converged"; exit right after a converged check with currentIteration >= mMax.
+    // The plain sweeps between two checks need no host decision, so they are enqueued back to back.
+    const unsigned stagger = harmonic->numIterationsToStaggerCheck;
+    result = EPIC_SUCCESS;
+    while (result != EPIC_SUCCESS_AND_CONVERGED || harmonic->currentIteration < mMax) {
+        if (harmonic->currentIteration % stagger == 0) {
+            result = harmonic_update_and_check_gpu(harmonic, numThreads);
+            if (result != EPIC_SUCCESS && result != EPIC_SUCCESS_AND_CONVERGED) {
+                report(fn, "Failed to perform the Jacobi update and check step.");
+                return result;
+            }
+        } else {
+            result = harmonic_update_gpu(harmonic, numThreads);
+            if (result != EPIC_SUCCESS) {
+                report(fn, "Failed to perform the Jacobi update step.");
+                return result;
+            }
+        }
+    }
+
+    result = harmonic_get_potential_values_gpu(harmonic);
+    if (result != EPIC_SUCCESS) {
+        report(fn, "Failed to get all the potential values.");
+        return result;
+    }
+    result = harmonic_uninitialize_gpu(harmonic);
+    if (result != EPIC_SUCCESS) {
+        report(fn, "Failed to uninitialize GPU variables.");
+        return result;
+    }
+    return EPIC_SUCCESS;
+}
+
+int harmonic_complete_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmonic_gpu.cu:168-201
+{
+    int result = harmonic_initialize_dimension_size_gpu(harmonic);
+    if (result != EPIC_SUCCESS) return result;
+    result = harmonic_initialize_potential_values_gpu(harmonic);
+    if (result != EPIC_SUCCESS) return result;
+    result = harmonic_initialize_locked_gpu(harmonic);
+    if (result != EPIC_SUCCESS) return result;
+
+    result = harmonic_execute_gpu(harmonic, numThreads);
+    if (result != EPIC_SUCCESS) return result;
+
+    result = EPIC_SUCCESS;
+    if (harmonic_uninitialize_dimension_size_gpu(harmonic) != EPIC_SUCCESS) result = EPIC_ERROR_DEVICE_FREE;
+    if (harmonic_uninitialize_potential_values_gpu(harmonic) != EPIC_SUCCESS) result = EPIC_ERROR_DEVICE_FREE;
+    if (harmonic_uninitialize_locked_gpu(harmonic) != EPIC_SUCCESS) result = EPIC_ERROR_DEVICE_FREE;
+    return result;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// sparse edits on the resident state (reference: libepic/src/harmonic/harmonic_utilities_gpu.cu:66-138)
+// ---------------------------------------------------------------------------------------------------------
+
+int harmonic_utilities_set_cells_2d_gpu(Harmonic *harmonic, unsigned int numThreads, unsigned int k, unsigned int *v,
+                                        unsigned int *types)
+{
+    static const char *fn = "harmonic_utilities_set_cells_2d_gpu";
+    (void)numThreads;
+    if (harmonic == nullptr || harmonic->n == 0 || harmonic->m == nullptr || harmonic->u == nullptr ||
+        harmonic->locked == nullptr || k == 0 || v == nullptr || types == nullptr) {
+        report(fn, "Invalid data.");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    Ctx *c = find_ctx(harmonic);
+    if (!ready(harmonic, c) || c->n != 2) {
+        report(fn, "Invalid data.");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    unsigned *d_v = nullptr, *d_types = nullptr;
+    int rc = EPIC_SUCCESS;
+    if (hipMalloc((void **)&d_v, 2 * (size_t)k * sizeof(unsigned)) != hipSuccess ||
+        hipMalloc((void **)&d_types, (size_t)k * sizeof(unsigned)) != hipSuccess) {
+        (void)hipGetLastError();
+        report(fn, "Failed to allocate device-side memory for the cell locations and types.");
+        rc = EPIC_ERROR_DEVICE_MALLOC;
+    } else if (hipMemcpyAsync(d_v, v, 2 * (size_t)k * sizeof(unsigned), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+               hipMemcpyAsync(d_types, types, (size_t)k * sizeof(unsigned), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+        report(fn, "Failed to copy memory from host to device for the cell locations and types.");
+        rc = EPIC_ERROR_MEMCPY_TO_DEVICE;
+    } else if (epic_hip::launch_set_cells_2d(c->buf[c->cur], c->maskw, c->rows, c->cols, c->pitch, k, d_v, d_types,
+                                             c->stream) != hipSuccess) {
+        report(fn, "Failed to execute the 'set cells' kernel.");
+        rc = EPIC_ERROR_KERNEL_EXECUTION;
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess && rc == EPIC_SUCCESS) {
+        report(fn, "Failed to synchronize the device after 'set cells' kernel.");
+        rc = EPIC_ERROR_DEVICE_SYNCHRONIZE;
+    }
+    if (d_v) (void)hipFree(d_v);       // freed on every path (the reference leaks them on errors)
+    if (d_types) (void)hipFree(d_types);
+    return rc;
+}
+
+}  // extern "C"
+}  // namespace epic
+
+// ---------------------------------------------------------------------------------------------------------
+// extension entry points (include/epic_hip.h)
+// ---------------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *epic_hip_version(void) { return "epic-hip 0.1.0 gfx950"; }
+
+int epic_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int epic_hip_update_n_gpu(Harmonic *harmonic, unsigned int sweeps, int check_last)
+{
+    static const char *fn = "epic_hip_update_n_gpu";
+    Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
+    if (!harmonic || !ready(harmonic, c) || (check_last && c->d_delta == nullptr)) {
+        report(fn, "Invalid data.");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    for (unsigned s = 0; s < sweeps; s++) {
+        const bool check = check_last && s + 1 == sweeps;
+        if (enqueue_sweep(c, check) != hipSuccess) {
+            report(fn, "Failed to execute the 'Jacobi update' kernel.");
+            return EPIC_ERROR_KERNEL_EXECUTION;
+        }
+        if (!check) harmonic->currentIteration++;
+    }
+    harmonic->d_u = c->buf[c->cur];
+    if (check_last && sweeps > 0) {
+        int rc = read_delta(harmonic, c, fn);
+        if (rc != EPIC_SUCCESS) return rc;
+        harmonic->currentIteration++;
+        return harmonic->delta < harmonic->epsilon ? EPIC_SUCCESS_AND_CONVERGED : EPIC_SUCCESS;
+    }
+    return EPIC_SUCCESS;
+}
+
+int epic_hip_timed_sweeps_gpu(Harmonic *harmonic, unsigned int sweeps, unsigned int check_every, float *elapsed_ms)
+{
+    static const char *fn = "epic_hip_timed_sweeps_gpu";
+    Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
+    if (!harmonic || !elapsed_ms || !ready(harmonic, c) || (check_every && c->d_delta == nullptr)) {
+        report(fn, "Invalid data.");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return EPIC_ERROR_DEVICE_MALLOC;
+    int rc = EPIC_SUCCESS;
+    (void)hipEventRecord(e0, c->stream);
+    bool checked = false;
+    for (unsigned s = 0; s < sweeps && rc == EPIC_SUCCESS; s++) {
+        const bool check = check_every && (harmonic->currentIteration % check_every == 0);
+        if (enqueue_sweep(c, check) != hipSuccess) {
+            report(fn, "Failed to execute the 'Jacobi update' kernel.");
+            rc = EPIC_ERROR_KERNEL_EXECUTION;
+        }
+        checked |= check;
+        harmonic->currentIteration++;
+    }
+    (void)hipEventRecord(e1, c->stream);
+    harmonic->d_u = c->buf[c->cur];
+    if (rc == EPIC_SUCCESS) {
+        if (checked) rc = read_delta(harmonic, c, fn);  // the most recent check sweep's delta
+        if (hipEventSynchronize(e1) != hipSuccess) rc = EPIC_ERROR_DEVICE_SYNCHRONIZE;
+        else (void)hipEventElapsedTime(elapsed_ms, e0, e1);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+int epic_hip_set_rows_per_task(Harmonic *harmonic, unsigned int rows_per_task)
+{
+    Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
+    if (!c || rows_per_task > 65536) return EPIC_ERROR_INVALID_DATA;
+    c->rows_per_task = (int)rows_per_task;
+    return EPIC_SUCCESS;
+}
+
+int epic_hip_get_layout(Harmonic *harmonic, unsigned int *pitch, size_t *u_bytes, size_t *mask_bytes)
+{
+    Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
+    if (!c || c->pitch == 0) return EPIC_ERROR_INVALID_DATA;
+    if (pitch) *pitch = (unsigned)c->pitch;
+    if (u_bytes) *u_bytes = c->u_bytes();
+    if (mask_bytes) *mask_bytes = c->mask_bytes();
+    return EPIC_SUCCESS;
+}
+
+size_t epic_hip_mask_words_2d(unsigned int rows, unsigned int pitch) { return epic_hip::mask_words_2d((int)rows, (int)pitch); }
+unsigned int epic_hip_pitch_for_cols(unsigned int cols) { return (unsigned)epic_hip::pitch_for_cols((int)cols); }
+
+int epic_hip_pack_mask_2d(const uint32_t *d_locked, unsigned int rows, unsigned int cols, unsigned int pitch,
+                          int ghost_top, int ghost_bottom, uint32_t *d_maskw, void *stream)
+{
+    if (!d_locked || !d_maskw || rows < 3 || cols < 3 || pitch < cols || pitch % 64 != 0) return EPIC_ERROR_INVALID_DATA;
+    return epic_hip::launch_pack_mask_2d(d_locked, (int)rows, (int)cols, (int)pitch, ghost_top, ghost_bottom, d_maskw,
+                                         (hipStream_t)stream) == hipSuccess
+               ? EPIC_SUCCESS
+               : EPIC_ERROR_KERNEL_EXECUTION;
+}
+
+int epic_hip_sweep_2d(const float *d_in, float *d_out, const uint32_t *d_maskw, unsigned int rows, unsigned int pitch,
+                      unsigned int row_begin, unsigned int row_end, unsigned int rows_per_task, uint32_t *d_delta_bits,
+                      void *stream)
+{
+    if (!d_in || !d_out || !d_maskw || d_in == d_out || rows < 3 || pitch % 64 != 0 || pitch == 0 || row_end > rows ||
+        row_begin > row_end)
+        return EPIC_ERROR_INVALID_DATA;
+    if (rows_per_task == 0) rows_per_task = 32;
+    return epic_hip::launch_sweep_2d(d_in, d_out, d_maskw, (int)rows, (int)pitch, (int)row_begin, (int)row_end,
+                                     (int)rows_per_task, d_delta_bits, (hipStream_t)stream) == hipSuccess
+               ? EPIC_SUCCESS
+               : EPIC_ERROR_KERNEL_EXECUTION;
+}
+
+}  // extern "C"

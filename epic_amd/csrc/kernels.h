@@ -1,0 +1,30 @@
+// kernels.h -- internal launchers (host side) for the gfx950 kernels.  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace epic_hip {
+
+// ---- 2-D (kernels_2d.hip) -------------------------------------------------------------------
+// One Jacobi sweep of rows [row_begin, row_end) of a pitched rows x pitch grid.  delta_bits == nullptr
+// selects the plain kernel; otherwise max |du| is atomicMax'ed into *delta_bits (float bits, zero it first).
+hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int row_begin,
+                           int row_end, int rows_per_task, unsigned *delta_bits, hipStream_t stream);
+hipError_t launch_pack_mask_2d(const uint32_t *locked, int rows, int cols, int pitch, int ghost_top,
+                               int ghost_bottom, uint32_t *maskw, hipStream_t stream);
+hipError_t launch_fill(float *p, size_t n, float v, hipStream_t stream);
+hipError_t launch_set_cells_2d(float *u, uint32_t *maskw, int rows, int cols, int pitch, unsigned k,
+                               const unsigned *v, const unsigned *types, hipStream_t stream);
+
+inline int pitch_for_cols(int cols) { return (cols + 63) / 64 * 64; }
+inline size_t mask_words_2d(int rows, int pitch) { return (size_t)((rows + 7) / 8) * (size_t)(pitch / 4); }
+
+// ---- 3-D (kernels_3d.hip) -------------------------------------------------------------------
+hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, int m0, int m1, int pitch,
+                           int plane_begin, int plane_end, unsigned *delta_bits, hipStream_t stream);
+hipError_t launch_pack_mask_3d(const uint32_t *locked, int m0, int m1, int m2, int pitch, uint32_t *maskw,
+                               hipStream_t stream);
+inline size_t mask_words_3d(int m0, int m1, int pitch) { return (size_t)m0 * (size_t)m1 * (size_t)(pitch / 32); }
+
+}  // namespace epic_hip

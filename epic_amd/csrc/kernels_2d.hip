@@ -1,0 +1,266 @@
+// kernels_2d.hip -- 2-D log-space Jacobi sweep for gfx950 (MI355X), hand-written HIP.
+//
+// Replaces the reference CUDA kernels harmonic_update_2d_gpu / harmonic_update_and_check_2d_gpu /
+// harmonic_compute_max_delta_gpu (libepic/src/harmonic/harmonic_gpu.cu:39-153).  Not a translation:
+// the reference does an in-place red-black half-sweep with one block per row, stride-2 column access,
+// a uint32 mask word per cell and a second kernel + host sync for the max-delta.  Here:
+//
+//  * Jacobi ping-pong (u_in -> u_out), every cell read once and written once per sweep: 8 B / cell-update.
+//  * One wave (64 lanes) owns a 256-column strip and marches down `rows_per_task` rows.  Each lane holds
+//    4 consecutive columns as one dwordx4, so a wave-row is one fully coalesced 1 KiB load and 1 KiB store.
+//    The three live rows (up / centre / down) stay in registers while marching, so vertical neighbours cost
+//    no extra traffic; horizontal neighbours inside the strip move with one full-wave DPP shift each
+//    (v_mov_b32_dpp wave_shr:1 / wave_shl:1); the two strip-edge columns are one 2-lane halo load per row.
+//  * The obstacle/goal mask is bit-packed and tiled (8 rows x 4 columns per dword) so a lane fetches its
+//    mask once per 8 rows: +0.125 B/cell instead of the reference's +4 B/cell.
+//  * max |u_new - u_old| is reduced in registers, across the wave with shuffles, and leaves the wave as a
+//    single atomicMax on the float's bit pattern (valid order for non-negative floats).  No second kernel.
+//  * blockIdx is remapped so that each XCD sweeps a contiguous band of rows: vertically adjacent tasks share
+//    their two halo rows through that XCD's L2.
+//
+// Roofline: HBM.  ~45 VALU-slots per cell (4 v_exp_f32 + 1 v_log_f32 at quarter rate) keep it memory-bound.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cell_update.h"
+#include "kernels.h"
+
+namespace epic_hip {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kColsPerLane = 4;
+constexpr int kStripCols = kWave * kColsPerLane;  // 256
+constexpr int kWavesPerBlock = 4;
+constexpr int kNumXcd = 8;
+
+struct Sweep2dArgs {
+    const float *in;
+    float *out;
+    const uint32_t *maskw;  // tiled bits: word (r>>3, c>>2), bit 4*(r&7) + (c&3); 1 = locked
+    unsigned *delta_bits;   // max |du| as float bits (atomicMax), used when CHECK
+    int rows;               // rows of the (local) grid, including ghost rows in slab mode
+    int pitch;              // floats per row, multiple of 64
+    int row_begin, row_end; // rows swept by this launch
+    int rows_per_task;
+    int nstrips;            // ceil(pitch / 256)
+    int ntasks;             // nstrips * nchunks
+};
+
+// Blocks are dealt round-robin over the 8 XCDs (b % 8 labels the XCD group).  Give each group a
+// contiguous range of logical block ids; bijective for any grid size.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_contiguous_block(int b, int nblk)
+{
+    int x = b % kNumXcd, i = b / kNumXcd;
+    int q = nblk / kNumXcd, rem = nblk % kNumXcd;
+    return x * q + (x < rem ? x : rem) + i;
+}
+
+template <bool CHECK>
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2dArgs a)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    // wave-uniform quantities are forced into SGPRs: the row loop, its addresses and branches are scalar
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int task = xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
+    if (task >= a.ntasks) return;
+    const int strip = task % a.nstrips;
+    const int chunk = task / a.nstrips;
+    const int r0 = a.row_begin + chunk * a.rows_per_task;
+    const int r1 = min(r0 + a.rows_per_task, a.row_end);
+
+    const int col0 = strip * kStripCols;
+    const int col = col0 + lane * kColsPerLane;
+    const bool active = col < a.pitch;                       // pitch % 64 == 0: whole 16-lane groups drop out
+    const int lcol = active ? col : a.pitch - kColsPerLane;  // every lane keeps loading (DPP wants all lanes live)
+    const int hcol = (lane == 0) ? max(col0 - 1, 0) : min(col0 + kStripCols, a.pitch - 1);
+    const bool edge_lane = (lane == 0) | (lane == kWave - 1);
+    const int rlast = a.rows - 1;
+    const size_t pitch = (size_t)a.pitch;
+    const int qpitch = a.pitch >> 2;  // mask words per 8-row group
+    const int glast = rlast >> 3;
+
+    auto ld = [&](int r) -> float4 {
+        r = min(max(r, 0), rlast);
+        const float *row = a.in + (size_t)r * pitch;
+        return *reinterpret_cast<const float4 *>(row + lcol);
+    };
+    auto ldh = [&](int r) -> float {  // lane 0: u[r][col0-1]; lane 63: u[r][col0+256]
+        float h = 0.0f;
+        r = min(max(r, 0), rlast);
+        const float *row = a.in + (size_t)r * pitch;
+        if (edge_lane) h = row[hcol];
+        return h;
+    };
+    auto ldm = [&](int g) -> uint32_t {
+        const uint32_t *row = a.maskw + (size_t)min(g, glast) * qpitch;
+        return row[lcol >> 2];
+    };
+
+    float dmax = 0.0f;
+    uint32_t mw = ldm(r0 >> 3), mw_next = ldm((r0 >> 3) + 1);
+
+    // One row: up / c / dn are rows r-1, r, r+1 of u_in, h the two strip-edge values of row r.
+    auto row_step = [&](int r, const float4 &up, const float4 &c, const float4 &dn, float h) {
+        const float lf = wave_from_left(c.w, h);   // u[r][col-1]
+        const float rt = wave_from_right(c.x, h);  // u[r][col+4]
+        const uint32_t nib = mw >> ((r & 7) * 4);
+        float4 o;
+        o.x = cell_update_2d(up.x, dn.x, lf, c.y);
+        o.y = cell_update_2d(up.y, dn.y, c.x, c.z);
+        o.z = cell_update_2d(up.z, dn.z, c.y, c.w);
+        o.w = cell_update_2d(up.w, dn.w, c.z, rt);
+        o.x = (nib & 1u) ? c.x : o.x;
+        o.y = (nib & 2u) ? c.y : o.y;
+        o.z = (nib & 4u) ? c.z : o.z;
+        o.w = (nib & 8u) ? c.w : o.w;
+        if (CHECK) {
+            dmax = max2(dmax, fabsf(c.x - o.x));
+            dmax = max2(dmax, fabsf(c.y - o.y));
+            dmax = max2(dmax, fabsf(c.z - o.z));
+            dmax = max2(dmax, fabsf(c.w - o.w));
+        }
+        float *orow = a.out + (size_t)r * pitch;
+        if (active) *reinterpret_cast<float4 *>(orow + col) = o;
+        if (((r + 1) & 7) == 0) {  // scalar branch: next 8-row mask group
+            mw = mw_next;
+            mw_next = ldm(((r + 1) >> 3) + 1);
+        }
+    };
+
+    // Software pipeline, rotated by hand over a 4-row register ring so that no register moves (and hence no
+    // vmcnt(0)) sit between a load and its use two rows later: while row r is computed, rows r+1 and r+2
+    // are already in flight.
+    float4 q0 = ld(r0 - 1), q1 = ld(r0), q2 = ld(r0 + 1), q3;
+    float h1 = ldh(r0), h2 = ldh(r0 + 1), h3, h0;
+    for (int r = r0; r < r1; r += 4) {
+        q3 = ld(r + 2); h3 = ldh(r + 2);
+        row_step(r, q0, q1, q2, h1);
+        if (r + 1 >= r1) break;
+        q0 = ld(r + 3); h0 = ldh(r + 3);
+        row_step(r + 1, q1, q2, q3, h2);
+        if (r + 2 >= r1) break;
+        q1 = ld(r + 4); h1 = ldh(r + 4);
+        row_step(r + 2, q2, q3, q0, h3);
+        if (r + 3 >= r1) break;
+        q2 = ld(r + 5); h2 = ldh(r + 5);
+        row_step(r + 3, q3, q0, q1, h0);
+    }
+
+    if (CHECK) {
+        if (!active) dmax = 0.0f;
+        dmax = wave_max(dmax);
+        if (lane == 0 && dmax > 0.0f) atomicMax(a.delta_bits, __float_as_uint(dmax));
+    }
+}
+
+// uint32-per-cell mask (the ABI's format, rows x cols, unpitched) -> tiled bits.  Border cells and the
+// padding beyond `cols` / `rows` are forced locked (harmonic.h:35-37 "assumes border values are locked").
+__global__ void pack_mask_2d_kernel(const uint32_t *locked, int rows, int cols, int pitch, int ghost_top,
+                                    int ghost_bottom, uint32_t *maskw, int ngroups)
+{
+    const int qpitch = pitch >> 2;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.y;
+    if (q >= qpitch || g >= ngroups) return;
+    uint32_t w = 0;
+    for (int rr = 0; rr < 8; ++rr) {
+        const int r = g * 8 + rr;
+        for (int cc = 0; cc < 4; ++cc) {
+            const int cidx = q * 4 + cc;
+            bool lk = true;
+            const bool ghost = (ghost_top && r == 0) || (ghost_bottom && r == rows - 1);
+            const bool border = (!ghost_top && r == 0) || (!ghost_bottom && r == rows - 1) || cidx == 0 || cidx == cols - 1;
+            if (r < rows && cidx < cols && !border && !ghost) lk = locked[(size_t)r * cols + cidx] != 0;
+            w |= (lk ? 1u : 0u) << (rr * 4 + cc);
+        }
+    }
+    maskw[(size_t)g * qpitch + q] = w;
+}
+
+__global__ void fill_kernel(float *p, size_t n, float v)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+// Sparse edits (harmonic_utilities_gpu.cu:38-63): one thread per edit, into the CURRENT buffer and the
+// tiled mask.  Border cells stay locked in the mask whatever the edit says (the sweep never updates them).
+__global__ void set_cells_2d_kernel(float *u, uint32_t *maskw, int rows, int cols, int pitch, unsigned k,
+                                    const unsigned *v, const unsigned *types)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const unsigned x = v[2 * i], y = v[2 * i + 1];
+    if (y >= (unsigned)rows || x >= (unsigned)cols) return;
+    const unsigned t = types[i];
+    if (t > 2u) return;
+    const float val = (t == 0u) ? 0.0f : -1e6f;
+    const bool lock = (t != 2u) || x == 0 || y == 0 || x == (unsigned)cols - 1 || y == (unsigned)rows - 1;
+    u[(size_t)y * pitch + x] = val;
+    uint32_t *w = maskw + (size_t)(y >> 3) * (pitch >> 2) + (x >> 2);
+    const uint32_t bit = 1u << ((y & 7) * 4 + (x & 3));
+    if (lock) atomicOr(w, bit);
+    else atomicAnd(w, ~bit);
+}
+
+}  // namespace
+
+hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int row_begin,
+                           int row_end, int rows_per_task, unsigned *delta_bits, hipStream_t stream)
+{
+    if (row_end <= row_begin) return hipSuccess;
+    if (pitch <= 0 || (pitch % 64) != 0 || rows <= 0 || row_begin < 0 || row_end > rows || rows_per_task <= 0)
+        return hipErrorInvalidValue;
+    Sweep2dArgs a;
+    a.in = in;
+    a.out = out;
+    a.maskw = maskw;
+    a.delta_bits = delta_bits;
+    a.rows = rows;
+    a.pitch = pitch;
+    a.row_begin = row_begin;
+    a.row_end = row_end;
+    a.rows_per_task = rows_per_task;
+    a.nstrips = (pitch + kStripCols - 1) / kStripCols;
+    const int nchunks = (row_end - row_begin + rows_per_task - 1) / rows_per_task;
+    a.ntasks = a.nstrips * nchunks;
+    const int nblocks = (a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (delta_bits)
+        hipLaunchKernelGGL(sweep2d_kernel<true>, dim3(nblocks), dim3(kWave * kWavesPerBlock), 0, stream, a);
+    else
+        hipLaunchKernelGGL(sweep2d_kernel<false>, dim3(nblocks), dim3(kWave * kWavesPerBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_mask_2d(const uint32_t *locked, int rows, int cols, int pitch, int ghost_top,
+                               int ghost_bottom, uint32_t *maskw, hipStream_t stream)
+{
+    const int ngroups = (rows + 7) / 8;
+    const int qpitch = pitch / 4;
+    dim3 grid((qpitch + 255) / 256, ngroups);
+    hipLaunchKernelGGL(pack_mask_2d_kernel, grid, dim3(256), 0, stream, locked, rows, cols, pitch, ghost_top,
+                       ghost_bottom, maskw, ngroups);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill(float *p, size_t n, float v, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, stream, p, n, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_set_cells_2d(float *u, uint32_t *maskw, int rows, int cols, int pitch, unsigned k,
+                               const unsigned *v, const unsigned *types, hipStream_t stream)
+{
+    if (k == 0) return hipSuccess;
+    hipLaunchKernelGGL(set_cells_2d_kernel, dim3((k + 255) / 256), dim3(256), 0, stream, u, maskw, rows, cols, pitch, k,
+                       v, types);
+    return hipGetLastError();
+}
+
+}  // namespace epic_hip

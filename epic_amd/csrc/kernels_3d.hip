@@ -1,0 +1,190 @@
+// kernels_3d.hip -- 3-D (n = 3) log-space Jacobi sweep for gfx950, 7-point stencil.
+//
+// The reference has no GPU code for n = 3 (the branches are empty: libepic/src/harmonic/harmonic_gpu.cu:160-162,
+// :334-336, :367-369); the arithmetic follows its CPU sweep (libepic/src/harmonic/harmonic_cpu.cpp:81-133):
+// neighbours in the order x0-1, x0+1, x1-1, x1+1, x2-1, x2+1, constant log(6.0).
+//
+// Layout: u[x0][x1][x2] with x2 contiguous and padded to `pitch` (multiple of 64 floats).  A wave owns 256 x2-columns
+// (4 per lane, one dwordx4) of one x0-plane and marches along x1, keeping rows x1-1 / x1 / x1+1 of its plane in
+// registers; x2 neighbours are full-wave DPP shifts; the rows of planes x0-1 and x0+1 are loaded per step.  The four
+// waves of a workgroup sweep four consecutive planes of the same (x1-chunk, strip), so those extra rows are the
+// sibling waves' centre rows and are served by the CU's L1 / the XCD's L2 rather than HBM.
+// Mask: 1 bit per cell, 32 consecutive x2 cells per word.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cell_update.h"
+#include "kernels.h"
+
+namespace epic_hip {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kStripCols = 256;
+constexpr int kWavesPerBlock = 4;  // = consecutive planes per workgroup
+constexpr int kRowsPerTask = 32;
+
+struct Sweep3dArgs {
+    const float *in;
+    float *out;
+    const uint32_t *maskw;
+    unsigned *delta_bits;
+    int m0, m1, pitch;
+    int plane_begin, plane_end;
+    int nstrips, nchunks, nplane_groups;
+};
+
+template <bool CHECK>
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3dArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    int b = blockIdx.x;
+    const int strip = b % a.nstrips;
+    b /= a.nstrips;
+    const int chunk = b % a.nchunks;
+    const int pg = b / a.nchunks;
+    const int x0 = a.plane_begin + pg * kWavesPerBlock + wave;
+    if (x0 >= a.plane_end) return;  // wave-uniform
+    const int r0 = chunk * kRowsPerTask;
+    const int r1 = min(r0 + kRowsPerTask, a.m1);
+
+    const int col0 = strip * kStripCols;
+    const int col = col0 + lane * 4;
+    const bool active = col < a.pitch;
+    const int lcol = active ? col : a.pitch - 4;
+    const int hcol = (lane == 0) ? max(col0 - 1, 0) : min(col0 + kStripCols, a.pitch - 1);
+    const bool edge_lane = (lane == 0) | (lane == 63);
+    const size_t pitch = (size_t)a.pitch;
+    const size_t plane = (size_t)a.m1 * pitch;
+    const int wpitch = a.pitch >> 5;
+
+    const float *pc = a.in + (size_t)x0 * plane;
+    const float *pa = a.in + (size_t)max(x0 - 1, 0) * plane;
+    const float *pb = a.in + (size_t)min(x0 + 1, a.m0 - 1) * plane;
+    const int rlast = a.m1 - 1;
+
+    auto ld = [&](const float *p, int r) -> float4 {
+        r = min(max(r, 0), rlast);
+        return *reinterpret_cast<const float4 *>(p + (size_t)r * pitch + lcol);
+    };
+    auto ldh = [&](int r) -> float {
+        float h = 0.0f;
+        r = min(max(r, 0), rlast);
+        if (edge_lane) h = pc[(size_t)r * pitch + hcol];
+        return h;
+    };
+    auto ldm = [&](int r) -> uint32_t {
+        r = min(r, rlast);
+        return a.maskw[((size_t)x0 * a.m1 + r) * wpitch + (lcol >> 5)];
+    };
+
+    float4 up = ld(pc, r0 - 1), c = ld(pc, r0), d1 = ld(pc, r0 + 1);
+    float4 a1 = ld(pa, r0), b1 = ld(pb, r0);
+    float hc = ldh(r0), h1 = ldh(r0 + 1);
+    uint32_t mw = ldm(r0);
+    float dmax = 0.0f;
+
+    for (int r = r0; r < r1; ++r) {
+        const float4 d2 = ld(pc, r + 2);
+        const float4 a2 = ld(pa, r + 1), b2 = ld(pb, r + 1);
+        const float h2 = ldh(r + 2);
+        const uint32_t mw2 = ldm(r + 1);
+
+        const float lf = wave_from_left(c.w, hc);
+        const float rt = wave_from_right(c.x, hc);
+        const uint32_t nib = mw >> (lcol & 31);
+
+        float4 o;
+        o.x = cell_update_3d(a1.x, b1.x, up.x, d1.x, lf, c.y);
+        o.y = cell_update_3d(a1.y, b1.y, up.y, d1.y, c.x, c.z);
+        o.z = cell_update_3d(a1.z, b1.z, up.z, d1.z, c.y, c.w);
+        o.w = cell_update_3d(a1.w, b1.w, up.w, d1.w, c.z, rt);
+        o.x = (nib & 1u) ? c.x : o.x;
+        o.y = (nib & 2u) ? c.y : o.y;
+        o.z = (nib & 4u) ? c.z : o.z;
+        o.w = (nib & 8u) ? c.w : o.w;
+        if (CHECK) {
+            dmax = max2(dmax, fabsf(c.x - o.x));
+            dmax = max2(dmax, fabsf(c.y - o.y));
+            dmax = max2(dmax, fabsf(c.z - o.z));
+            dmax = max2(dmax, fabsf(c.w - o.w));
+        }
+        if (active) *reinterpret_cast<float4 *>(a.out + (size_t)x0 * plane + (size_t)r * pitch + col) = o;
+
+        up = c; c = d1; d1 = d2;
+        a1 = a2; b1 = b2;
+        hc = h1; h1 = h2;
+        mw = mw2;
+    }
+
+    if (CHECK) {
+        if (!active) dmax = 0.0f;
+        dmax = wave_max(dmax);
+        if (lane == 0 && dmax > 0.0f) atomicMax(a.delta_bits, __float_as_uint(dmax));
+    }
+}
+
+// uint32-per-cell mask (m0 x m1 x m2, unpitched) -> 1 bit per cell, 32 x2-cells per word; faces and padding locked.
+__global__ void pack_mask_3d_kernel(const uint32_t *locked, int m0, int m1, int m2, int pitch, uint32_t *maskw)
+{
+    const int wpitch = pitch >> 5;
+    const size_t nwords = (size_t)m0 * m1 * wpitch;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwords) return;
+    const int w = (int)(i % wpitch);
+    const size_t row = i / wpitch;
+    const int x1 = (int)(row % m1);
+    const int x0 = (int)(row / m1);
+    const bool face01 = x0 == 0 || x0 == m0 - 1 || x1 == 0 || x1 == m1 - 1;
+    uint32_t bits = 0;
+    for (int k = 0; k < 32; ++k) {
+        const int x2 = w * 32 + k;
+        bool lk = true;
+        if (!face01 && x2 > 0 && x2 < m2 - 1) lk = locked[((size_t)x0 * m1 + x1) * m2 + x2] != 0;
+        bits |= (lk ? 1u : 0u) << k;
+    }
+    maskw[i] = bits;
+}
+
+}  // namespace
+
+hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, int m0, int m1, int pitch,
+                           int plane_begin, int plane_end, unsigned *delta_bits, hipStream_t stream)
+{
+    if (plane_end <= plane_begin) return hipSuccess;
+    if (pitch <= 0 || (pitch % 64) != 0 || m0 <= 0 || m1 <= 0 || plane_begin < 0 || plane_end > m0)
+        return hipErrorInvalidValue;
+    Sweep3dArgs a;
+    a.in = in;
+    a.out = out;
+    a.maskw = maskw;
+    a.delta_bits = delta_bits;
+    a.m0 = m0;
+    a.m1 = m1;
+    a.pitch = pitch;
+    a.plane_begin = plane_begin;
+    a.plane_end = plane_end;
+    a.nstrips = (pitch + kStripCols - 1) / kStripCols;
+    a.nchunks = (m1 + kRowsPerTask - 1) / kRowsPerTask;
+    a.nplane_groups = (plane_end - plane_begin + kWavesPerBlock - 1) / kWavesPerBlock;
+    const long long nblocks = (long long)a.nstrips * a.nchunks * a.nplane_groups;
+    if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (delta_bits)
+        hipLaunchKernelGGL(sweep3d_kernel<true>, dim3((unsigned)nblocks), dim3(kWave * kWavesPerBlock), 0, stream, a);
+    else
+        hipLaunchKernelGGL(sweep3d_kernel<false>, dim3((unsigned)nblocks), dim3(kWave * kWavesPerBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_mask_3d(const uint32_t *locked, int m0, int m1, int m2, int pitch, uint32_t *maskw,
+                               hipStream_t stream)
+{
+    const size_t nwords = mask_words_3d(m0, m1, pitch);
+    hipLaunchKernelGGL(pack_mask_3d_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, stream, locked, m0, m1,
+                       m2, pitch, maskw);
+    return hipGetLastError();
+}
+
+}  // namespace epic_hip

@@ -1,0 +1,67 @@
+/*
+ * epic_hip.h -- extension entry points of the MI355X-native libepic.so (plain C ABI).
+ *
+ * The reference ABI (include/epic/epic_abi.h) has no notion of streams, batches of sweeps, timing or
+ * more than one GPU.  These additions sit beside it for callers that want them (bench.py, the slab
+ * decomposition driver epic_amd/slab.py, a ROS node that wants "k sweeps" in one call); nothing in the
+ * reference ABI depends on them.  All pointers named d_* are device pointers on the current HIP device;
+ * `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ */
+#ifndef EPIC_HIP_H
+#define EPIC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+namespace epic { struct Harmonic; }
+typedef epic::Harmonic EpicHarmonicT;
+extern "C" {
+#else
+struct Harmonic;
+typedef struct Harmonic EpicHarmonicT;
+#endif
+
+/* "epic-hip <semver> gfx950" */
+const char *epic_hip_version(void);
+/* Number of HIP devices visible (0 on a GPU-less host; never fails). */
+int epic_hip_device_count(void);
+
+/* ---- batches on an initialised Harmonic (device state created by harmonic_initialize_*_gpu) ----------
+ * Enqueue `sweeps` Jacobi sweeps without a host round-trip; currentIteration advances by `sweeps`.
+ * If check_last != 0 the last sweep also reduces max|du| and the call synchronises, stores it in
+ * harmonic->delta and returns EPIC_SUCCESS_AND_CONVERGED when delta < epsilon (needs harmonic_initialize_gpu).
+ * Otherwise it returns after enqueueing (ordering points: any *_and_check, get_potential_values, update_model,
+ * set_cells, uninitialize).  Replaces a loop over harmonic_update_gpu (libepic/src/harmonic/harmonic_gpu.cu:327-350),
+ * e.g. the navigation node's update(num_steps) (src/epic_navigation_node_harmonic.cpp:165-189). */
+int epic_hip_update_n_gpu(EpicHarmonicT *harmonic, unsigned int sweeps, int check_last);
+
+/* Same, bracketed by HIP events on the library's own stream; *elapsed_ms = device time of the batch.
+ * Synchronises.  check_every = 0: no checks; k > 0: every k-th sweep (counted by currentIteration % k == 0,
+ * the reference's rule, harmonic_gpu.cu:268) is a check sweep. */
+int epic_hip_timed_sweeps_gpu(EpicHarmonicT *harmonic, unsigned int sweeps, unsigned int check_every,
+                              float *elapsed_ms);
+
+/* Tuning knob: rows marched by one wave in the 2-D kernel (0 = automatic).  Also EPIC_HIP_ROWS_PER_TASK. */
+int epic_hip_set_rows_per_task(EpicHarmonicT *harmonic, unsigned int rows_per_task);
+
+/* Geometry of the device-resident state: pitch in floats, bytes of one u buffer, bytes of the packed mask. */
+int epic_hip_get_layout(EpicHarmonicT *harmonic, unsigned int *pitch, size_t *u_bytes, size_t *mask_bytes);
+
+/* ---- raw operators on caller-owned device memory (slab decomposition / multi-process drivers) ----------
+ * 2-D grid of `rows` x `pitch` floats (pitch % 64 == 0, rows include any ghost rows); the mask is the tiled
+ * bit layout produced by epic_hip_pack_mask_2d (epic_hip_mask_words_2d(rows, pitch) uint32 words).
+ * epic_hip_sweep_2d sweeps rows [row_begin, row_end) from d_in to d_out; if d_delta_bits != NULL the max |du|
+ * of those rows is atomically max-ed into it as float bits (zero it first).  Asynchronous on `stream`. */
+size_t epic_hip_mask_words_2d(unsigned int rows, unsigned int pitch);
+unsigned int epic_hip_pitch_for_cols(unsigned int cols);
+int epic_hip_pack_mask_2d(const uint32_t *d_locked, unsigned int rows, unsigned int cols, unsigned int pitch,
+                          int ghost_top, int ghost_bottom, uint32_t *d_maskw, void *stream);
+int epic_hip_sweep_2d(const float *d_in, float *d_out, const uint32_t *d_maskw, unsigned int rows,
+                      unsigned int pitch, unsigned int row_begin, unsigned int row_end, unsigned int rows_per_task,
+                      uint32_t *d_delta_bits, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPIC_HIP_H */

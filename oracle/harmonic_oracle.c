@@ -1,0 +1,319 @@
+/*
+ * harmonic_oracle.c -- CPU ORACLE for the log-space harmonic relaxation path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library.  Nothing under epic_amd/ links,
+ * imports or calls it; the shipped libepic.so has its own sources under epic_amd/csrc/.
+ *
+ * It restates, in plain C, the algorithm of the reference's CPU solver
+ * (/root/reference/libepic/src/harmonic/harmonic_cpu.cpp) so that a checker exists on
+ * the GPU box, where /root/reference does not.  Every function cites the reference
+ * lines it follows.  Parity status: PINNED -- tests/test_oracle_vs_ref.py compares it
+ * bit for bit with the reference sources compiled here into oracle/_ref/ (see Makefile)
+ * and tests/test_oracle_golden.py with the committed vectors in tests/golden/ that were
+ * produced by that reference build (tests/golden/generate_goldens.py).
+ *
+ * Build: gcc -O3 -std=c11 -shared -fPIC (NO -ffast-math, NO -march=native: the
+ * reference is built with plain -O3, libepic/Makefile:1-21, and its rounding sequence
+ * is what parity is defined on).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* Same layout as the reference's struct (libepic/include/epic/harmonic/harmonic.h:44-64):
+ * 80 bytes on x86-64 SysV. */
+typedef struct OracleHarmonic {
+    unsigned int n;
+    unsigned int *m;
+    float *u;
+    unsigned int *locked;
+    float epsilon;
+    float delta;
+    unsigned int numIterationsToStaggerCheck;
+    unsigned int currentIteration;
+    unsigned int *d_m;
+    float *d_u;
+    unsigned int *d_locked;
+    float *d_delta;
+} OracleHarmonic;
+
+#define ORACLE_SUCCESS 0
+#define ORACLE_SUCCESS_AND_CONVERGED 1
+#define ORACLE_ERROR_INVALID_DATA 2
+
+static inline float fmax2(float a, float b) { return a < b ? b : a; } /* std::max(a,b) */
+
+/* ---- the per-cell update --------------------------------------------------------
+ * harmonic_cpu.cpp:60-70 (2-D) and :110-123 (3-D).  Rounding sequence, spelled out:
+ *   mx = max over neighbours                          (float)
+ *   s  = ((expf(a-mx) + expf(b-mx)) + expf(c-mx)) + expf(d-mx) [+ ...]   (float, left-assoc)
+ *   t  = mx + logf(s)                                 (float)
+ *   u  = (float)((double)t - log(2.0 * n))            (double subtract, then round)
+ */
+static inline float cell_update_2d(float up, float down, float left, float right)
+{
+    float mx = fmax2(up, down);
+    mx = fmax2(mx, left);
+    mx = fmax2(mx, right);
+    float s = expf(up - mx) + expf(down - mx) + expf(left - mx) + expf(right - mx);
+    float t = mx + logf(s);
+    return (float)((double)t - log(2.0 * 2));
+}
+
+static inline float cell_update_3d(float a0, float a1, float b0, float b1, float c0, float c1)
+{
+    float mx = fmax2(a0, a1);
+    mx = fmax2(mx, b0);
+    mx = fmax2(mx, b1);
+    mx = fmax2(mx, c0);
+    mx = fmax2(mx, c1);
+    float s = expf(a0 - mx) + expf(a1 - mx) + expf(b0 - mx) + expf(b1 - mx) + expf(c0 - mx) + expf(c1 - mx);
+    float t = mx + logf(s);
+    return (float)((double)t - log(2.0 * 3));
+}
+
+/* ---- red-black half-sweeps (the reference's scheme) ------------------------------ */
+
+/* harmonic_cpu.cpp:38-78.  Returns the number of cells recomputed. */
+static uint64_t rb_update_2d(OracleHarmonic *h, int check)
+{
+    const unsigned int m0 = h->m[0], m1 = h->m[1];
+    uint64_t updates = 0;
+    if (check) h->delta = 0.0f;
+    for (unsigned int x0 = 1; x0 + 1 < m0; x0++) {
+        unsigned int offset = (unsigned int)((h->currentIteration % 2) != (x0 % 2));
+        for (unsigned int x1 = 1 + offset; x1 + 1 < m1; x1 += 2) {
+            size_t c = (size_t)x0 * m1 + x1;
+            if (h->locked[c]) continue;
+            float prev = h->u[c];
+            float v = cell_update_2d(h->u[c - m1], h->u[c + m1], h->u[c - 1], h->u[c + 1]);
+            h->u[c] = v;
+            updates++;
+            if (check) h->delta = fmax2(h->delta, (float)fabs(prev - v));
+        }
+    }
+    return updates;
+}
+
+/* harmonic_cpu.cpp:81-133. */
+static uint64_t rb_update_3d(OracleHarmonic *h, int check)
+{
+    const unsigned int m0 = h->m[0], m1 = h->m[1], m2 = h->m[2];
+    const size_t s0 = (size_t)m1 * m2, s1 = m2;
+    uint64_t updates = 0;
+    if (check) h->delta = 0.0f;
+    for (unsigned int x0 = 1; x0 + 1 < m0; x0++) {
+        for (unsigned int x1 = 1; x1 + 1 < m1; x1++) {
+            unsigned int offset = (unsigned int)((h->currentIteration % 2) != (x0 % 2));
+            if (x1 % 2 == 0) offset = !offset;
+            for (unsigned int x2 = 1 + offset; x2 + 1 < m2; x2 += 2) {
+                size_t c = x0 * s0 + x1 * s1 + x2;
+                if (h->locked[c]) continue;
+                float prev = h->u[c];
+                float v = cell_update_3d(h->u[c - s0], h->u[c + s0], h->u[c - s1], h->u[c + s1],
+                                         h->u[c - 1], h->u[c + 1]);
+                h->u[c] = v;
+                updates++;
+                if (check) h->delta = fmax2(h->delta, (float)fabs(prev - v));
+            }
+        }
+    }
+    return updates;
+}
+
+static uint64_t g_updates; /* cells recomputed since oracle_reset_counters() */
+
+void oracle_reset_counters(void) { g_updates = 0; }
+uint64_t oracle_cell_updates(void) { return g_updates; }
+
+/* harmonic_cpu.cpp:187-200 (n == 4 is a no-op that still counts an iteration). */
+int oracle_update(OracleHarmonic *h)
+{
+    if (h->n == 2) g_updates += rb_update_2d(h, 0);
+    else if (h->n == 3) g_updates += rb_update_3d(h, 0);
+    h->currentIteration++;
+    return ORACLE_SUCCESS;
+}
+
+/* harmonic_cpu.cpp:203-220. */
+int oracle_update_and_check(OracleHarmonic *h)
+{
+    if (h->n == 2) g_updates += rb_update_2d(h, 1);
+    else if (h->n == 3) g_updates += rb_update_3d(h, 1);
+    h->currentIteration++;
+    return (h->delta < h->epsilon) ? ORACLE_SUCCESS_AND_CONVERGED : ORACLE_SUCCESS;
+}
+
+/* harmonic_cpu.cpp:136-184.  Exit only right after a check sweep that converged AND
+ * with currentIteration >= max(m[i]). */
+int oracle_complete(OracleHarmonic *h)
+{
+    if (h == NULL || h->m == NULL || h->u == NULL || h->locked == NULL || h->epsilon <= 0.0)
+        return ORACLE_ERROR_INVALID_DATA;
+    unsigned int mMax = 0;
+    for (unsigned int i = 0; i < h->n; i++) mMax = h->m[i] > mMax ? h->m[i] : mMax;
+    h->currentIteration = 0;
+    h->delta = h->epsilon + 1.0;
+    int result = ORACLE_SUCCESS;
+    while (result != ORACLE_SUCCESS_AND_CONVERGED || h->currentIteration < mMax) {
+        if (h->currentIteration % h->numIterationsToStaggerCheck == 0)
+            result = oracle_update_and_check(h);
+        else
+            result = oracle_update(h);
+    }
+    return ORACLE_SUCCESS;
+}
+
+/* ---- Jacobi sweeps: the SAME per-cell update applied to all unlocked interior cells
+ * from the previous sweep's values (what the HIP kernels do; SURVEY.md §7 shows the
+ * scheme does not move the f32 stagnation point).  Not in the reference: it exists so
+ * that fixed-sweep-count GPU results can be compared cell by cell. ------------------ */
+
+static void jacobi_sweep_2d(const OracleHarmonic *h, const float *in, float *out, float *delta)
+{
+    const unsigned int m0 = h->m[0], m1 = h->m[1];
+    float d = 0.0f;
+    memcpy(out, in, (size_t)m0 * m1 * sizeof(float));
+    for (unsigned int x0 = 1; x0 + 1 < m0; x0++) {
+        for (unsigned int x1 = 1; x1 + 1 < m1; x1++) {
+            size_t c = (size_t)x0 * m1 + x1;
+            if (h->locked[c]) continue;
+            float v = cell_update_2d(in[c - m1], in[c + m1], in[c - 1], in[c + 1]);
+            out[c] = v;
+            d = fmax2(d, (float)fabs(in[c] - v));
+            g_updates++;
+        }
+    }
+    if (delta) *delta = d;
+}
+
+static void jacobi_sweep_3d(const OracleHarmonic *h, const float *in, float *out, float *delta)
+{
+    const unsigned int m0 = h->m[0], m1 = h->m[1], m2 = h->m[2];
+    const size_t s0 = (size_t)m1 * m2, s1 = m2;
+    float d = 0.0f;
+    memcpy(out, in, (size_t)m0 * s0 * sizeof(float));
+    for (unsigned int x0 = 1; x0 + 1 < m0; x0++)
+        for (unsigned int x1 = 1; x1 + 1 < m1; x1++)
+            for (unsigned int x2 = 1; x2 + 1 < m2; x2++) {
+                size_t c = x0 * s0 + x1 * s1 + x2;
+                if (h->locked[c]) continue;
+                float v = cell_update_3d(in[c - s0], in[c + s0], in[c - s1], in[c + s1], in[c - 1], in[c + 1]);
+                out[c] = v;
+                d = fmax2(d, (float)fabs(in[c] - v));
+                g_updates++;
+            }
+    if (delta) *delta = d;
+}
+
+static size_t num_cells(const OracleHarmonic *h)
+{
+    size_t c = 1;
+    for (unsigned int i = 0; i < h->n; i++) c *= h->m[i];
+    return c;
+}
+
+/* Run `sweeps` Jacobi sweeps on h->u in place; h->delta = max |du| of the LAST sweep;
+ * currentIteration advances by `sweeps`. */
+int oracle_jacobi_run(OracleHarmonic *h, unsigned int sweeps)
+{
+    if (h == NULL || h->m == NULL || h->u == NULL || h->locked == NULL || (h->n != 2 && h->n != 3))
+        return ORACLE_ERROR_INVALID_DATA;
+    size_t cells = num_cells(h);
+    float *a = h->u, *b = (float *)malloc(cells * sizeof(float));
+    if (!b) return ORACLE_ERROR_INVALID_DATA;
+    for (unsigned int s = 0; s < sweeps; s++) {
+        if (h->n == 2) jacobi_sweep_2d(h, a, b, &h->delta);
+        else jacobi_sweep_3d(h, a, b, &h->delta);
+        float *t = a; a = b; b = t;
+        h->currentIteration++;
+    }
+    if (a != h->u) { memcpy(h->u, a, cells * sizeof(float)); free(a); }
+    else free(b);
+    return ORACLE_SUCCESS;
+}
+
+/* Jacobi driven by the reference's loop rule (harmonic_cpu.cpp:158-173): delta is
+ * looked at only on sweeps with currentIteration % stagger == 0 (before the increment). */
+int oracle_jacobi_complete(OracleHarmonic *h)
+{
+    if (h == NULL || h->m == NULL || h->u == NULL || h->locked == NULL || h->epsilon <= 0.0 ||
+        (h->n != 2 && h->n != 3) || h->numIterationsToStaggerCheck == 0)
+        return ORACLE_ERROR_INVALID_DATA;
+    size_t cells = num_cells(h);
+    unsigned int mMax = 0;
+    for (unsigned int i = 0; i < h->n; i++) mMax = h->m[i] > mMax ? h->m[i] : mMax;
+    float *a = h->u, *b = (float *)malloc(cells * sizeof(float));
+    if (!b) return ORACLE_ERROR_INVALID_DATA;
+    h->currentIteration = 0;
+    h->delta = h->epsilon + 1.0;
+    int converged = 0;
+    while (!converged || h->currentIteration < mMax) {
+        int check = (h->currentIteration % h->numIterationsToStaggerCheck) == 0;
+        float d;
+        if (h->n == 2) jacobi_sweep_2d(h, a, b, &d);
+        else jacobi_sweep_3d(h, a, b, &d);
+        float *t = a; a = b; b = t;
+        h->currentIteration++;
+        if (check) { h->delta = d; converged = d < h->epsilon; }
+        else converged = 0;
+    }
+    if (a != h->u) { memcpy(h->u, a, cells * sizeof(float)); free(a); }
+    else free(b);
+    return ORACLE_SUCCESS;
+}
+
+/* ---- sparse cell edits: harmonic_utilities_cpu.cpp:38-76 ------------------------- */
+int oracle_set_cells_2d(OracleHarmonic *h, unsigned int k, const unsigned int *v, const unsigned int *types)
+{
+    if (h == NULL || h->n == 0 || h->m == NULL || h->u == NULL || h->locked == NULL || k == 0 ||
+        v == NULL || types == NULL)
+        return ORACLE_ERROR_INVALID_DATA;
+    for (unsigned int i = 0; i < k; i++) {
+        unsigned int x = v[2 * i], y = v[2 * i + 1];
+        if (y >= h->m[0] || x >= h->m[1]) continue;
+        size_t c = (size_t)y * h->m[1] + x;
+        if (types[i] == 0) { h->u[c] = 0.0f; h->locked[c] = 1; }
+        else if (types[i] == 1) { h->u[c] = -1e6f; h->locked[c] = 1; }
+        else if (types[i] == 2) { h->u[c] = -1e6f; h->locked[c] = 0; }
+    }
+    return ORACLE_SUCCESS;
+}
+
+/* ---- synthetic occupancy grids (not in the reference) ----
+ * Counter-based hash so that C, numpy and the device generate identical maps:
+ *   h = splitmix64_mix(seed ^ (idx * 0x9E3779B97F4A7C15)); obstacle iff (h >> 11) * 2^-53 < density
+ * border cells are obstacles, the centre cell is the single goal (u = 0), the rest free (u = -1e6).
+ */
+static inline uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+void oracle_synthetic(unsigned int n, const unsigned int *m, uint64_t seed, double density, float *u,
+                      unsigned int *locked)
+{
+    size_t cells = 1, goal = 0;
+    for (unsigned int i = 0; i < n; i++) cells *= m[i];
+    for (unsigned int i = 0; i < n; i++) goal = goal * m[i] + m[i] / 2;
+    const uint64_t thresh = (uint64_t)(density * 9007199254740992.0); /* density * 2^53 */
+    for (size_t idx = 0; idx < cells; idx++) {
+        size_t r = idx;
+        int border = 0;
+        for (int i = (int)n - 1; i >= 0; i--) {
+            unsigned int x = (unsigned int)(r % m[i]);
+            r /= m[i];
+            if (x == 0 || x == m[i] - 1) border = 1;
+        }
+        uint64_t hsh = mix64(seed ^ ((uint64_t)idx * 0x9E3779B97F4A7C15ULL));
+        int obstacle = border || ((hsh >> 11) < thresh);
+        u[idx] = -1e6f;
+        locked[idx] = (unsigned int)obstacle;
+    }
+    u[goal] = 0.0f;
+    locked[goal] = 1;
+}

@@ -1,0 +1,36 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """The product library and the checker must exist before anything is imported.  Prebuilt files travel to the
+    GPU box; here they are (re)built from source when missing."""
+    lib = os.path.join(ROOT, "epic_amd", "lib", "libepic.so")
+    if not os.path.exists(lib):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "epic_amd", "csrc")], check=True)
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+
+
+@pytest.fixture(scope="session")
+def goldens():
+    import json
+
+    import numpy as np
+
+    g = os.path.join(ROOT, "tests", "golden")
+    return dict(manifest=json.load(open(os.path.join(g, "manifest.json"))),
+                small=np.load(os.path.join(g, "small_grids.npz")),
+                maps=np.load(os.path.join(g, "maps_converged.npz")))

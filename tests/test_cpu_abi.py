@@ -1,0 +1,158 @@
+"""Boundary checks that need no GPU: the library loads, exports what include/ declares, keeps the struct layout,
+and its CPU entry points (the reference's fallback path) are bit-identical to the reference's results."""
+import ctypes as ct
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from epic_amd import epic_harmonic as eh
+from epic_amd.harmonic import Harmonic
+from epic_amd.harmonic_map import HarmonicMap
+
+ROOT = O.ROOT
+
+
+def _problem(m, u, locked, eps=1e-6, stagger=100):
+    """An EpicHarmonic (product struct class) over fresh numpy arrays."""
+    h = Harmonic()
+    h.set_grid(m, u, locked)
+    h.epsilon = eps
+    h.numIterationsToStaggerCheck = stagger
+    return h
+
+
+def test_every_declared_symbol_is_exported():
+    declared = set()
+    for path in glob.glob(os.path.join(ROOT, "include", "**", "*.h"), recursive=True):
+        text = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        declared |= set(re.findall(r"\b((?:harmonic|epic_hip)_\w+)\s*\(", text))
+    assert len(declared) >= 29
+    lib = ct.CDLL(eh.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_reference_abi_symbols_present():
+    """The hot-path subset of `nm -D libepic/lib/libepic.so`."""
+    names = """harmonic_complete_cpu harmonic_update_cpu harmonic_update_and_check_cpu harmonic_complete_gpu
+    harmonic_initialize_gpu harmonic_execute_gpu harmonic_uninitialize_gpu harmonic_update_gpu
+    harmonic_update_and_check_gpu harmonic_get_potential_values_gpu harmonic_initialize_dimension_size_gpu
+    harmonic_uninitialize_dimension_size_gpu harmonic_initialize_potential_values_gpu
+    harmonic_uninitialize_potential_values_gpu harmonic_initialize_locked_gpu harmonic_uninitialize_locked_gpu
+    harmonic_update_model_gpu harmonic_utilities_set_cells_2d_cpu harmonic_utilities_set_cells_2d_gpu""".split()
+    lib = ct.CDLL(eh.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_struct_layout():
+    offs = {f[0]: getattr(eh.EpicHarmonic, f[0]).offset for f in eh.EpicHarmonic._fields_}
+    assert ct.sizeof(eh.EpicHarmonic) == 80
+    assert offs == dict(n=0, m=8, u=16, locked=24, epsilon=32, delta=36, numIterationsToStaggerCheck=40,
+                        currentIteration=44, d_m=48, d_u=56, d_locked=64, d_delta=72)
+
+
+@pytest.mark.parametrize("name", ["g2d_16", "g2d_64", "g2d_23x37", "g2d_3x3", "g2d_70x66_dense", "g3d_8",
+                                  "g3d_7x9x11", "g3d_20x12x34"])
+def test_cpu_exports_match_golden(goldens, name):
+    g, info = goldens["small"], goldens["manifest"]["small"][name]
+    m, u0, locked = g[name + "/m"], g[name + "/u0"], g[name + "/locked"]
+    for k in (1, 2, 3, 10):
+        h = _problem(m, u0, locked)
+        for i in range(k):
+            (eh._epic.harmonic_update_and_check_cpu if i == k - 1 else eh._epic.harmonic_update_cpu)(h)
+        assert np.array_equal(h.u_array().ravel(), g[f"{name}/rb{k}"])
+        assert np.float32(h.delta) == g[f"{name}/rb{k}_delta"]
+    h = _problem(m, u0, locked, info["epsilon"], info["stagger"])
+    assert eh._epic.harmonic_complete_cpu(h) == 0
+    assert h.currentIteration == info["iterations"] and float(h.delta) == info["delta"]
+    assert np.array_equal(h.u_array().ravel(), g[name + "/converged"])
+
+
+def test_cpu_exports_match_oracle_random():
+    rng = np.random.default_rng(3)
+    lib = O.oracle()
+    for trial in range(8):
+        n = 2 if trial % 2 else 3
+        m = rng.integers(3, 30 if n == 2 else 12, size=n)
+        u0, locked = O.oracle_synthetic(m, seed=trial, density=0.15)
+        a = O.Problem(m, u0, locked, 1e-4, 7)
+        h = _problem(m, u0, locked, 1e-4, 7)
+        assert lib.oracle_complete(ct.byref(a.h)) == 0 and eh._epic.harmonic_complete_cpu(h) == 0
+        assert a.h.currentIteration == h.currentIteration
+        assert np.array_equal(a.u, h.u_array().ravel())
+
+
+def test_python_solve_cpu_on_reference_map(goldens):
+    """BASELINE config 1 in miniature: image -> loader -> Harmonic.solve(process='cpu') -> golden."""
+    info = goldens["manifest"]["maps"]["basic"]
+    h = HarmonicMap().load(os.path.join(ROOT, "tests", "golden", "maps", "basic.png"))
+    assert list(h.shape) == info["m"]
+    h.solve(process="cpu", epsilon=1e-6)
+    assert h.currentIteration == info["runs"]["1e-06"]["iterations"]
+    assert np.array_equal(h.u_array().ravel(), goldens["maps"]["basic/converged_1e-06"])
+
+
+@pytest.mark.parametrize("name", ["basic", "maze", "umass"])
+def test_loader_matches_reference_rule(goldens, name):
+    import hashlib
+
+    info = goldens["manifest"]["maps"][name]
+    h = HarmonicMap().load(os.path.join(ROOT, "tests", "golden", "maps", name + ".png"))
+    assert list(h.shape) == info["m"]
+    assert hashlib.sha256(h.u_array().tobytes()).hexdigest() == info["sha_u0"]
+    assert hashlib.sha256(h.locked_array().tobytes()).hexdigest() == info["sha_locked"]
+
+
+def test_cpu_validation_codes(capfd):
+    h = Harmonic()
+    assert eh._epic.harmonic_complete_cpu(h) == eh.EPIC_ERROR_INVALID_DATA  # null arrays
+    u0, locked = O.oracle_synthetic([8, 8], 1, 0.0)
+    h = _problem([8, 8], u0, locked, eps=0.0)
+    assert eh._epic.harmonic_complete_cpu(h) == eh.EPIC_ERROR_INVALID_DATA  # epsilon <= 0
+    h = _problem([8, 8], u0, locked, eps=1e-3, stagger=0)
+    assert eh._epic.harmonic_complete_cpu(h) == eh.EPIC_ERROR_INVALID_DATA  # the reference divides by zero here
+    assert "Error[harmonic_complete_cpu]: Invalid data." in capfd.readouterr().err
+
+
+def test_n4_is_a_counting_noop():
+    """harmonic_cpu.cpp:193-195: n = 4 sweeps nothing but still advances currentIteration."""
+    h = Harmonic()
+    h.set_grid([3, 3, 3, 3], np.zeros(81, np.float32), np.zeros(81, np.uint32))
+    before = h.u_array().copy()
+    assert eh._epic.harmonic_update_cpu(h) == 0 and h.currentIteration == 1
+    assert np.array_equal(before, h.u_array())
+
+
+def test_set_cells_cpu_matches_golden(goldens, capfd):
+    g = goldens["small"]
+    h = _problem(g["set_cells/m"], g["set_cells/u0"], g["set_cells/locked0"])
+    v, t = g["set_cells/v"].astype(np.uint32), g["set_cells/types"].astype(np.uint32)
+    UP = ct.POINTER(ct.c_uint)
+    assert eh._epic.harmonic_utilities_set_cells_2d_cpu(h, len(t), v.ctypes.data_as(UP), t.ctypes.data_as(UP)) == 0
+    assert np.array_equal(h.u_array().ravel(), g["set_cells/u1"])
+    assert np.array_equal(h.locked_array().ravel(), g["set_cells/locked1"])
+    assert "Warning[harmonic_utilities_set_cells_2d_cpu]" in capfd.readouterr().err
+    assert eh._epic.harmonic_utilities_set_cells_2d_cpu(h, 0, v.ctypes.data_as(UP), t.ctypes.data_as(UP)) == 2
+
+
+def test_gpu_entry_points_fail_loudly_without_a_device(capfd):
+    """On a GPU-less host the GPU path must report the reference's code (4, EPIC_ERROR_DEVICE_MALLOC: SURVEY.md
+    §8b) -- never compute on the CPU behind the caller's back."""
+    if eh._epic.epic_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    u0, locked = O.oracle_synthetic([16, 16], 1, 0.05)
+    h = _problem([16, 16], u0, locked)
+    before = h.u_array().copy()
+    assert eh._epic.harmonic_complete_gpu(h, 1024) == eh.EPIC_ERROR_DEVICE_MALLOC
+    assert np.array_equal(before, h.u_array()) and h.currentIteration == 0
+    assert not h.d_u and not h.d_locked and not h.d_m and not h.d_delta
+    assert "Error[harmonic_initialize_dimension_size_gpu]" in capfd.readouterr().err
+    with pytest.raises(RuntimeError):
+        h.solve(process="gpu")
+    assert eh._epic.harmonic_update_gpu(h, 1024) == eh.EPIC_ERROR_INVALID_DATA

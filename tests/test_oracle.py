@@ -1,0 +1,108 @@
+"""The checker itself: oracle/harmonic_oracle.c against (a) the compiled reference when it is available and
+(b) the committed golden vectors that the reference produced (tests/golden/generate_goldens.py)."""
+import ctypes as ct
+
+import numpy as np
+import pytest
+
+import _oracle as O
+
+SMALL = ["g2d_16", "g2d_32", "g2d_64", "g2d_23x37", "g2d_5x7", "g2d_3x3", "g2d_8x300", "g2d_70x66_dense",
+         "g3d_8", "g3d_16", "g3d_7x9x11", "g3d_20x12x34"]
+
+
+def _steps(lib_update, lib_check, prob, k):
+    for i in range(k):
+        (lib_check if i == k - 1 else lib_update)(ct.byref(prob.h))
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_oracle_matches_golden_half_sweeps(goldens, name):
+    g = goldens["small"]
+    m, u0, locked = g[name + "/m"], g[name + "/u0"], g[name + "/locked"]
+    lib = O.oracle()
+    for k in (1, 2, 3, 10):
+        p = O.Problem(m, u0, locked, 1e-6, 100)
+        _steps(lib.oracle_update, lib.oracle_update_and_check, p, k)
+        assert np.array_equal(p.u, g[f"{name}/rb{k}"]), f"{name}: field after {k} half-sweeps"
+        assert np.float32(p.h.delta) == g[f"{name}/rb{k}_delta"]
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_oracle_matches_golden_converged(goldens, name):
+    g, info = goldens["small"], goldens["manifest"]["small"][name]
+    p = O.Problem(g[name + "/m"], g[name + "/u0"], g[name + "/locked"], info["epsilon"], info["stagger"])
+    assert O.oracle().oracle_complete(ct.byref(p.h)) == 0
+    assert p.h.currentIteration == info["iterations"]
+    assert float(p.h.delta) == info["delta"]
+    assert np.array_equal(p.u, g[name + "/converged"])
+
+
+def test_oracle_matches_golden_map_basic(goldens):
+    """A reference PNG map end to end (256x256, ~1 s): loader rule, iteration count, final delta, full field."""
+    info = goldens["manifest"]["maps"]["basic"]
+    m, u0, locked = O.load_png_reference_rule(O.ROOT + "/tests/golden/maps/basic.png")
+    assert m == info["m"]
+    for eps in ("0.001", "1e-06"):
+        p = O.Problem(m, u0, locked, float(eps), 100)
+        assert O.oracle().oracle_complete(ct.byref(p.h)) == 0
+        run = info["runs"][eps]
+        assert p.h.currentIteration == run["iterations"] and float(p.h.delta) == run["delta"]
+        assert np.array_equal(p.u[goldens["maps"]["basic/sample_idx"]], goldens["maps"][f"basic/samples_{eps}"])
+    assert np.array_equal(p.u, goldens["maps"]["basic/converged_1e-06"])
+
+
+def test_oracle_matches_compiled_reference_random():
+    """Bit-for-bit against oracle/_ref (the reference's own sources) on fresh random cases, incl. n = 3 and the
+    single-step entry points.  Skipped where the reference was never compiled."""
+    ref = O.ref()
+    if ref is None:
+        pytest.skip("oracle/_ref/libepic_ref.so not built (no /root/reference)")
+    lib = O.oracle()
+    rng = np.random.default_rng(7)
+    for trial in range(12):
+        n = 2 if trial % 3 else 3
+        m = rng.integers(3, 40 if n == 2 else 14, size=n)
+        u0, locked = O.oracle_synthetic(m, seed=100 + trial, density=float(rng.uniform(0, 0.35)))
+        # a few extra goals so the field is not trivially symmetric
+        free = np.flatnonzero(locked == 0)
+        if free.size:
+            extra = rng.choice(free, size=min(3, free.size), replace=False)
+            u0[extra] = 0.0
+            locked[extra] = 1
+        a = O.Problem(m, u0, locked, 1e-5, int(rng.integers(1, 20)))
+        b = a.clone()
+        assert ref.harmonic_complete_cpu(ct.byref(a.h)) == 0
+        assert lib.oracle_complete(ct.byref(b.h)) == 0
+        assert a.h.currentIteration == b.h.currentIteration and a.h.delta == b.h.delta
+        assert np.array_equal(a.u, b.u)
+        a, b = O.Problem(m, u0, locked), O.Problem(m, u0, locked)
+        for i in range(7):
+            ra = (ref.harmonic_update_and_check_cpu if i % 3 == 0 else ref.harmonic_update_cpu)(ct.byref(a.h))
+            rb = (lib.oracle_update_and_check if i % 3 == 0 else lib.oracle_update)(ct.byref(b.h))
+            assert ra == rb and np.array_equal(a.u, b.u)
+
+
+def test_oracle_set_cells_matches_golden(goldens):
+    g = goldens["small"]
+    p = O.Problem(g["set_cells/m"], g["set_cells/u0"], g["set_cells/locked0"])
+    v, t = g["set_cells/v"].astype(np.uint32), g["set_cells/types"].astype(np.uint32)
+    rc = O.oracle().oracle_set_cells_2d(ct.byref(p.h), len(t), v.ctypes.data_as(ct.POINTER(ct.c_uint)),
+                                        t.ctypes.data_as(ct.POINTER(ct.c_uint)))
+    assert rc == 0
+    assert np.array_equal(p.u, g["set_cells/u1"]) and np.array_equal(p.locked, g["set_cells/locked1"])
+
+
+def test_jacobi_and_red_black_reach_the_same_field():
+    """with the same per-cell arithmetic the sweep order does not move the f32 stagnation point.
+    This is what lets a Jacobi GPU result be compared with the red-black reference at convergence."""
+    lib = O.oracle()
+    u0, locked = O.oracle_synthetic([96, 80], seed=5, density=0.05)
+    a = O.Problem([96, 80], u0, locked, 1e-6, 10)
+    b = a.clone()
+    assert lib.oracle_complete(ct.byref(a.h)) == 0
+    assert lib.oracle_jacobi_complete(ct.byref(b.h)) == 0
+    reach = (a.locked == 0) & (a.u > -9e5)
+    assert np.array_equal(a.u <= -9e5, b.u <= -9e5)
+    rel = np.abs(a.u[reach] - b.u[reach]) / np.maximum(1.0, np.abs(a.u[reach]))
+    assert rel.max() < 2e-6
