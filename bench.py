@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: log-space harmonic relaxation throughput on MI355X.
+
+Metric (BASELINE.json): Mcell-updates/s + % of HBM peak on the synthetic 8192 x 8192 grid (5 % random obstacles,
+one goal, seed 20240601), relaxing towards epsilon = 1e-6.
+
+A *step* is one pass of the reference's driver loop over `stagger` = 100 iterations (harmonic_gpu.cu:266-290):
+one check sweep (max |du| reduced on the device, read back) followed by 99 plain Jacobi sweeps, on u resident in
+HBM.  A cell-update is one unlocked cell recomputed once.  With N > 1 (one process per GPU, launched by
+torch.distributed.run) every rank owns an 8192-row slab of an (8192 N) x 8192 grid (weak scaling) and exchanges
+one halo row with each neighbour per sweep over RCCL (epic_amd/slab.py).
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline      dominant kernel (sweep2d) vs the HBM roofline: 8 algorithmic bytes per grid cell per sweep
+                (read u once, write u once) / mean launch-to-launch device time, measured with HIP
+                events on the stream the kernels run on (epic_hip_timed_sweeps_gpu).
+  cpu_baseline  the CPU restatement of the reference solver (oracle/liboracle.so, kind "port", 1 thread -- the
+                reference is single-threaded) timed on this host for a bounded number of red-black half-sweeps of
+                the same grid.  Rank 0, N = 1 only.
+  relax         (N = 1) the complete relaxation to epsilon = 1e-6 through harmonic_execute_gpu: sweeps, seconds.
+"""
+import argparse
+import ctypes as ct
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+BYTES_PER_CELL_SWEEP = 8.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=8192, help="grid is size x size per GPU")
+    ap.add_argument("--stagger", type=int, default=100, help="sweeps per step (numIterationsToStaggerCheck)")
+    ap.add_argument("--rows-per-task", type=int, default=0)
+    ap.add_argument("--cpu-half-sweeps", type=int, default=12, help="bounded CPU sample (about 1 s each at 8192^2)")
+    ap.add_argument("--math", choices=("precise", "fast"), default="precise",
+                    help="precise = libm-equivalent exp/log (the parity mode, default); fast = v_exp_f32/v_log_f32")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-relax", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(m, u0, locked, half_sweeps):
+    """Checker leg: the reference's red-black half-sweep (port in oracle/), single thread, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+
+    lib = O.oracle()
+    p = O.Problem(m, u0, locked, 1e-6, 100)
+    lib.oracle_reset_counters()
+    t0 = time.perf_counter()
+    for i in range(half_sweeps):
+        (lib.oracle_update_and_check if i % 100 == 0 else lib.oracle_update)(ct.byref(p.h))
+    dt = time.perf_counter() - t0
+    updates = int(lib.oracle_cell_updates())
+    return dict(value=round(updates / dt / 1e6, 3), unit="Mcell-updates/s", cores=1, host_cores=os.cpu_count(),
+                kind="port", seconds=round(dt, 2),
+                sample="%d red-black half-sweeps of the same %dx%d grid (full relaxation needs ~5e4, ~15 h on one core)"
+                       % (half_sweeps, m[0], m[1]))
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch  # first: one HIP runtime per process (epic_amd/epic_harmonic.py)
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from epic_amd import epic_harmonic as eh
+    from epic_amd.synthetic import synthetic_grid
+
+    E = eh._epic
+    n = args.size
+    grid = [n * world, n]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if world == 1:
+        from epic_amd.harmonic import Harmonic
+
+        u0, locked = synthetic_grid(grid)
+        free_cells = int((locked == 0).sum())
+        h = Harmonic()
+        h.set_grid(grid, u0, locked)
+        h.epsilon = 1e-6
+        h.numIterationsToStaggerCheck = args.stagger
+        t0 = time.perf_counter()
+        for fn in (E.harmonic_initialize_dimension_size_gpu, E.harmonic_initialize_potential_values_gpu,
+                   E.harmonic_initialize_locked_gpu):
+            if fn(h) != 0:
+                sys.exit("bench.py: %s failed -- no usable GPU" % fn.__name__)
+        upload_s = time.perf_counter() - t0
+        assert E.harmonic_initialize_gpu(h, 1024) == 0
+        if args.rows_per_task:
+            E.epic_hip_set_rows_per_task(h, args.rows_per_task)
+        assert E.epic_hip_set_math_mode(h, 1 if args.math == "fast" else 0) == 0
+        ms = ct.c_float(0.0)
+
+        def step():
+            rc = E.epic_hip_timed_sweeps_gpu(h, args.stagger, args.stagger, ct.byref(ms))
+            assert rc == 0, rc
+            return ms.value
+
+        solver = None
+    else:
+        from epic_amd.slab import SlabSolver
+
+        solver = SlabSolver(grid, rank, world, device=torch.device("cuda", local), stagger=args.stagger,
+                            rows_per_task=args.rows_per_task, math=args.math)
+        free_cells = solver.load_synthetic()
+        upload_s = None
+
+        def step():
+            return solver.timed_step()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    dev_ms = 0.0
+    for _ in range(args.steps):
+        dev_ms += step()
+    barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, dev_ms = float(t[0]), float(t[1])
+        f = torch.tensor([free_cells], dtype=torch.int64, device="cuda")
+        dist.all_reduce(f)
+        free_cells = int(f[0])
+
+    sweeps = args.steps * args.stagger
+    value = free_cells * sweeps / wall / 1e6
+    launch_us = dev_ms * 1e3 / sweeps
+    cells_per_launch = n * n  # per GPU
+    achieved = BYTES_PER_CELL_SWEEP * cells_per_launch / (launch_us * 1e-6) / 1e9
+    out = {
+        "metric": "cell_updates_per_s_log_harmonic_relax_8192sq",
+        "value": round(value, 1),
+        "unit": "Mcell-updates/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(wall * 1e3 / args.steps, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "synthetic %dx%d occupancy grid per GPU, 5%% random obstacles + 1 goal (BASELINE configs[2]), "
+                        "log-space Jacobi relax towards eps=1e-6" % (n, n),
+            "grid": grid,
+            "sweeps_per_step": args.stagger,
+            "check_every": args.stagger,
+            "math": args.math,
+            "free_cells": free_cells,
+            "parallelism": "1 GPU" if world == 1 else "row slabs x%d, 1-row halo exchange per sweep over RCCL" % world,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "sweep2d_kernel",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": None,
+            "launch_us": round(launch_us, 3),
+            "bytes_per_launch": int(BYTES_PER_CELL_SWEEP * cells_per_launch),
+            "note": "8 B x grid cells per launch / mean launch-to-launch device time (HIP events on the kernel's stream)",
+        },
+    }
+
+    if world == 1:
+        if upload_s is not None:
+            out["config"]["h2d_seconds"] = round(upload_s, 3)
+        if not args.no_relax:
+            # the complete relaxation, exactly as the plugin runs it (harmonic_execute_gpu), from the initial state
+            assert E.harmonic_uninitialize_gpu(h) == 0
+            h.u_array().ravel()[:] = u0
+            assert E.harmonic_update_model_gpu(h) == 0
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rc = E.harmonic_execute_gpu(h, 1024)
+            dt = time.perf_counter() - t0
+            assert rc == 0, rc
+            out["relax"] = {"epsilon": 1e-6, "sweeps": int(h.currentIteration), "seconds": round(dt, 3),
+                            "delta": float(h.delta),
+                            "Mcell_updates_per_s": round(free_cells * h.currentIteration / dt / 1e6, 1),
+                            "note": "includes the final D2H of u"}
+        else:
+            E.harmonic_uninitialize_gpu(h)
+        for fn in (E.harmonic_uninitialize_dimension_size_gpu, E.harmonic_uninitialize_potential_values_gpu,
+                   E.harmonic_uninitialize_locked_gpu):
+            fn(h)
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(grid, u0, locked, args.cpu_half_sweeps)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -43,6 +43,7 @@ struct Ctx {
     float *h_delta = nullptr;      // pinned
     hipStream_t stream = nullptr;
     int rows_per_task = 0;         // 0 = automatic
+    int math = 0;                  // 0 = precise (default), 1 = fast; EPIC_HIP_MATH / epic_hip_set_math_mode
     size_t u_bytes() const { return (size_t)rows * pitch * sizeof(float); }
     size_t mask_bytes() const
     {
@@ -119,6 +120,8 @@ Ctx *get_ctx(Harmonic *h, bool create)
     }
     const char *e = getenv("EPIC_HIP_ROWS_PER_TASK");
     if (e) c->rows_per_task = atoi(e);
+    e = getenv("EPIC_HIP_MATH");
+    if (e && strcmp(e, "fast") == 0) c->math = 1;
     g_ctx[h] = c;
     return c;
 }
@@ -161,10 +164,10 @@ hipError_t enqueue_sweep(Ctx *c, bool check)
     const float *in = c->buf[c->cur];
     float *out = c->buf[c->cur ^ 1];
     if (c->n == 2)
-        e = epic_hip::launch_sweep_2d(in, out, c->maskw, c->rows, c->pitch, 0, c->rows, auto_rows_per_task(c),
+        e = epic_hip::launch_sweep_2d(in, out, c->maskw, c->rows, c->pitch, 0, c->rows, auto_rows_per_task(c), c->math,
                                       check ? c->d_delta : nullptr, c->stream);
     else
-        e = epic_hip::launch_sweep_3d(in, out, c->maskw, c->m[0], c->m[1], c->pitch, 0, c->m[0],
+        e = epic_hip::launch_sweep_3d(in, out, c->maskw, c->m[0], c->m[1], c->pitch, 0, c->m[0], c->math,
                                       check ? c->d_delta : nullptr, c->stream);
     if (e == hipSuccess) c->cur ^= 1;
     return e;
@@ -735,6 +738,21 @@ int epic_hip_set_rows_per_task(Harmonic *harmonic, unsigned int rows_per_task)
     return EPIC_SUCCESS;
 }
 
+int epic_hip_set_math_mode(Harmonic *harmonic, int mode)
+{
+    Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
+    if (!c || (mode != 0 && mode != 1)) return EPIC_ERROR_INVALID_DATA;
+    c->math = mode;
+    return EPIC_SUCCESS;
+}
+
+int epic_hip_eval_math(const float *d_in, float *d_out, size_t n, int which, void *stream)
+{
+    if (!d_in || !d_out) return EPIC_ERROR_INVALID_DATA;
+    return epic_hip::launch_eval_math(d_in, d_out, n, which, (hipStream_t)stream) == hipSuccess ? EPIC_SUCCESS
+                                                                                                  : EPIC_ERROR_KERNEL_EXECUTION;
+}
+
 int epic_hip_get_layout(Harmonic *harmonic, unsigned int *pitch, size_t *u_bytes, size_t *mask_bytes)
 {
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
@@ -759,15 +777,16 @@ int epic_hip_pack_mask_2d(const uint32_t *d_locked, unsigned int rows, unsigned 
 }
 
 int epic_hip_sweep_2d(const float *d_in, float *d_out, const uint32_t *d_maskw, unsigned int rows, unsigned int pitch,
-                      unsigned int row_begin, unsigned int row_end, unsigned int rows_per_task, uint32_t *d_delta_bits,
-                      void *stream)
+                      unsigned int row_begin, unsigned int row_end, unsigned int rows_per_task, int math_mode,
+                      uint32_t *d_delta_bits, void *stream)
 {
     if (!d_in || !d_out || !d_maskw || d_in == d_out || rows < 3 || pitch % 64 != 0 || pitch == 0 || row_end > rows ||
         row_begin > row_end)
         return EPIC_ERROR_INVALID_DATA;
     if (rows_per_task == 0) rows_per_task = 32;
+    if (math_mode != 0 && math_mode != 1) return EPIC_ERROR_INVALID_DATA;
     return epic_hip::launch_sweep_2d(d_in, d_out, d_maskw, (int)rows, (int)pitch, (int)row_begin, (int)row_end,
-                                     (int)rows_per_task, d_delta_bits, (hipStream_t)stream) == hipSuccess
+                                     (int)rows_per_task, math_mode, d_delta_bits, (hipStream_t)stream) == hipSuccess
                ? EPIC_SUCCESS
                : EPIC_ERROR_KERNEL_EXECUTION;
 }

@@ -9,8 +9,10 @@ namespace epic_hip {
 // ---- 2-D (kernels_2d.hip) -------------------------------------------------------------------
 // One Jacobi sweep of rows [row_begin, row_end) of a pitched rows x pitch grid.  delta_bits == nullptr
 // selects the plain kernel; otherwise max |du| is atomicMax'ed into *delta_bits (float bits, zero it first).
+// math: 0 = precise (libm-equivalent exp/log in f64, the default), 1 = fast (v_exp_f32 / v_log_f32).
 hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int row_begin,
-                           int row_end, int rows_per_task, unsigned *delta_bits, hipStream_t stream);
+                           int row_end, int rows_per_task, int math, unsigned *delta_bits, hipStream_t stream);
+hipError_t launch_eval_math(const float *in, float *out, size_t n, int which, hipStream_t stream);
 hipError_t launch_pack_mask_2d(const uint32_t *locked, int rows, int cols, int pitch, int ghost_top,
                                int ghost_bottom, uint32_t *maskw, hipStream_t stream);
 hipError_t launch_fill(float *p, size_t n, float v, hipStream_t stream);
@@ -22,7 +24,7 @@ inline size_t mask_words_2d(int rows, int pitch) { return (size_t)((rows + 7) / 
 
 // ---- 3-D (kernels_3d.hip) -------------------------------------------------------------------
 hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, int m0, int m1, int pitch,
-                           int plane_begin, int plane_end, unsigned *delta_bits, hipStream_t stream);
+                           int plane_begin, int plane_end, int math, unsigned *delta_bits, hipStream_t stream);
 hipError_t launch_pack_mask_3d(const uint32_t *locked, int m0, int m1, int m2, int pitch, uint32_t *maskw,
                                hipStream_t stream);
 inline size_t mask_words_3d(int m0, int m1, int pitch) { return (size_t)m0 * (size_t)m1 * (size_t)(pitch / 32); }

@@ -57,9 +57,14 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nblk)
     return x * q + (x < rem ? x : rem) + i;
 }
 
-template <bool CHECK>
+template <bool CHECK, int MATH>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2dArgs a)
 {
+    __shared__ double lds[kMathLdsDoubles];  // libm tables (precise math only)
+    if (MATH == kMathPrecise) {
+        math_tables_to_lds(lds);
+        __syncthreads();
+    }
     const int lane = threadIdx.x & (kWave - 1);
     // wave-uniform quantities are forced into SGPRs: the row loop, its addresses and branches are scalar
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -107,10 +112,10 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
         const float rt = wave_from_right(c.x, h);  // u[r][col+4]
         const uint32_t nib = mw >> ((r & 7) * 4);
         float4 o;
-        o.x = cell_update_2d(up.x, dn.x, lf, c.y);
-        o.y = cell_update_2d(up.y, dn.y, c.x, c.z);
-        o.z = cell_update_2d(up.z, dn.z, c.y, c.w);
-        o.w = cell_update_2d(up.w, dn.w, c.z, rt);
+        o.x = cell_update_2d<MATH>(up.x, dn.x, lf, c.y, lds);
+        o.y = cell_update_2d<MATH>(up.y, dn.y, c.x, c.z, lds);
+        o.z = cell_update_2d<MATH>(up.z, dn.z, c.y, c.w, lds);
+        o.w = cell_update_2d<MATH>(up.w, dn.w, c.z, rt, lds);
         o.x = (nib & 1u) ? c.x : o.x;
         o.y = (nib & 2u) ? c.y : o.y;
         o.z = (nib & 4u) ? c.z : o.z;
@@ -206,10 +211,39 @@ __global__ void set_cells_2d_kernel(float *u, uint32_t *maskw, int rows, int col
     else atomicAnd(w, ~bit);
 }
 
+// libm-replica check: out[i] = which ? ln(in[i]) : exp(in[i]) with the PRECISE device routines (test hook).
+__global__ void eval_math_kernel(const float *in, float *out, size_t n, int which)
+{
+    __shared__ double lds[kMathLdsDoubles];
+    math_tables_to_lds(lds);
+    __syncthreads();
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = which ? precise_ln(in[i], lds) : precise_exp(in[i], lds);
+}
+
+}  // namespace
+
+hipError_t launch_eval_math(const float *in, float *out, size_t n, int which, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(eval_math_kernel, dim3(4096), dim3(256), 0, stream, in, out, n, which);
+    return hipGetLastError();
+}
+
+namespace {
+template <bool CHECK>
+void launch_sweep_2d_math(int math, int nblocks, hipStream_t stream, const Sweep2dArgs &a)
+{
+    if (math == kMathFast)
+        hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathFast>), dim3(nblocks), dim3(kWave * kWavesPerBlock), 0, stream, a);
+    else
+        hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathPrecise>), dim3(nblocks), dim3(kWave * kWavesPerBlock), 0, stream, a);
+}
 }  // namespace
 
 hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int row_begin,
-                           int row_end, int rows_per_task, unsigned *delta_bits, hipStream_t stream)
+                           int row_end, int rows_per_task, int math, unsigned *delta_bits, hipStream_t stream)
 {
     if (row_end <= row_begin) return hipSuccess;
     if (pitch <= 0 || (pitch % 64) != 0 || rows <= 0 || row_begin < 0 || row_end > rows || rows_per_task <= 0)
@@ -228,10 +262,8 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, i
     const int nchunks = (row_end - row_begin + rows_per_task - 1) / rows_per_task;
     a.ntasks = a.nstrips * nchunks;
     const int nblocks = (a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (delta_bits)
-        hipLaunchKernelGGL(sweep2d_kernel<true>, dim3(nblocks), dim3(kWave * kWavesPerBlock), 0, stream, a);
-    else
-        hipLaunchKernelGGL(sweep2d_kernel<false>, dim3(nblocks), dim3(kWave * kWavesPerBlock), 0, stream, a);
+    if (delta_bits) launch_sweep_2d_math<true>(math, nblocks, stream, a);
+    else launch_sweep_2d_math<false>(math, nblocks, stream, a);
     return hipGetLastError();
 }
 

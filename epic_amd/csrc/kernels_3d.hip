@@ -35,11 +35,16 @@ struct Sweep3dArgs {
     int nstrips, nchunks, nplane_groups;
 };
 
-template <bool CHECK>
+template <bool CHECK, int MATH>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3dArgs a)
 {
+    __shared__ double lds[kMathLdsDoubles];  // libm tables (precise math only)
+    if (MATH == kMathPrecise) {
+        math_tables_to_lds(lds);
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int b = blockIdx.x;
     const int strip = b % a.nstrips;
     b /= a.nstrips;
@@ -97,10 +102,10 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3d
         const uint32_t nib = mw >> (lcol & 31);
 
         float4 o;
-        o.x = cell_update_3d(a1.x, b1.x, up.x, d1.x, lf, c.y);
-        o.y = cell_update_3d(a1.y, b1.y, up.y, d1.y, c.x, c.z);
-        o.z = cell_update_3d(a1.z, b1.z, up.z, d1.z, c.y, c.w);
-        o.w = cell_update_3d(a1.w, b1.w, up.w, d1.w, c.z, rt);
+        o.x = cell_update_3d<MATH>(a1.x, b1.x, up.x, d1.x, lf, c.y, lds);
+        o.y = cell_update_3d<MATH>(a1.y, b1.y, up.y, d1.y, c.x, c.z, lds);
+        o.z = cell_update_3d<MATH>(a1.z, b1.z, up.z, d1.z, c.y, c.w, lds);
+        o.w = cell_update_3d<MATH>(a1.w, b1.w, up.w, d1.w, c.z, rt, lds);
         o.x = (nib & 1u) ? c.x : o.x;
         o.y = (nib & 2u) ? c.y : o.y;
         o.z = (nib & 4u) ? c.z : o.z;
@@ -151,7 +156,7 @@ __global__ void pack_mask_3d_kernel(const uint32_t *locked, int m0, int m1, int 
 }  // namespace
 
 hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, int m0, int m1, int pitch,
-                           int plane_begin, int plane_end, unsigned *delta_bits, hipStream_t stream)
+                           int plane_begin, int plane_end, int math, unsigned *delta_bits, hipStream_t stream)
 {
     if (plane_end <= plane_begin) return hipSuccess;
     if (pitch <= 0 || (pitch % 64) != 0 || m0 <= 0 || m1 <= 0 || plane_begin < 0 || plane_end > m0)
@@ -171,10 +176,14 @@ hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, i
     a.nplane_groups = (plane_end - plane_begin + kWavesPerBlock - 1) / kWavesPerBlock;
     const long long nblocks = (long long)a.nstrips * a.nchunks * a.nplane_groups;
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (delta_bits)
-        hipLaunchKernelGGL(sweep3d_kernel<true>, dim3((unsigned)nblocks), dim3(kWave * kWavesPerBlock), 0, stream, a);
-    else
-        hipLaunchKernelGGL(sweep3d_kernel<false>, dim3((unsigned)nblocks), dim3(kWave * kWavesPerBlock), 0, stream, a);
+    const dim3 grid((unsigned)nblocks), block(kWave * kWavesPerBlock);
+    if (delta_bits) {
+        if (math == kMathFast) hipLaunchKernelGGL((sweep3d_kernel<true, kMathFast>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((sweep3d_kernel<true, kMathPrecise>), grid, block, 0, stream, a);
+    } else {
+        if (math == kMathFast) hipLaunchKernelGGL((sweep3d_kernel<false, kMathFast>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((sweep3d_kernel<false, kMathPrecise>), grid, block, 0, stream, a);
+    }
     return hipGetLastError();
 }
 

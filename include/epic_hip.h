@@ -45,6 +45,14 @@ int epic_hip_timed_sweeps_gpu(EpicHarmonicT *harmonic, unsigned int sweeps, unsi
 /* Tuning knob: rows marched by one wave in the 2-D kernel (0 = automatic).  Also EPIC_HIP_ROWS_PER_TASK. */
 int epic_hip_set_rows_per_task(EpicHarmonicT *harmonic, unsigned int rows_per_task);
 
+/* Arithmetic of the sweep kernels: 0 = precise (default; exp/log equivalent to the host libm's expf/logf, evaluated
+ * in f64 -- what the parity claims are made with), 1 = fast (v_exp_f32 / v_log_f32; ~1e-4 relative drift on
+ * ill-conditioned maps).  Also EPIC_HIP_MATH=fast|precise in the environment at initialisation. */
+int epic_hip_set_math_mode(EpicHarmonicT *harmonic, int mode);
+
+/* Test hook: d_out[i] = which ? ln(d_in[i]) : exp(d_in[i]) with the precise device routines. */
+int epic_hip_eval_math(const float *d_in, float *d_out, size_t n, int which, void *stream);
+
 /* Geometry of the device-resident state: pitch in floats, bytes of one u buffer, bytes of the packed mask. */
 int epic_hip_get_layout(EpicHarmonicT *harmonic, unsigned int *pitch, size_t *u_bytes, size_t *mask_bytes);
 
@@ -59,7 +67,7 @@ int epic_hip_pack_mask_2d(const uint32_t *d_locked, unsigned int rows, unsigned 
                           int ghost_top, int ghost_bottom, uint32_t *d_maskw, void *stream);
 int epic_hip_sweep_2d(const float *d_in, float *d_out, const uint32_t *d_maskw, unsigned int rows,
                       unsigned int pitch, unsigned int row_begin, unsigned int row_end, unsigned int rows_per_task,
-                      uint32_t *d_delta_bits, void *stream);
+                      int math_mode, uint32_t *d_delta_bits, void *stream);
 
 #ifdef __cplusplus
 }
