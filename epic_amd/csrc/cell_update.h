@@ -52,10 +52,11 @@ constexpr int kMathPrecise = 0;
 constexpr int kMathFast = 1;
 
 // ---- libm-equivalent expf / logf in f64 (glibc 2.35 algorithm, see header) --------------------------------
-// LDS image: 32 x u64 exp table, then 16 x {invc, logc}.  64 doubles = 512 B, one copy per workgroup.
-constexpr int kMathLdsDoubles = 64;
+// LDS image (160 doubles = 1.25 KiB per workgroup): [0, 32) exp table; [32, 160) log table, 64 x {invc, y0}.
+constexpr int kMathLdsDoubles = 160;
 
-// tab[i] = bits(2^(i/32)) - (i << 47)    (glibc e_exp2f_data.c, EXP2F_TABLE_BITS = 5)
+// glibc's tab[i] = bits(2^(i/32)) - (i << 47) (e_exp2f_data.c, EXP2F_TABLE_BITS = 5); the kernel wants the plain
+// 2^(i/32), so math_tables_to_lds() adds the i << 47 back.
 __constant__ const uint64_t kExpTab[32] = {
     0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51, 0x3fef72b83c7d517b,
     0x3fef54873168b9aa, 0x3fef387a6e756238, 0x3fef1e9df51fdee1, 0x3fef06fe0a31b715, 0x3feef1a7373aa9cb,
@@ -77,44 +78,54 @@ __constant__ const double kLogTab[32] = {
     0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2,  0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2,
 };
 
-// Stage both tables into LDS; call from every thread of the workgroup, then __syncthreads().
+// Stage the tables into LDS; call from every thread of a >= 128-thread workgroup, then __syncthreads().
+// The log table is expanded over the binade index k = 0..3 (arguments in [0.7, 11.2) cover the sums of 4 or 6 terms
+// <= 1 with one term == 1): entry (k, i) = {invc_i, logc_i + k ln2}, so the kernel needs neither k nor a multiply.
 __device__ __forceinline__ void math_tables_to_lds(double *lds)
 {
     const int t = threadIdx.x;
-    if (t < 32) lds[t] = __builtin_bit_cast(double, kExpTab[t]);
-    else if (t < 64) lds[t] = kLogTab[t - 32];
+    if (t < 32) {
+        lds[t] = __builtin_bit_cast(double, kExpTab[t] + ((uint64_t)t << 47));
+    } else if (t < 32 + 64) {
+        const int e = t - 32, k = e >> 4, i = e & 15;
+        lds[32 + 2 * e] = kLogTab[2 * i];
+        lds[32 + 2 * e + 1] = kLogTab[2 * i + 1] + (double)k * 0x1.62e42fefa39efp-1;
+    }
 }
 
-// e^x for x <= 0 (glibc e_expf.c: z = x N/ln2, k = rint(z), r = z - k, 2^(k/N) from the table, cubic in r).
+// e^x for x <= 0.  glibc e_expf.c: z = x N/ln2, k = round(z), r = z - k, s = 2^(k/N) from the table, cubic in r,
+// all in double, one rounding to float at the end.  Differences to the C source that cannot change the float result
+// (the double result carries ~2^-30 of slack, checked exhaustively by test_device_libm_replica): k is taken from the
+// low word of fma(x, N/ln2, 1.5 * 2^52) (glibc's own non-intrinsic path does the same with an add), r comes from a
+// second fma instead of a rounded product, the cubic is in Horner form.
 __device__ __forceinline__ float precise_exp(float x, const double *lds)
 {
-    x = max2(x, -104.0f);  // below this e^x < 2^-150; such a term cannot change a sum that is >= 1
-    const double z = 0x1.71547652b82fep+5 * (double)x;
-    const double kd = __builtin_rint(z);
-    const int ki = (int)kd;
-    const double r = z - kd;
-    uint64_t t = __builtin_bit_cast(uint64_t, lds[ki & 31]);
-    t += (uint64_t)((uint32_t)ki << 15) << 32;  // t += ki << 47 (only the high dword changes)
-    const double s = __builtin_bit_cast(double, t);
-    const double zz = __builtin_fma(0x1.c6af84b912394p-20, r, 0x1.ebfce50fac4f3p-13);
-    const double r2 = r * r;
-    double y = __builtin_fma(0x1.62e42ff0c52d6p-6, r, 1.0);
-    y = __builtin_fma(zz, r2, y);
-    return (float)(y * s);
+    const double xd = (double)x;
+    const double kInvLn2N = 0x1.71547652b82fep+5, kShift = 0x1.8p+52;
+    const double ks = __builtin_fma(xd, kInvLn2N, kShift);
+    const int ki = (int)(uint32_t)__builtin_bit_cast(uint64_t, ks);  // low word: k in two's complement
+    const double kd = ks - kShift;
+    const double r = __builtin_fma(xd, kInvLn2N, -kd);
+    // glibc forms s = 2^(k/N) by adding k << 47 to the table word; 2^((k mod N)/N) scaled by ldexp is the same number
+    // and, unlike the integer add, degrades to 0 for the x = -1e6 terms (neighbours that are obstacles) without a clamp.
+    const double s0 = lds[ki & 31];
+    double y = __builtin_fma(0x1.c6af84b912394p-20, r, 0x1.ebfce50fac4f3p-13);
+    y = __builtin_fma(y, r, 0x1.62e42ff0c52d6p-6);
+    y = __builtin_fma(y, r, 1.0);
+    return (float)__builtin_ldexp(y * s0, ki >> 5);
 }
 
-// ln(s) for normal positive s (glibc e_logf.c: s = 2^k z, z in [OFF, 2 OFF); r = z invc - 1; cubic in r).
+// ln(s) for s in [0.7, 11.2).  glibc e_logf.c: s = 2^k z with z in [OFF, 2 OFF) split into 16 sub-intervals,
+// r = z invc - 1, ln s = log1p(r) + logc + k ln2 with a cubic for log1p, all in double.
 __device__ __forceinline__ float precise_ln(float sf, const double *lds)
 {
     const uint32_t ix = __builtin_bit_cast(uint32_t, sf);
     const uint32_t tmp = ix - 0x3f330000u;
-    const int i = (tmp >> 19) & 15;
-    const int k = (int)tmp >> 23;
-    const uint32_t iz = ix - (tmp & 0xff800000u);
-    const double invc = lds[32 + 2 * i], logc = lds[32 + 2 * i + 1];
+    const uint32_t e = tmp >> 19;                    // 16 k + i
+    const uint32_t iz = ix - (tmp & 0xff800000u);    // z = s / 2^k
+    const double invc = lds[32 + 2 * e], y0 = lds[32 + 2 * e + 1];
     const double z = (double)__builtin_bit_cast(float, iz);
     const double r = __builtin_fma(z, invc, -1.0);
-    const double y0 = __builtin_fma((double)k, 0x1.62e42fefa39efp-1, logc);
     const double r2 = r * r;
     double y = __builtin_fma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);
     y = __builtin_fma(-0x1.00ea348b88334p-2, r2, y);

@@ -143,8 +143,10 @@ int auto_rows_per_task(const Ctx *c)
 {
     if (c->rows_per_task > 0) return c->rows_per_task;
     const long long nstrips = (c->pitch + 255) / 256;
-    long long r = (long long)c->rows * nstrips / 4096;   // aim at >= 4096 wave-tasks (16 per CU)
-    r = (r + 7) / 8 * 8;
+    // The kernel is VALU-bound (precise math), so what matters is keeping every SIMD at 8 resident waves with a
+    // short tail: aim at >= 16384 wave-tasks (2 rounds of 8192 resident waves); 2 extra halo rows per task are cheap.
+    long long r = (long long)c->rows * nstrips / 16384;
+    r = r / 8 * 8;
     return (int)std::min<long long>(64, std::max<long long>(8, r));
 }
 
