@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--cpu-half-sweeps", type=int, default=12, help="bounded CPU sample (about 1 s each at 8192^2)")
     ap.add_argument("--math", choices=("precise", "fast"), default="precise",
                     help="precise = libm-equivalent exp/log (the parity mode, default); fast = v_exp_f32/v_log_f32")
+    ap.add_argument("--slab", action="store_true", help="use the slab-decomposition driver even on one GPU")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-relax", action="store_true")
     return ap.parse_args()
@@ -99,7 +100,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world == 1:
+    use_abi = world == 1 and not args.slab
+    if use_abi:
         from epic_amd.harmonic import Harmonic
 
         u0, locked = synthetic_grid(grid)
@@ -196,7 +198,7 @@ def main():
         },
     }
 
-    if world == 1:
+    if use_abi:
         if upload_s is not None:
             out["config"]["h2d_seconds"] = round(upload_s, 3)
         if not args.no_relax:

@@ -1,0 +1,253 @@
+"""Row-slab decomposition of one 2-D relaxation over several GPUs, one process per GPU.
+
+Not in the reference (it has no multi-GPU code); BASELINE.json asks for it: the global grid is cut
+into `world` contiguous row slabs, each rank keeps its slab (+ one ghost row per interior side) resident in HBM and,
+per Jacobi sweep, exchanges exactly one boundary row with each neighbour -- the only data the 5-point stencil needs
+from the other side.  No other collective sits on the data path; the convergence test is one MAX all-reduce of a
+single float every `stagger` sweeps.
+
+Per sweep and rank:
+    1. boundary kernel  : sweep the first and the last owned row (2 x 1 row) on the compute stream
+    2. halo exchange    : on a second stream, after (1): isend the two fresh rows, irecv the neighbours' rows into the
+                          ghost rows of the OUTPUT buffer (torch.distributed P2P = RCCL send/recv over xGMI)
+    3. interior kernel  : sweep every other owned row on the compute stream, concurrently with (2)
+    4. join             : the compute stream waits for the exchange; swap buffers
+The sweeps themselves are the library's raw operator (include/epic_hip.h: epic_hip_sweep_2d) on torch-owned device
+memory and torch's streams: PyTorch is plumbing here (memory, streams, process group), the arithmetic is the HIP kernel.
+
+The sweep backend is injected so that the decomposition / exchange logic can be exercised on CPU tensors with the
+gloo backend (tests/test_slab_gloo.py passes the checker's row sweep).  There is no CPU fallback: the default
+backend needs the HIP library and a GPU.
+"""
+import ctypes as ct
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .synthetic import DEFAULT_SEED, _GOLD, _mix64
+
+
+def partition_rows(rows, world):
+    """Contiguous, near-equal row ranges [(lo, hi), ...] covering [0, rows)."""
+    base, rem = divmod(rows, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def synthetic_rows(m, row_lo, row_hi, seed=DEFAULT_SEED, density=0.05):
+    """Rows [row_lo, row_hi) of epic_amd.synthetic.synthetic_grid(m) without building the whole grid."""
+    rows, cols = int(m[0]), int(m[1])
+    thresh = np.uint64(int(density * 9007199254740992.0))
+    n = (row_hi - row_lo) * cols
+    locked = np.empty(n, dtype=np.uint32)
+    u = np.full(n, -1e6, dtype=np.float32)
+    chunk_rows = max(1, (1 << 24) // cols)
+    with np.errstate(over="ignore"):
+        for r0 in range(row_lo, row_hi, chunk_rows):
+            r1 = min(row_hi, r0 + chunk_rows)
+            idx = np.arange(r0 * cols, r1 * cols, dtype=np.uint64)
+            h = _mix64(np.uint64(seed) ^ (idx * _GOLD))
+            obstacle = (h >> np.uint64(11)) < thresh
+            rr = idx // np.uint64(cols)
+            cc = idx % np.uint64(cols)
+            border = (rr == 0) | (rr == np.uint64(rows - 1)) | (cc == 0) | (cc == np.uint64(cols - 1))
+            locked[(r0 - row_lo) * cols:(r1 - row_lo) * cols] = obstacle | border
+    gr, gc = rows // 2, cols // 2
+    if row_lo <= gr < row_hi:
+        u[(gr - row_lo) * cols + gc] = 0.0
+        locked[(gr - row_lo) * cols + gc] = 1
+    return u, locked
+
+
+class HipBackend:
+    """Sweeps through libepic.so's raw operators on the current torch stream."""
+
+    def __init__(self, rows_per_task=0, math="precise"):
+        from . import epic_harmonic as eh
+
+        self.E = eh._epic
+        if self.E.epic_hip_device_count() < 1:
+            raise RuntimeError("epic_amd.slab: no HIP device -- the slab solver has no CPU path")
+        self.rows_per_task = int(rows_per_task) or 16
+        self.math = 1 if math == "fast" else 0
+
+    def pitch_for(self, cols):
+        return int(self.E.epic_hip_pitch_for_cols(cols))
+
+    def mask_words(self, rows, pitch):
+        return int(self.E.epic_hip_mask_words_2d(rows, pitch))
+
+    def pack_mask(self, locked_i32, rows, cols, pitch, ghost_top, ghost_bottom, maskw):
+        rc = self.E.epic_hip_pack_mask_2d(locked_i32.data_ptr(), rows, cols, pitch, int(ghost_top), int(ghost_bottom),
+                                          maskw.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("epic_hip_pack_mask_2d failed: %d" % rc)
+
+    def sweep(self, src, dst, maskw, rows, pitch, row_begin, row_end, delta_bits):
+        if row_end <= row_begin:
+            return
+        rc = self.E.epic_hip_sweep_2d(src.data_ptr(), dst.data_ptr(), maskw.data_ptr(), rows, pitch, row_begin, row_end,
+                                      self.rows_per_task, self.math,
+                                      delta_bits.data_ptr() if delta_bits is not None else None,
+                                      torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("epic_hip_sweep_2d failed: %d" % rc)
+
+
+class SlabSolver:
+    """One rank's share of a row-slab-decomposed 2-D relaxation."""
+
+    def __init__(self, grid, rank, world, device, stagger=100, epsilon=1e-6, rows_per_task=0, math="precise",
+                 backend=None, group=None):
+        self.grid = (int(grid[0]), int(grid[1]))
+        self.rank, self.world, self.device = rank, world, torch.device(device)
+        self.stagger, self.epsilon = int(stagger), float(epsilon)
+        self.group = group
+        self.backend = backend if backend is not None else HipBackend(rows_per_task, math)
+        self.lo, self.hi = partition_rows(self.grid[0], world)[rank]
+        if self.hi - self.lo < 2:
+            raise ValueError("every slab needs at least 2 rows")
+        self.ghost_top = rank > 0
+        self.ghost_bottom = rank < world - 1
+        self.rows = (self.hi - self.lo) + int(self.ghost_top) + int(self.ghost_bottom)
+        self.cols = self.grid[1]
+        self.pitch = self.backend.pitch_for(self.cols)
+        self.first = int(self.ghost_top)          # first owned local row
+        self.last = self.rows - 1 - int(self.ghost_bottom)  # last owned local row
+        self.cuda = self.device.type == "cuda"
+        self.buf = [torch.full((self.rows, self.pitch), -1e6, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.cur = 0
+        self.maskw = torch.zeros(self.backend.mask_words(self.rows, self.pitch), dtype=torch.int32, device=self.device)
+        self.delta_bits = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.iteration = 0
+        self.delta = self.epsilon + 1.0
+        self.free_cells = 0
+        if self.cuda:
+            self.comm_stream = torch.cuda.Stream(device=self.device)
+            self.ev_boundary = torch.cuda.Event()
+            self.ev_comm = torch.cuda.Event()
+
+    # ---- data --------------------------------------------------------------------------------------------
+    def load_rows(self, u_rows, locked_rows):
+        """u_rows / locked_rows: this rank's LOCAL rows including ghost rows, shape (rows, cols) (ghost rows hold the
+        neighbours' boundary rows).  Returns the number of unlocked owned cells."""
+        u_rows = np.ascontiguousarray(u_rows, dtype=np.float32).reshape(self.rows, self.cols)
+        locked_rows = np.ascontiguousarray(locked_rows, dtype=np.uint32).reshape(self.rows, self.cols)
+        for b in self.buf:
+            b.fill_(-1e6)
+            b[:, :self.cols] = torch.from_numpy(u_rows).to(self.device)
+        lk = torch.from_numpy(locked_rows.astype(np.int32)).to(self.device)
+        self.backend.pack_mask(lk, self.rows, self.cols, self.pitch, self.ghost_top, self.ghost_bottom, self.maskw)
+        if self.cuda:
+            torch.cuda.synchronize(self.device)
+        self.cur = 0
+        self.iteration = 0
+        owned = locked_rows[self.first:self.last + 1]
+        interior = np.ones_like(owned, dtype=bool)
+        interior[:, 0] = interior[:, -1] = False
+        if self.rank == 0:
+            interior[0] = False
+        if self.rank == self.world - 1:
+            interior[-1] = False
+        self.free_cells = int(((owned == 0) & interior).sum())
+        return self.free_cells
+
+    def load_synthetic(self, seed=DEFAULT_SEED, density=0.05):
+        lo = self.lo - int(self.ghost_top)
+        hi = self.hi + int(self.ghost_bottom)
+        u, lk = synthetic_rows(self.grid, lo, hi, seed, density)
+        return self.load_rows(u, lk)
+
+    def owned(self):
+        """This rank's owned rows of the current field, (hi - lo, cols), on the host."""
+        return self.buf[self.cur][self.first:self.last + 1, :self.cols].cpu().numpy()
+
+    # ---- sweeps ------------------------------------------------------------------------------------------
+    def _exchange(self, dst):
+        ops = []
+        if self.ghost_top:
+            ops.append(dist.P2POp(dist.isend, dst[self.first], self.rank - 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, dst[0], self.rank - 1, self.group))
+        if self.ghost_bottom:
+            ops.append(dist.P2POp(dist.isend, dst[self.last], self.rank + 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, dst[self.rows - 1], self.rank + 1, self.group))
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def sweep(self, check=False):
+        """One Jacobi sweep of the whole (distributed) grid.  With check=True the local max |du| lands in
+        self.delta_bits (float bits); combine across ranks with reduce_delta()."""
+        src, dst = self.buf[self.cur], self.buf[self.cur ^ 1]
+        be, d = self.backend, (self.delta_bits if check else None)
+        if check:
+            self.delta_bits.zero_()
+        # 1. boundary rows first, so their exchange overlaps the interior sweep
+        be.sweep(src, dst, self.maskw, self.rows, self.pitch, self.first, self.first + 1, d)
+        if self.last > self.first:
+            be.sweep(src, dst, self.maskw, self.rows, self.pitch, self.last, self.last + 1, d)
+        # 2. halo exchange on the second stream
+        if self.cuda:
+            self.ev_boundary.record()
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(self.ev_boundary)
+                works = self._exchange(dst)
+                for w in works:
+                    w.wait()           # stream-ordered for NCCL/RCCL: makes comm_stream wait, not the host
+                self.ev_comm.record()
+        else:
+            works = self._exchange(dst)
+        # 3. interior rows
+        be.sweep(src, dst, self.maskw, self.rows, self.pitch, self.first + 1, self.last, d)
+        # 4. join
+        if self.cuda:
+            torch.cuda.current_stream().wait_event(self.ev_comm)
+        else:
+            for w in works:
+                w.wait()
+        self.cur ^= 1
+        self.iteration += 1
+
+    def reduce_delta(self):
+        """Global max |du| of the last check sweep (one MAX all-reduce of one float)."""
+        t = self.delta_bits.view(torch.float32).clone()
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        self.delta = float(t.item())
+        return self.delta
+
+    def step(self):
+        """One pass of the reference's driver loop over `stagger` iterations (harmonic_gpu.cu:266-290): a check
+        sweep when iteration % stagger == 0, plain sweeps otherwise.  Returns True if the check sweep converged."""
+        converged = False
+        for _ in range(self.stagger):
+            check = self.iteration % self.stagger == 0
+            self.sweep(check)
+            if check:
+                converged = self.reduce_delta() < self.epsilon
+        return converged
+
+    def timed_step(self):
+        """step() bracketed by events on the compute stream; returns device milliseconds."""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.step()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+
+    def solve(self, max_sweeps=None):
+        """Relax until a check sweep finds delta < epsilon with iteration >= max(grid) (the reference's exit rule)."""
+        self.iteration = 0
+        floor = max(self.grid)
+        result = False
+        while not result or self.iteration < floor:
+            check = self.iteration % self.stagger == 0
+            self.sweep(check)
+            result = (self.reduce_delta() < self.epsilon) if check else False
+            if max_sweeps is not None and self.iteration >= max_sweeps:
+                break
+        return self.iteration

@@ -317,3 +317,24 @@ void oracle_synthetic(unsigned int n, const unsigned int *m, uint64_t seed, doub
     u[goal] = 0.0f;
     locked[goal] = 1;
 }
+
+/* ---- row-range Jacobi on a pitched local array (checker side of the slab-decomposition tests) ----------------
+ * Sweeps rows [row_begin, row_end) of a rows x pitch array (first `cols` columns meaningful) from `in` to `out`
+ * with the same per-cell update; cells with locked != 0, the first/last column and rows 0 / rows-1 are copied.
+ * Returns max |du| over the rows swept.  Not in the reference (it has no multi-GPU code). */
+float oracle_jacobi_rows_2d(const float *in, float *out, const unsigned int *locked, unsigned int rows,
+                            unsigned int cols, unsigned int pitch, unsigned int row_begin, unsigned int row_end)
+{
+    float d = 0.0f;
+    for (unsigned int r = row_begin; r < row_end && r < rows; r++) {
+        for (unsigned int c = 0; c < pitch; c++) {
+            size_t i = (size_t)r * pitch + c;
+            int fixed = c >= cols || c == 0 || c == cols - 1 || r == 0 || r == rows - 1 || locked[(size_t)r * cols + c];
+            if (fixed) { out[i] = in[i]; continue; }
+            float v = cell_update_2d(in[i - pitch], in[i + pitch], in[i - 1], in[i + 1]);
+            out[i] = v;
+            d = fmax2(d, (float)fabs(in[i] - v));
+        }
+    }
+    return d;
+}
