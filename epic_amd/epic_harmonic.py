@@ -95,6 +95,28 @@ _SIGNATURES = {
     # harmonic_utilities_{cpu,gpu}.h
     "harmonic_utilities_set_cells_2d_cpu": (_H, ct.c_uint, _UP, _UP),
     "harmonic_utilities_set_cells_2d_gpu": (_H, ct.c_uint, ct.c_uint, _UP, _UP),
+    # harmonic_path_cpu.h (reference parameters are pointers at the ABI level)
+    "harmonic_compute_potential_2d_cpu": (_H, ct.c_float, ct.c_float, ct.POINTER(ct.c_float)),
+    "harmonic_compute_gradient_2d_cpu": (_H, ct.c_float, ct.c_float, ct.c_float, ct.POINTER(ct.c_float),
+                                         ct.POINTER(ct.c_float)),
+    "harmonic_compute_path_2d_cpu": (_H, ct.c_float, ct.c_float, ct.c_float, ct.c_float, ct.c_uint, _UP,
+                                     ct.POINTER(ct.POINTER(ct.c_float))),
+    "harmonic_free_path_cpu": (ct.POINTER(ct.POINTER(ct.c_float)),),
+    # harmonic_legacy_cpu.h / harmonic_legacy_path_cpu.h
+    "harmonic_legacy_sor_2d_float_cpu": (ct.c_uint, ct.c_uint, ct.c_float, ct.c_float, _UP, ct.POINTER(ct.c_float), _UP),
+    "harmonic_legacy_sor_2d_double_cpu": (ct.c_uint, ct.c_uint, ct.c_double, ct.c_double, _UP, ct.POINTER(ct.c_double),
+                                          _UP),
+    "harmonic_legacy_sor_2d_long_double_cpu": (ct.c_uint, ct.c_uint, ct.c_longdouble, ct.c_longdouble, _UP,
+                                               ct.POINTER(ct.c_longdouble), _UP),
+    "harmonic_legacy_compute_potential_2d_cpu": (ct.c_uint, ct.c_uint, _UP, ct.POINTER(ct.c_double), ct.c_double,
+                                                 ct.c_double, ct.POINTER(ct.c_double)),
+    "harmonic_legacy_compute_gradient_2d_cpu": (ct.c_uint, ct.c_uint, _UP, ct.POINTER(ct.c_double), ct.c_double,
+                                                ct.c_double, ct.c_double, ct.POINTER(ct.c_double),
+                                                ct.POINTER(ct.c_double)),
+    "harmonic_legacy_compute_path_2d_cpu": (ct.c_uint, ct.c_uint, _UP, ct.POINTER(ct.c_double), ct.c_double,
+                                            ct.c_double, ct.c_double, ct.c_double, ct.c_uint, ct.c_int, _UP,
+                                            ct.POINTER(ct.POINTER(ct.c_double))),
+    "harmonic_legacy_free_path_cpu": (ct.POINTER(ct.POINTER(ct.c_double)),),
     # include/epic_hip.h (extensions)
     "epic_hip_device_count": (),
     "epic_hip_update_n_gpu": (_H, ct.c_uint, ct.c_int),

@@ -7,11 +7,11 @@ from the other side.  No other collective sits on the data path; the convergence
 single float every `stagger` sweeps.
 
 Per sweep and rank:
-    1. boundary kernel  : sweep the first and the last owned row (2 x 1 row) on the compute stream
-    2. halo exchange    : on a second stream, after (1): isend the two fresh rows, irecv the neighbours' rows into the
-                          ghost rows of the OUTPUT buffer (torch.distributed P2P = RCCL send/recv over xGMI)
-    3. interior kernel  : sweep every other owned row on the compute stream, concurrently with (2)
-    4. join             : the compute stream waits for the exchange; swap buffers
+    second stream  : sweep the first and the last owned row (2 x 1 row), then isend those two fresh rows and irecv the
+                     neighbours' rows into the ghost rows of the OUTPUT buffer (torch.distributed P2P = RCCL send/recv
+                     over xGMI; one pitch x 4 B message each way per neighbour)
+    compute stream : sweep every other owned row, concurrently with the above
+    join           : the compute stream waits for the exchange; swap buffers
 The sweeps themselves are the library's raw operator (include/epic_hip.h: epic_hip_sweep_2d) on torch-owned device
 memory and torch's streams: PyTorch is plumbing here (memory, streams, process group), the arithmetic is the HIP kernel.
 
@@ -185,27 +185,27 @@ class SlabSolver:
         be, d = self.backend, (self.delta_bits if check else None)
         if check:
             self.delta_bits.zero_()
-        # 1. boundary rows first, so their exchange overlaps the interior sweep
-        be.sweep(src, dst, self.maskw, self.rows, self.pitch, self.first, self.first + 1, d)
-        if self.last > self.first:
-            be.sweep(src, dst, self.maskw, self.rows, self.pitch, self.last, self.last + 1, d)
-        # 2. halo exchange on the second stream
+
+        def boundary_rows():
+            be.sweep(src, dst, self.maskw, self.rows, self.pitch, self.first, self.first + 1, d)
+            if self.last > self.first:
+                be.sweep(src, dst, self.maskw, self.rows, self.pitch, self.last, self.last + 1, d)
+
         if self.cuda:
-            self.ev_boundary.record()
+            # second stream: boundary rows, then their exchange -- all of it concurrent with the interior sweep
+            self.ev_boundary.record()          # everything the previous sweep wrote is visible after this point
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(self.ev_boundary)
-                works = self._exchange(dst)
-                for w in works:
-                    w.wait()           # stream-ordered for NCCL/RCCL: makes comm_stream wait, not the host
+                boundary_rows()
+                for w in self._exchange(dst):
+                    w.wait()                   # stream-ordered for NCCL/RCCL: makes comm_stream wait, not the host
                 self.ev_comm.record()
-        else:
-            works = self._exchange(dst)
-        # 3. interior rows
-        be.sweep(src, dst, self.maskw, self.rows, self.pitch, self.first + 1, self.last, d)
-        # 4. join
-        if self.cuda:
+            be.sweep(src, dst, self.maskw, self.rows, self.pitch, self.first + 1, self.last, d)
             torch.cuda.current_stream().wait_event(self.ev_comm)
         else:
+            boundary_rows()
+            works = self._exchange(dst)
+            be.sweep(src, dst, self.maskw, self.rows, self.pitch, self.first + 1, self.last, d)
             for w in works:
                 w.wait()
         self.cur ^= 1

@@ -108,6 +108,35 @@ int harmonic_utilities_set_cells_2d_cpu(Harmonic *harmonic, unsigned int k, unsi
 int harmonic_utilities_set_cells_2d_gpu(Harmonic *harmonic, unsigned int numThreads, unsigned int k,
                                         unsigned int *v, unsigned int *types);
 
+/* ---- streamline extraction on the host field, libepic/include/epic/harmonic/harmonic_path_cpu.h:42-82.
+ * (x, y) are "float pixel" coordinates (x along m[1]).  *path must be NULL on entry; on success it points at
+ * 2*k floats allocated with new[] -- C++ callers release it with delete[] (src/epic_nav_core_plugin.cpp:303-305),
+ * everyone else with harmonic_free_path_cpu. ---- */
+int harmonic_compute_potential_2d_cpu(Harmonic *harmonic, float x, float y, EPIC_OUT(float) potential); /* :42 */
+int harmonic_compute_gradient_2d_cpu(Harmonic *harmonic, float x, float y, float cdPrecision,
+                                     EPIC_OUT(float) partialX, EPIC_OUT(float) partialY);               /* :56 */
+int harmonic_compute_path_2d_cpu(Harmonic *harmonic, float x, float y, float stepSize, float cdPrecision,
+                                 unsigned int maxLength, EPIC_OUT(unsigned int) k, EPIC_OUT(float *) path); /* :73 */
+int harmonic_free_path_cpu(EPIC_OUT(float *) path);                                                      /* :82 */
+
+/* ---- legacy linear-space SOR and its path follower (the paper's comparison baseline; CPU only, never accelerated):
+ * libepic/include/epic/harmonic/harmonic_legacy_cpu.h:44-77, harmonic_legacy_path_cpu.h:43-90 ---- */
+int harmonic_legacy_sor_2d_float_cpu(unsigned int w, unsigned int h, float epsilon, float omega, unsigned int *locked,
+                                     float *u, EPIC_OUT(unsigned int) iter);
+int harmonic_legacy_sor_2d_double_cpu(unsigned int w, unsigned int h, double epsilon, double omega,
+                                      unsigned int *locked, double *u, EPIC_OUT(unsigned int) iter);
+int harmonic_legacy_sor_2d_long_double_cpu(unsigned int w, unsigned int h, long double epsilon, long double omega,
+                                           unsigned int *locked, long double *u, EPIC_OUT(unsigned int) iter);
+int harmonic_legacy_compute_potential_2d_cpu(unsigned int w, unsigned int h, unsigned int *locked, double *u, double x,
+                                             double y, EPIC_OUT(double) potential);
+int harmonic_legacy_compute_gradient_2d_cpu(unsigned int w, unsigned int h, unsigned int *locked, double *u, double x,
+                                            double y, double cdPrecision, EPIC_OUT(double) partialX,
+                                            EPIC_OUT(double) partialY);
+int harmonic_legacy_compute_path_2d_cpu(unsigned int w, unsigned int h, unsigned int *locked, double *u, double x,
+                                        double y, double stepSize, double cdPrecision, unsigned int maxLength,
+                                        int flipped, EPIC_OUT(unsigned int) k, EPIC_OUT(double *) path);
+int harmonic_legacy_free_path_cpu(EPIC_OUT(double *) path);
+
 #ifdef __cplusplus
 } /* extern "C" */
 } /* namespace epic */
