@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--stagger", type=int, default=100, help="sweeps per step (numIterationsToStaggerCheck)")
     ap.add_argument("--rows-per-task", type=int, default=0)
     ap.add_argument("--cpu-half-sweeps", type=int, default=12, help="bounded CPU sample (about 1 s each at 8192^2)")
-    ap.add_argument("--math", choices=("precise", "fast"), default="precise",
+    ap.add_argument("--math", choices=("precise", "df32", "fast", "traffic"), default="precise",
                     help="precise = libm-equivalent exp/log (the parity mode, default); fast = v_exp_f32/v_log_f32")
     ap.add_argument("--slab", action="store_true", help="use the slab-decomposition driver even on one GPU")
     ap.add_argument("--no-cpu", action="store_true")
@@ -119,7 +119,7 @@ def main():
         assert E.harmonic_initialize_gpu(h, 1024) == 0
         if args.rows_per_task:
             E.epic_hip_set_rows_per_task(h, args.rows_per_task)
-        assert E.epic_hip_set_math_mode(h, 1 if args.math == "fast" else 0) == 0
+        assert E.epic_hip_set_math_mode(h, {"precise": 0, "fast": 1, "traffic": 2, "df32": 3}[args.math]) == 0
         ms = ct.c_float(0.0)
 
         def step():

@@ -122,6 +122,7 @@ Ctx *get_ctx(Harmonic *h, bool create)
     if (e) c->rows_per_task = atoi(e);
     e = getenv("EPIC_HIP_MATH");
     if (e && strcmp(e, "fast") == 0) c->math = 1;
+    if (e && strcmp(e, "df32") == 0) c->math = 3;
     g_ctx[h] = c;
     return c;
 }
@@ -743,7 +744,7 @@ int epic_hip_set_rows_per_task(Harmonic *harmonic, unsigned int rows_per_task)
 int epic_hip_set_math_mode(Harmonic *harmonic, int mode)
 {
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
-    if (!c || (mode != 0 && mode != 1)) return EPIC_ERROR_INVALID_DATA;
+    if (!c || mode < 0 || mode > 3) return EPIC_ERROR_INVALID_DATA;  // 2 = traffic-only diagnostic, 3 = df32 (2-D)
     c->math = mode;
     return EPIC_SUCCESS;
 }
@@ -786,7 +787,7 @@ int epic_hip_sweep_2d(const float *d_in, float *d_out, const uint32_t *d_maskw, 
         row_begin > row_end)
         return EPIC_ERROR_INVALID_DATA;
     if (rows_per_task == 0) rows_per_task = 32;
-    if (math_mode != 0 && math_mode != 1) return EPIC_ERROR_INVALID_DATA;
+    if (math_mode < 0 || math_mode > 3) return EPIC_ERROR_INVALID_DATA;
     return epic_hip::launch_sweep_2d(d_in, d_out, d_maskw, (int)rows, (int)pitch, (int)row_begin, (int)row_end,
                                      (int)rows_per_task, math_mode, d_delta_bits, (hipStream_t)stream) == hipSuccess
                ? EPIC_SUCCESS

@@ -61,8 +61,13 @@ template <bool CHECK, int MATH>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2dArgs a)
 {
     __shared__ double lds[kMathLdsDoubles];  // libm tables (precise math only)
+    __shared__ __attribute__((aligned(16))) float ldsf[kDfLdsFloats];  // df32 tables (df32 math only)
     if (MATH == kMathPrecise) {
         math_tables_to_lds(lds);
+        __syncthreads();
+    }
+    if (MATH == kMathDf32) {
+        df_tables_to_lds(ldsf);
         __syncthreads();
     }
     const int lane = threadIdx.x & (kWave - 1);
@@ -112,10 +117,16 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
         const float rt = wave_from_right(c.x, h);  // u[r][col+4]
         const uint32_t nib = mw >> ((r & 7) * 4);
         float4 o;
-        o.x = cell_update_2d<MATH>(up.x, dn.x, lf, c.y, lds);
-        o.y = cell_update_2d<MATH>(up.y, dn.y, c.x, c.z, lds);
-        o.z = cell_update_2d<MATH>(up.z, dn.z, c.y, c.w, lds);
-        o.w = cell_update_2d<MATH>(up.w, dn.w, c.z, rt, lds);
+        if (MATH == kMathDf32) {  // two cells per packed instruction
+            const v2f a = df_pair_update_2d(v2f{up.x, up.y}, v2f{dn.x, dn.y}, v2f{lf, c.x}, v2f{c.y, c.z}, ldsf);
+            const v2f b = df_pair_update_2d(v2f{up.z, up.w}, v2f{dn.z, dn.w}, v2f{c.y, c.z}, v2f{c.w, rt}, ldsf);
+            o = make_float4(a.x, a.y, b.x, b.y);
+        } else {
+            o.x = cell_update_2d<MATH>(up.x, dn.x, lf, c.y, lds);
+            o.y = cell_update_2d<MATH>(up.y, dn.y, c.x, c.z, lds);
+            o.z = cell_update_2d<MATH>(up.z, dn.z, c.y, c.w, lds);
+            o.w = cell_update_2d<MATH>(up.w, dn.w, c.z, rt, lds);
+        }
         o.x = (nib & 1u) ? c.x : o.x;
         o.y = (nib & 2u) ? c.y : o.y;
         o.z = (nib & 4u) ? c.z : o.z;
@@ -215,11 +226,23 @@ __global__ void set_cells_2d_kernel(float *u, uint32_t *maskw, int rows, int col
 __global__ void eval_math_kernel(const float *in, float *out, size_t n, int which)
 {
     __shared__ double lds[kMathLdsDoubles];
+    __shared__ __attribute__((aligned(16))) float ldsf[kDfLdsFloats];
     math_tables_to_lds(lds);
+    df_tables_to_lds(ldsf);
     __syncthreads();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) out[i] = which ? precise_ln(in[i], lds) : precise_exp(in[i], lds);
+    for (; i < n; i += stride) {
+        const float x = in[i];
+        float r;
+        if (which == 0) r = precise_exp(x, lds);
+        else if (which == 1) r = precise_ln(x, lds);
+        else if (which == 2) r = df_exp2(v2f{x, -0.25f}, ldsf).x;   // df32 pair routines, first component
+        else if (which == 3) r = df_ln2(v2f{x, 2.5f}, ldsf).x;
+        else if (which == 4) r = df_exp2(v2f{0.0f, x}, ldsf).y;         // second component, first one at the other extreme
+        else r = df_ln2(v2f{4.0f, x}, ldsf).y;
+        out[i] = r;
+    }
 }
 
 }  // namespace
@@ -237,6 +260,10 @@ void launch_sweep_2d_math(int math, int nblocks, hipStream_t stream, const Sweep
 {
     if (math == kMathFast)
         hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathFast>), dim3(nblocks), dim3(kWave * kWavesPerBlock), 0, stream, a);
+    else if (math == kMathTraffic)
+        hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathTraffic>), dim3(nblocks), dim3(kWave * kWavesPerBlock), 0, stream, a);
+    else if (math == kMathDf32)
+        hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathDf32>), dim3(nblocks), dim3(kWave * kWavesPerBlock), 0, stream, a);
     else
         hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathPrecise>), dim3(nblocks), dim3(kWave * kWavesPerBlock), 0, stream, a);
 }

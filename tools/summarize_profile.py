@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (gpurun_out/…) into the small text summaries kept under profiles/.
+
+  python tools/summarize_profile.py stats  <dir-with-*_kernel_stats.csv>  > profiles/rNN_kernel_stats_<tag>.txt
+  python tools/summarize_profile.py pmc    <fetch-dir> <write-dir>        > profiles/rNN_hbm_traffic_<tag>.txt
+
+PMC handling follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are collected in separate
+passes; both are reported by rocprofv3 in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced
+streaming reads, so the read side is doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores.
+"""
+import csv
+import glob
+import os
+import statistics
+import sys
+
+
+def find(d, pat):
+    hits = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    if not hits:
+        sys.exit("no %s under %s" % (pat, d))
+    return hits[0]
+
+
+def stats(d):
+    rows = list(csv.DictReader(open(find(d, "*_kernel_stats.csv"))))
+    print("# rocprofv3 --kernel-trace --stats  (%s)" % d)
+    print("%-100s %8s %14s %12s %7s %10s %10s" % ("kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns"))
+    for r in rows:
+        print("%-100s %8s %14s %12.1f %7s %10s %10s" % (r["Name"][:100], r["Calls"], r["TotalDurationNs"],
+                                                        float(r["AverageNs"]), r["Percentage"], r["MinNs"], r["MaxNs"]))
+
+
+def pmc_values(d, counter):
+    rows = list(csv.DictReader(open(find(d, "*_counter_collection.csv"))))
+    vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == counter and "sweep" in r["Kernel_Name"]]
+    names = sorted({r["Kernel_Name"] for r in rows if "sweep" in r["Kernel_Name"]})
+    return vals, names
+
+
+def pmc(fetch_dir, write_dir):
+    f, names = pmc_values(fetch_dir, "FETCH_SIZE")
+    w, _ = pmc_values(write_dir, "WRITE_SIZE")
+    fmean, wmean = statistics.mean(f), statistics.mean(w)
+    read_b = fmean * 1024 * 2      # KiB -> B, gfx950 streaming-read correction x2
+    write_b = wmean * 1024
+    print("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), per sweep dispatch")
+    print("kernels: %s" % "; ".join(n[:90] for n in names))
+    print("dispatches: fetch %d, write %d" % (len(f), len(w)))
+    print("FETCH_SIZE mean %.1f KiB (min %.1f max %.1f)  -> read  %.1f MB after the gfx950 x2 correction" % (
+        fmean, min(f), max(f), read_b / 1e6))
+    print("WRITE_SIZE mean %.1f KiB (min %.1f max %.1f)  -> write %.1f MB" % (wmean, min(w), max(w), write_b / 1e6))
+    print("HBM traffic per launch: %.1f MB" % ((read_b + write_b) / 1e6))
+    return read_b + write_b
+
+
+if __name__ == "__main__":
+    if len(sys.argv) >= 3 and sys.argv[1] == "stats":
+        stats(sys.argv[2])
+    elif len(sys.argv) >= 4 and sys.argv[1] == "pmc":
+        pmc(sys.argv[2], sys.argv[3])
+    else:
+        sys.exit(__doc__)
