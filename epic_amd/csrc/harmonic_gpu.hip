@@ -44,6 +44,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     int rows_per_task = 0;         // 0 = automatic
     int math = 0;                  // 0 = precise (default), 1 = fast; EPIC_HIP_MATH / epic_hip_set_math_mode
+    bool redblack = false;         // 2-D scheme: false = Jacobi ping-pong (default), true = in-place red-black (EPIC_HIP_SCHEME)
     size_t u_bytes() const { return (size_t)rows * pitch * sizeof(float); }
     size_t mask_bytes() const
     {
@@ -123,6 +124,8 @@ Ctx *get_ctx(Harmonic *h, bool create)
     e = getenv("EPIC_HIP_MATH");
     if (e && strcmp(e, "fast") == 0) c->math = 1;
     if (e && strcmp(e, "df32") == 0) c->math = 3;
+    e = getenv("EPIC_HIP_SCHEME");
+    if (e && strcmp(e, "redblack") == 0) c->redblack = true;
     g_ctx[h] = c;
     return c;
 }
@@ -156,8 +159,9 @@ bool ready(const Harmonic *h, const Ctx *c)
     return c && c->buf[0] && c->buf[1] && c->maskw && h->d_u && h->d_locked;
 }
 
-// One Jacobi sweep, enqueued.  check != 0 also zeroes and fills the device delta word.
-hipError_t enqueue_sweep(Ctx *c, bool check)
+// One iteration, enqueued: a Jacobi sweep (buffers swap) or, in the red-black scheme (2-D), the reference's half-sweep
+// of the colour selected by `iteration` in place.  check != 0 also zeroes and fills the device delta word.
+hipError_t enqueue_sweep(Ctx *c, bool check, unsigned iteration)
 {
     hipError_t e;
     if (check) {
@@ -166,9 +170,13 @@ hipError_t enqueue_sweep(Ctx *c, bool check)
     }
     const float *in = c->buf[c->cur];
     float *out = c->buf[c->cur ^ 1];
+    if (c->n == 2 && c->redblack)
+        return epic_hip::launch_sweep_2d(in, c->buf[c->cur], c->maskw, c->rows, c->pitch, 0, c->rows,
+                                         auto_rows_per_task(c), c->math, (int)(iteration & 1u),
+                                         check ? c->d_delta : nullptr, c->stream);
     if (c->n == 2)
         e = epic_hip::launch_sweep_2d(in, out, c->maskw, c->rows, c->pitch, 0, c->rows, auto_rows_per_task(c), c->math,
-                                      check ? c->d_delta : nullptr, c->stream);
+                                      -1, check ? c->d_delta : nullptr, c->stream);
     else
         e = epic_hip::launch_sweep_3d(in, out, c->maskw, c->m[0], c->m[1], c->pitch, 0, c->m[0], c->math,
                                       check ? c->d_delta : nullptr, c->stream);
@@ -473,7 +481,7 @@ int harmonic_update_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmoni
         report(fn, "Invalid data.");
         return EPIC_ERROR_INVALID_DATA;
     }
-    if (enqueue_sweep(c, false) != hipSuccess) {
+    if (enqueue_sweep(c, false, harmonic->currentIteration) != hipSuccess) {
         report(fn, "Failed to execute the 'Jacobi update' kernel.");
         return EPIC_ERROR_KERNEL_EXECUTION;
     }
@@ -491,7 +499,7 @@ int harmonic_update_and_check_gpu(Harmonic *harmonic, unsigned int numThreads)  
         report(fn, "Invalid data.");
         return EPIC_ERROR_INVALID_DATA;
     }
-    if (enqueue_sweep(c, true) != hipSuccess) {
+    if (enqueue_sweep(c, true, harmonic->currentIteration) != hipSuccess) {
         report(fn, "Failed to execute the 'Jacobi update and check' kernel.");
         return EPIC_ERROR_KERNEL_EXECUTION;
     }
@@ -683,7 +691,7 @@ int epic_hip_update_n_gpu(Harmonic *harmonic, unsigned int sweeps, int check_las
     }
     for (unsigned s = 0; s < sweeps; s++) {
         const bool check = check_last && s + 1 == sweeps;
-        if (enqueue_sweep(c, check) != hipSuccess) {
+        if (enqueue_sweep(c, check, harmonic->currentIteration) != hipSuccess) {
             report(fn, "Failed to execute the 'Jacobi update' kernel.");
             return EPIC_ERROR_KERNEL_EXECUTION;
         }
@@ -714,7 +722,7 @@ int epic_hip_timed_sweeps_gpu(Harmonic *harmonic, unsigned int sweeps, unsigned 
     bool checked = false;
     for (unsigned s = 0; s < sweeps && rc == EPIC_SUCCESS; s++) {
         const bool check = check_every && (harmonic->currentIteration % check_every == 0);
-        if (enqueue_sweep(c, check) != hipSuccess) {
+        if (enqueue_sweep(c, check, harmonic->currentIteration) != hipSuccess) {
             report(fn, "Failed to execute the 'Jacobi update' kernel.");
             rc = EPIC_ERROR_KERNEL_EXECUTION;
         }
@@ -746,6 +754,15 @@ int epic_hip_set_math_mode(Harmonic *harmonic, int mode)
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
     if (!c || mode < 0 || mode > 3) return EPIC_ERROR_INVALID_DATA;  // 2 = traffic-only diagnostic, 3 = df32 (2-D)
     c->math = mode;
+    return EPIC_SUCCESS;
+}
+
+int epic_hip_set_scheme(Harmonic *harmonic, int scheme)
+{
+    Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
+    if (!c || (scheme != 0 && scheme != 1)) return EPIC_ERROR_INVALID_DATA;
+    if (scheme == 1 && c->n == 3) return EPIC_ERROR_INVALID_DATA;  // red-black is built for n = 2 only
+    c->redblack = scheme == 1;
     return EPIC_SUCCESS;
 }
 
@@ -789,7 +806,7 @@ int epic_hip_sweep_2d(const float *d_in, float *d_out, const uint32_t *d_maskw, 
     if (rows_per_task == 0) rows_per_task = 32;
     if (math_mode < 0 || math_mode > 3) return EPIC_ERROR_INVALID_DATA;
     return epic_hip::launch_sweep_2d(d_in, d_out, d_maskw, (int)rows, (int)pitch, (int)row_begin, (int)row_end,
-                                     (int)rows_per_task, math_mode, d_delta_bits, (hipStream_t)stream) == hipSuccess
+                                     (int)rows_per_task, math_mode, -1, d_delta_bits, (hipStream_t)stream) == hipSuccess
                ? EPIC_SUCCESS
                : EPIC_ERROR_KERNEL_EXECUTION;
 }

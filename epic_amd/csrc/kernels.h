@@ -10,8 +10,10 @@ namespace epic_hip {
 // One Jacobi sweep of rows [row_begin, row_end) of a pitched rows x pitch grid.  delta_bits == nullptr
 // selects the plain kernel; otherwise max |du| is atomicMax'ed into *delta_bits (float bits, zero it first).
 // math: 0 = precise (libm-equivalent exp/log in f64, the default), 1 = fast (v_exp_f32 / v_log_f32).
+// parity < 0: Jacobi (in != out); parity 0 / 1: red-black half-sweep of that colour, in place (in == out).
 hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int row_begin,
-                           int row_end, int rows_per_task, int math, unsigned *delta_bits, hipStream_t stream);
+                           int row_end, int rows_per_task, int math, int parity, unsigned *delta_bits,
+                           hipStream_t stream);
 hipError_t launch_eval_math(const float *in, float *out, size_t n, int which, hipStream_t stream);
 hipError_t launch_pack_mask_2d(const uint32_t *locked, int rows, int cols, int pitch, int ghost_top,
                                int ghost_bottom, uint32_t *maskw, hipStream_t stream);

@@ -46,6 +46,7 @@ struct Sweep2dArgs {
     int rows_per_task;
     int nstrips;            // ceil(pitch / 256)
     int ntasks;             // nstrips * nchunks
+    int parity;             // red-black scheme only: currentIteration & 1 (which colour this half-sweep updates)
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (b % 8 labels the XCD group).  Give each group a
@@ -57,7 +58,11 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nblk)
     return x * q + (x < rem ? x : rem) + i;
 }
 
-template <bool CHECK, int MATH>
+// RB = false: Jacobi, in -> out.  RB = true: the reference's red-black half-sweep, IN PLACE (in == out): only the
+// cells with (row + col + currentIteration) odd are recomputed (harmonic_cpu.cpp:46-51), from neighbours that all have
+// the other colour and therefore do not change during this launch -- no ordering between waves is needed, and with
+// the precise math the result is the reference CPU solver's, bit for bit, half-sweep for half-sweep.
+template <bool CHECK, int MATH, bool RB>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2dArgs a)
 {
     __shared__ double lds[kMathLdsDoubles];  // libm tables (precise math only)
@@ -117,7 +122,32 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
         const float rt = wave_from_right(c.x, h);  // u[r][col+4]
         const uint32_t nib = mw >> ((r & 7) * 4);
         float4 o;
-        if (MATH == kMathDf32) {  // two cells per packed instruction
+        if (RB) {
+            o = c;
+            if (((r + a.parity) & 1) == 0) {  // scalar: this row's active cells sit in the odd columns (.y, .w)
+                float ny, nw;
+                if (MATH == kMathDf32) {
+                    const v2f n = df_pair_update_2d(v2f{up.y, up.w}, v2f{dn.y, dn.w}, v2f{c.x, c.z}, v2f{c.z, rt}, ldsf);
+                    ny = n.x; nw = n.y;
+                } else {
+                    ny = cell_update_2d<MATH>(up.y, dn.y, c.x, c.z, lds);
+                    nw = cell_update_2d<MATH>(up.w, dn.w, c.z, rt, lds);
+                }
+                o.y = (nib & 2u) ? c.y : ny;
+                o.w = (nib & 8u) ? c.w : nw;
+            } else {                           // even columns (.x, .z)
+                float nx, nz;
+                if (MATH == kMathDf32) {
+                    const v2f n = df_pair_update_2d(v2f{up.x, up.z}, v2f{dn.x, dn.z}, v2f{lf, c.y}, v2f{c.y, c.w}, ldsf);
+                    nx = n.x; nz = n.y;
+                } else {
+                    nx = cell_update_2d<MATH>(up.x, dn.x, lf, c.y, lds);
+                    nz = cell_update_2d<MATH>(up.z, dn.z, c.y, c.w, lds);
+                }
+                o.x = (nib & 1u) ? c.x : nx;
+                o.z = (nib & 4u) ? c.z : nz;
+            }
+        } else if (MATH == kMathDf32) {  // two cells per packed instruction
             const v2f a = df_pair_update_2d(v2f{up.x, up.y}, v2f{dn.x, dn.y}, v2f{lf, c.x}, v2f{c.y, c.z}, ldsf);
             const v2f b = df_pair_update_2d(v2f{up.z, up.w}, v2f{dn.z, dn.w}, v2f{c.y, c.z}, v2f{c.w, rt}, ldsf);
             o = make_float4(a.x, a.y, b.x, b.y);
@@ -127,10 +157,12 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
             o.z = cell_update_2d<MATH>(up.z, dn.z, c.y, c.w, lds);
             o.w = cell_update_2d<MATH>(up.w, dn.w, c.z, rt, lds);
         }
-        o.x = (nib & 1u) ? c.x : o.x;
-        o.y = (nib & 2u) ? c.y : o.y;
-        o.z = (nib & 4u) ? c.z : o.z;
-        o.w = (nib & 8u) ? c.w : o.w;
+        if (!RB) {
+            o.x = (nib & 1u) ? c.x : o.x;
+            o.y = (nib & 2u) ? c.y : o.y;
+            o.z = (nib & 4u) ? c.z : o.z;
+            o.w = (nib & 8u) ? c.w : o.w;
+        }
         if (CHECK) {
             dmax = max2(dmax, fabsf(c.x - o.x));
             dmax = max2(dmax, fabsf(c.y - o.y));
@@ -255,26 +287,26 @@ hipError_t launch_eval_math(const float *in, float *out, size_t n, int which, hi
 }
 
 namespace {
-template <bool CHECK>
+template <bool CHECK, bool RB>
 void launch_sweep_2d_math(int math, int nblocks, hipStream_t stream, const Sweep2dArgs &a)
 {
-    if (math == kMathFast)
-        hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathFast>), dim3(nblocks), dim3(kWave * kWavesPerBlock), 0, stream, a);
-    else if (math == kMathTraffic)
-        hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathTraffic>), dim3(nblocks), dim3(kWave * kWavesPerBlock), 0, stream, a);
-    else if (math == kMathDf32)
-        hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathDf32>), dim3(nblocks), dim3(kWave * kWavesPerBlock), 0, stream, a);
-    else
-        hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathPrecise>), dim3(nblocks), dim3(kWave * kWavesPerBlock), 0, stream, a);
+    const dim3 grid(nblocks), block(kWave * kWavesPerBlock);
+    if (math == kMathFast) hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathFast, RB>), grid, block, 0, stream, a);
+    else if (math == kMathTraffic) hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathTraffic, RB>), grid, block, 0, stream, a);
+    else if (math == kMathDf32) hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathDf32, RB>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathPrecise, RB>), grid, block, 0, stream, a);
 }
 }  // namespace
 
+// parity < 0: Jacobi sweep in -> out.  parity = 0 / 1: red-black half-sweep in place (in == out required).
 hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int row_begin,
-                           int row_end, int rows_per_task, int math, unsigned *delta_bits, hipStream_t stream)
+                           int row_end, int rows_per_task, int math, int parity, unsigned *delta_bits,
+                           hipStream_t stream)
 {
     if (row_end <= row_begin) return hipSuccess;
     if (pitch <= 0 || (pitch % 64) != 0 || rows <= 0 || row_begin < 0 || row_end > rows || rows_per_task <= 0)
         return hipErrorInvalidValue;
+    if ((parity >= 0) != (in == out)) return hipErrorInvalidValue;
     Sweep2dArgs a;
     a.in = in;
     a.out = out;
@@ -288,9 +320,15 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, i
     a.nstrips = (pitch + kStripCols - 1) / kStripCols;
     const int nchunks = (row_end - row_begin + rows_per_task - 1) / rows_per_task;
     a.ntasks = a.nstrips * nchunks;
+    a.parity = parity < 0 ? 0 : (parity & 1);
     const int nblocks = (a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (delta_bits) launch_sweep_2d_math<true>(math, nblocks, stream, a);
-    else launch_sweep_2d_math<false>(math, nblocks, stream, a);
+    if (parity < 0) {
+        if (delta_bits) launch_sweep_2d_math<true, false>(math, nblocks, stream, a);
+        else launch_sweep_2d_math<false, false>(math, nblocks, stream, a);
+    } else {
+        if (delta_bits) launch_sweep_2d_math<true, true>(math, nblocks, stream, a);
+        else launch_sweep_2d_math<false, true>(math, nblocks, stream, a);
+    }
     return hipGetLastError();
 }
 

@@ -123,6 +123,7 @@ _SIGNATURES = {
     "epic_hip_timed_sweeps_gpu": (_H, ct.c_uint, ct.c_uint, ct.POINTER(ct.c_float)),
     "epic_hip_set_rows_per_task": (_H, ct.c_uint),
     "epic_hip_set_math_mode": (_H, ct.c_int),
+    "epic_hip_set_scheme": (_H, ct.c_int),
     "epic_hip_eval_math": (ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_int, ct.c_void_p),
     "epic_hip_get_layout": (_H, _UP, ct.POINTER(ct.c_size_t), ct.POINTER(ct.c_size_t)),
     "epic_hip_pack_mask_2d": (ct.c_void_p, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_int, ct.c_int, ct.c_void_p,
@@ -151,6 +152,9 @@ EPIC_ERROR_INVALID_CUDA_PARAM = 3
 EPIC_ERROR_DEVICE_MALLOC = 4
 MATH_PRECISE = 0
 MATH_FAST = 1
+MATH_DF32 = 3
+SCHEME_JACOBI = 0
+SCHEME_REDBLACK = 1
 EPIC_CELL_TYPE_GOAL = 0
 EPIC_CELL_TYPE_OBSTACLE = 1
 EPIC_CELL_TYPE_FREE = 2

@@ -45,10 +45,20 @@ int epic_hip_timed_sweeps_gpu(EpicHarmonicT *harmonic, unsigned int sweeps, unsi
 /* Tuning knob: rows marched by one wave in the 2-D kernel (0 = automatic).  Also EPIC_HIP_ROWS_PER_TASK. */
 int epic_hip_set_rows_per_task(EpicHarmonicT *harmonic, unsigned int rows_per_task);
 
-/* Arithmetic of the sweep kernels: 0 = precise (default; exp/log equivalent to the host libm's expf/logf, evaluated
- * in f64 -- what the parity claims are made with), 1 = fast (v_exp_f32 / v_log_f32; ~1e-4 relative drift on
- * ill-conditioned maps).  Also EPIC_HIP_MATH=fast|precise in the environment at initialisation. */
+/* Arithmetic of the sweep kernels (also EPIC_HIP_MATH=precise|df32|fast in the environment at initialisation):
+ *   0 precise (default)  exp/log bit-identical to the host libm's expf/logf, evaluated in f64 -- the parity mode;
+ *   3 df32               packed-f32 double-float exp/log, <= 0.53 ulp, unbiased; ~1.3x faster; fixed sweep counts agree
+ *                        with precise to a few ulp, but the reference's absolute max|du| < eps test may never fire on
+ *                        ill-conditioned maps (the two checkerboard sub-sequences of Jacobi settle one ulp apart);
+ *   1 fast               v_exp_f32 / v_log_f32: biased, ~1e-4 relative drift on ill-conditioned maps; no parity claim;
+ *   2 traffic            diagnostic: same loads/stores, trivial arithmetic (2-D only). */
 int epic_hip_set_math_mode(EpicHarmonicT *harmonic, int mode);
+
+/* Iteration scheme of the 2-D solver: 0 = Jacobi ping-pong (default: one iteration recomputes every unlocked cell),
+ * 1 = the reference's red-black Gauss-Seidel, in place (one iteration = one colour, libepic/src/harmonic/harmonic_cpu.cpp:
+ * 46-51); with the precise math mode every half-sweep, the iteration count and the converged field are bit-identical to
+ * harmonic_complete_cpu.  Also EPIC_HIP_SCHEME=jacobi|redblack in the environment at initialisation. */
+int epic_hip_set_scheme(EpicHarmonicT *harmonic, int scheme);
 
 /* Test hook: d_out[i] = which ? ln(d_in[i]) : exp(d_in[i]) with the precise device routines. */
 int epic_hip_eval_math(const float *d_in, float *d_out, size_t n, int which, void *stream);

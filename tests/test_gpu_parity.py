@@ -425,3 +425,71 @@ def test_df32_maps_settle_on_the_reference_field(goldens, name):
     worst = assert_close(h.u_array(), want, h.locked_array(), CONVERGED_TOL, "df32 " + name)
     assert h.delta < 2e-5
     print(f"df32 {name}: sweeps {h.currentIteration}, delta {h.delta:.3e}, max rel {worst:.3e}")
+
+
+# ---- red-black scheme (EPIC_HIP_SCHEME=redblack / epic_hip_set_scheme(h, 1)): the reference's own iteration, in place.
+# With the precise math every half-sweep is the reference CPU solver's bit for bit, so the comparison is with the
+# REFERENCE-GENERATED goldens directly, tolerance 0, including iteration counts and the final delta.
+@pytest.fixture
+def redblack_env():
+    os.environ["EPIC_HIP_SCHEME"] = "redblack"
+    yield
+    del os.environ["EPIC_HIP_SCHEME"]
+
+
+SMALL_2D = [n for n in SMALL if n.startswith("g2d")]
+
+
+@pytest.mark.parametrize("name", SMALL_2D)
+def test_redblack_half_sweeps_equal_reference_golden(goldens, name):
+    g = goldens["small"]
+    m, u0, locked = g[name + "/m"], g[name + "/u0"], g[name + "/locked"]
+    for k in (1, 2, 3, 10):
+        h = make(m, u0, locked)
+        gpu_init(h)
+        assert E.epic_hip_set_scheme(h, eh.SCHEME_REDBLACK) == 0
+        for i in range(k):
+            rc = (E.harmonic_update_and_check_gpu if i == k - 1 else E.harmonic_update_gpu)(h, NT)
+            assert rc in (0, 1)
+        assert E.harmonic_get_potential_values_gpu(h) == 0
+        gpu_fini(h)
+        assert np.array_equal(h.u_array().ravel(), g[f"{name}/rb{k}"]), f"{name}: field after {k} half-sweeps"
+        assert np.float32(h.delta) == g[f"{name}/rb{k}_delta"]
+
+
+@pytest.mark.parametrize("name", SMALL_2D)
+def test_redblack_complete_gpu_is_the_reference_result(goldens, name, redblack_env):
+    g, info = goldens["small"], goldens["manifest"]["small"][name]
+    h = make(g[name + "/m"], g[name + "/u0"], g[name + "/locked"], info["epsilon"], info["stagger"])
+    assert E.harmonic_complete_gpu(h, NT) == 0
+    assert h.currentIteration == info["iterations"] and float(h.delta) == info["delta"]
+    assert np.array_equal(h.u_array().ravel(), g[name + "/converged"])
+
+
+@pytest.mark.parametrize("name", ["basic", "maze", "umass"])
+def test_redblack_maps_are_the_reference_result(goldens, name, redblack_env):
+    """BASELINE configs 1-2 with the reference's own scheme: same half-sweep count, same delta, same field, bit for bit,
+    as harmonic_complete_cpu produced on the reference's maps (tests/golden/generate_goldens.py)."""
+    run = goldens["manifest"]["maps"][name]["runs"]["1e-06"]
+    h = HarmonicMap().load(os.path.join(O.ROOT, "tests", "golden", "maps", name + ".png"))
+    h.solve(process="gpu", epsilon=1e-6)
+    assert h.currentIteration == run["iterations"] and float(h.delta) == run["delta"]
+    assert np.array_equal(h.u_array().ravel(), goldens["maps"][name + "/converged_1e-06"])
+
+
+def test_redblack_random_vs_checker_and_tiling():
+    m = [130, 300]
+    u0, locked = synthetic_grid(m, 17, 0.07)
+    p = O.Problem(m, u0, locked)
+    lib = O.oracle()
+    for rpt in (8, 13, 64):
+        h = make(m, u0, locked)
+        gpu_init(h)
+        assert E.epic_hip_set_scheme(h, 1) == 0 and E.epic_hip_set_rows_per_task(h, rpt) == 0
+        assert E.epic_hip_update_n_gpu(h, 37, 1) in (0, 1)
+        assert E.harmonic_get_potential_values_gpu(h) == 0
+        gpu_fini(h)
+        if rpt == 8:
+            for i in range(37):
+                (lib.oracle_update_and_check if i == 36 else lib.oracle_update)(ct.byref(p.h))
+        assert np.array_equal(h.u_array().ravel(), p.u) and h.delta == p.h.delta and h.currentIteration == 37
