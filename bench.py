@@ -41,9 +41,11 @@ def parse():
     ap.add_argument("--size", type=int, default=8192, help="grid is size x size per GPU")
     ap.add_argument("--stagger", type=int, default=100, help="sweeps per step (numIterationsToStaggerCheck)")
     ap.add_argument("--rows-per-task", type=int, default=0)
-    ap.add_argument("--cpu-half-sweeps", type=int, default=12, help="bounded CPU sample (about 1 s each at 8192^2)")
+    ap.add_argument("--cpu-half-sweeps", type=int, default=40, help="bounded CPU sample (about 0.35 s each at 8192^2)")
     ap.add_argument("--math", choices=("precise", "df32", "fast", "traffic"), default="precise",
                     help="precise = libm-equivalent exp/log (the parity mode, default); fast = v_exp_f32/v_log_f32")
+    ap.add_argument("--scheme", choices=("jacobi", "redblack"), default="jacobi",
+                    help="jacobi = ping-pong sweep of every cell (default); redblack = the reference's in-place half-sweeps")
     ap.add_argument("--slab", action="store_true", help="use the slab-decomposition driver even on one GPU")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-relax", action="store_true")
@@ -67,6 +69,17 @@ def cpu_baseline(m, u0, locked, half_sweeps):
                 kind="port", seconds=round(dt, 2),
                 sample="%d red-black half-sweeps of the same %dx%d grid (full relaxation needs ~5e4, ~15 h on one core)"
                        % (half_sweeps, m[0], m[1]))
+
+
+def measured_traffic(n, math, scheme):
+    """HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950
+    corrections applied by tools/summarize_profile.py) of this same command; recorded under profiles/ because bench.py
+    cannot run under the profiler by itself.  None when no measurement of this configuration is on file."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        return json.load(open(path)).get("%d_%s_%s" % (n, math, scheme))
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -106,6 +119,10 @@ def main():
 
         u0, locked = synthetic_grid(grid)
         free_cells = int((locked == 0).sum())
+        lk2 = locked.reshape(grid) == 0
+        rr, cc = np.indices(lk2.shape, sparse=True)
+        free_by_colour = [int((lk2 & (((rr + cc) & 1) == 1)).sum()), int((lk2 & (((rr + cc) & 1) == 0)).sum())]
+        del lk2
         h = Harmonic()
         h.set_grid(grid, u0, locked)
         h.epsilon = 1e-6
@@ -120,6 +137,7 @@ def main():
         if args.rows_per_task:
             E.epic_hip_set_rows_per_task(h, args.rows_per_task)
         assert E.epic_hip_set_math_mode(h, {"precise": 0, "fast": 1, "traffic": 2, "df32": 3}[args.math]) == 0
+        assert E.epic_hip_set_scheme(h, 1 if args.scheme == "redblack" else 0) == 0
         ms = ct.c_float(0.0)
 
         def step():
@@ -157,9 +175,21 @@ def main():
         free_cells = int(f[0])
 
     sweeps = args.steps * args.stagger
-    value = free_cells * sweeps / wall / 1e6
+
+    def updates_in(iterations, first=0):
+        """Unlocked cells recomputed by `iterations` iterations: all of them per Jacobi sweep; per red-black half-sweep
+        the cells with (row + col + iteration) odd (harmonic_cpu.cpp:46-51)."""
+        if args.scheme == "jacobi" or not use_abi:
+            return free_cells * iterations
+        even_it = (iterations + (1 - first % 2)) // 2      # iterations with even index update (row + col) odd
+        return even_it * free_by_colour[0] + (iterations - even_it) * free_by_colour[1]
+
+    value = updates_in(sweeps, args.warmup * args.stagger) / wall / 1e6
     launch_us = dev_ms * 1e3 / sweeps
-    cells_per_launch = n * n  # per GPU
+    # algorithmic bytes per launch: 8 B per cell the launch recomputes-or-copies.  A Jacobi sweep touches every cell of
+    # the grid; a red-black half-sweep recomputes one colour, i.e. half the grid (its row-major in-place layout still
+    # moves both colours -- that surplus shows up in `traffic`, not in `achieved`).
+    cells_per_launch = n * n if (args.scheme == "jacobi" or not use_abi) else n * n // 2
     achieved = BYTES_PER_CELL_SWEEP * cells_per_launch / (launch_us * 1e-6) / 1e9
     out = {
         "metric": "cell_updates_per_s_log_harmonic_relax_8192sq",
@@ -181,6 +211,7 @@ def main():
             "sweeps_per_step": args.stagger,
             "check_every": args.stagger,
             "math": args.math,
+            "scheme": args.scheme if use_abi else "jacobi",
             "free_cells": free_cells,
             "parallelism": "1 GPU" if world == 1 else "row slabs x%d, 1-row halo exchange per sweep over RCCL" % world,
         },
@@ -191,7 +222,7 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "traffic": None,
+            "traffic": measured_traffic(n, args.math, args.scheme),
             "launch_us": round(launch_us, 3),
             "bytes_per_launch": int(BYTES_PER_CELL_SWEEP * cells_per_launch),
             "note": "8 B x grid cells per launch / mean launch-to-launch device time (HIP events on the kernel's stream)",
@@ -201,22 +232,30 @@ def main():
     if use_abi:
         if upload_s is not None:
             out["config"]["h2d_seconds"] = round(upload_s, 3)
+        assert E.harmonic_uninitialize_gpu(h) == 0
         if not args.no_relax:
-            # the complete relaxation, exactly as the plugin runs it (harmonic_execute_gpu), from the initial state
-            assert E.harmonic_uninitialize_gpu(h) == 0
-            h.u_array().ravel()[:] = u0
-            assert E.harmonic_update_model_gpu(h) == 0
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            rc = E.harmonic_execute_gpu(h, 1024)
-            dt = time.perf_counter() - t0
-            assert rc == 0, rc
-            out["relax"] = {"epsilon": 1e-6, "sweeps": int(h.currentIteration), "seconds": round(dt, 3),
-                            "delta": float(h.delta),
-                            "Mcell_updates_per_s": round(free_cells * h.currentIteration / dt / 1e6, 1),
-                            "note": "includes the final D2H of u"}
-        else:
-            E.harmonic_uninitialize_gpu(h)
+            # the complete relaxation, exactly as the plugin runs it (harmonic_execute_gpu), from the initial state;
+            # once with the benchmarked scheme and once with the other one
+            for scheme in (args.scheme, "redblack" if args.scheme == "jacobi" else "jacobi"):
+                h.u_array().ravel()[:] = u0
+                assert E.harmonic_update_model_gpu(h) == 0
+                assert E.epic_hip_set_scheme(h, 1 if scheme == "redblack" else 0) == 0
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                rc = E.harmonic_execute_gpu(h, 1024)
+                dt = time.perf_counter() - t0
+                assert rc == 0, rc
+                its = int(h.currentIteration)
+                keep = args.scheme
+                args.scheme = scheme
+                upd = updates_in(its)
+                args.scheme = keep
+                out["relax" if scheme == args.scheme else "relax_" + scheme] = {
+                    "scheme": scheme, "epsilon": 1e-6, "iterations": its, "seconds": round(dt, 3),
+                    "delta": float(h.delta), "Mcell_updates_per_s": round(upd / dt / 1e6, 1),
+                    "note": "harmonic_execute_gpu from the initial state, includes the final D2H of u"
+                            + ("; red-black = the reference's scheme, result bit-identical to harmonic_complete_cpu"
+                               if scheme == "redblack" and args.math == "precise" else "")}
         for fn in (E.harmonic_uninitialize_dimension_size_gpu, E.harmonic_uninitialize_potential_values_gpu,
                    E.harmonic_uninitialize_locked_gpu):
             fn(h)

@@ -170,15 +170,19 @@ hipError_t enqueue_sweep(Ctx *c, bool check, unsigned iteration)
     }
     const float *in = c->buf[c->cur];
     float *out = c->buf[c->cur ^ 1];
-    if (c->n == 2 && c->redblack)
-        return epic_hip::launch_sweep_2d(in, c->buf[c->cur], c->maskw, c->rows, c->pitch, 0, c->rows,
-                                         auto_rows_per_task(c), c->math, (int)(iteration & 1u),
-                                         check ? c->d_delta : nullptr, c->stream);
+    if (c->redblack) {
+        float *inout = c->buf[c->cur];
+        if (c->n == 2)
+            return epic_hip::launch_sweep_2d(inout, inout, c->maskw, c->rows, c->pitch, 0, c->rows, auto_rows_per_task(c),
+                                             c->math, (int)(iteration & 1u), check ? c->d_delta : nullptr, c->stream);
+        return epic_hip::launch_sweep_3d(inout, inout, c->maskw, c->m[0], c->m[1], c->pitch, 0, c->m[0], c->math,
+                                         (int)(iteration & 1u), check ? c->d_delta : nullptr, c->stream);
+    }
     if (c->n == 2)
         e = epic_hip::launch_sweep_2d(in, out, c->maskw, c->rows, c->pitch, 0, c->rows, auto_rows_per_task(c), c->math,
                                       -1, check ? c->d_delta : nullptr, c->stream);
     else
-        e = epic_hip::launch_sweep_3d(in, out, c->maskw, c->m[0], c->m[1], c->pitch, 0, c->m[0], c->math,
+        e = epic_hip::launch_sweep_3d(in, out, c->maskw, c->m[0], c->m[1], c->pitch, 0, c->m[0], c->math, -1,
                                       check ? c->d_delta : nullptr, c->stream);
     if (e == hipSuccess) c->cur ^= 1;
     return e;
@@ -761,7 +765,6 @@ int epic_hip_set_scheme(Harmonic *harmonic, int scheme)
 {
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
     if (!c || (scheme != 0 && scheme != 1)) return EPIC_ERROR_INVALID_DATA;
-    if (scheme == 1 && c->n == 3) return EPIC_ERROR_INVALID_DATA;  // red-black is built for n = 2 only
     c->redblack = scheme == 1;
     return EPIC_SUCCESS;
 }

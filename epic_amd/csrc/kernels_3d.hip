@@ -33,9 +33,12 @@ struct Sweep3dArgs {
     int m0, m1, pitch;
     int plane_begin, plane_end;
     int nstrips, nchunks, nplane_groups;
+    int parity;  // red-black scheme only: currentIteration & 1
 };
 
-template <bool CHECK, int MATH>
+// RB = true: the reference's 3-D red-black half-sweep in place (in == out): cells with (x0 + x1 + x2 + currentIteration)
+// even are recomputed (harmonic_cpu.cpp:89-102), all six neighbours have the other colour.
+template <bool CHECK, int MATH, bool RB>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3dArgs a)
 {
     __shared__ double lds[kMathLdsDoubles];  // libm tables (precise math only)
@@ -102,14 +105,29 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3d
         const uint32_t nib = mw >> (lcol & 31);
 
         float4 o;
-        o.x = cell_update_3d<MATH>(a1.x, b1.x, up.x, d1.x, lf, c.y, lds);
-        o.y = cell_update_3d<MATH>(a1.y, b1.y, up.y, d1.y, c.x, c.z, lds);
-        o.z = cell_update_3d<MATH>(a1.z, b1.z, up.z, d1.z, c.y, c.w, lds);
-        o.w = cell_update_3d<MATH>(a1.w, b1.w, up.w, d1.w, c.z, rt, lds);
-        o.x = (nib & 1u) ? c.x : o.x;
-        o.y = (nib & 2u) ? c.y : o.y;
-        o.z = (nib & 4u) ? c.z : o.z;
-        o.w = (nib & 8u) ? c.w : o.w;
+        if (RB) {
+            o = c;
+            if (((x0 + r + a.parity) & 1) == 0) {  // scalar: even x2 columns (.x, .z) are this row's active cells
+                const float nx = cell_update_3d<MATH>(a1.x, b1.x, up.x, d1.x, lf, c.y, lds);
+                const float nz = cell_update_3d<MATH>(a1.z, b1.z, up.z, d1.z, c.y, c.w, lds);
+                o.x = (nib & 1u) ? c.x : nx;
+                o.z = (nib & 4u) ? c.z : nz;
+            } else {
+                const float ny = cell_update_3d<MATH>(a1.y, b1.y, up.y, d1.y, c.x, c.z, lds);
+                const float nw = cell_update_3d<MATH>(a1.w, b1.w, up.w, d1.w, c.z, rt, lds);
+                o.y = (nib & 2u) ? c.y : ny;
+                o.w = (nib & 8u) ? c.w : nw;
+            }
+        } else {
+            o.x = cell_update_3d<MATH>(a1.x, b1.x, up.x, d1.x, lf, c.y, lds);
+            o.y = cell_update_3d<MATH>(a1.y, b1.y, up.y, d1.y, c.x, c.z, lds);
+            o.z = cell_update_3d<MATH>(a1.z, b1.z, up.z, d1.z, c.y, c.w, lds);
+            o.w = cell_update_3d<MATH>(a1.w, b1.w, up.w, d1.w, c.z, rt, lds);
+            o.x = (nib & 1u) ? c.x : o.x;
+            o.y = (nib & 2u) ? c.y : o.y;
+            o.z = (nib & 4u) ? c.z : o.z;
+            o.w = (nib & 8u) ? c.w : o.w;
+        }
         if (CHECK) {
             dmax = max2(dmax, fabsf(c.x - o.x));
             dmax = max2(dmax, fabsf(c.y - o.y));
@@ -155,12 +173,24 @@ __global__ void pack_mask_3d_kernel(const uint32_t *locked, int m0, int m1, int 
 
 }  // namespace
 
+namespace {
+template <bool CHECK, bool RB>
+void launch_sweep_3d_math(int math, dim3 grid, dim3 block, hipStream_t stream, const Sweep3dArgs &a)
+{
+    if (math == kMathFast) hipLaunchKernelGGL((sweep3d_kernel<CHECK, kMathFast, RB>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((sweep3d_kernel<CHECK, kMathPrecise, RB>), grid, block, 0, stream, a);
+}
+}  // namespace
+
+// parity < 0: Jacobi (in != out); parity 0 / 1: red-black half-sweep in place (in == out).
 hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, int m0, int m1, int pitch,
-                           int plane_begin, int plane_end, int math, unsigned *delta_bits, hipStream_t stream)
+                           int plane_begin, int plane_end, int math, int parity, unsigned *delta_bits,
+                           hipStream_t stream)
 {
     if (plane_end <= plane_begin) return hipSuccess;
     if (pitch <= 0 || (pitch % 64) != 0 || m0 <= 0 || m1 <= 0 || plane_begin < 0 || plane_end > m0)
         return hipErrorInvalidValue;
+    if ((parity >= 0) != (in == out)) return hipErrorInvalidValue;
     Sweep3dArgs a;
     a.in = in;
     a.out = out;
@@ -176,13 +206,14 @@ hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, i
     a.nplane_groups = (plane_end - plane_begin + kWavesPerBlock - 1) / kWavesPerBlock;
     const long long nblocks = (long long)a.nstrips * a.nchunks * a.nplane_groups;
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    a.parity = parity < 0 ? 0 : (parity & 1);
     const dim3 grid((unsigned)nblocks), block(kWave * kWavesPerBlock);
-    if (delta_bits) {
-        if (math == kMathFast) hipLaunchKernelGGL((sweep3d_kernel<true, kMathFast>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((sweep3d_kernel<true, kMathPrecise>), grid, block, 0, stream, a);
+    if (parity < 0) {
+        if (delta_bits) launch_sweep_3d_math<true, false>(math, grid, block, stream, a);
+        else launch_sweep_3d_math<false, false>(math, grid, block, stream, a);
     } else {
-        if (math == kMathFast) hipLaunchKernelGGL((sweep3d_kernel<false, kMathFast>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((sweep3d_kernel<false, kMathPrecise>), grid, block, 0, stream, a);
+        if (delta_bits) launch_sweep_3d_math<true, true>(math, grid, block, stream, a);
+        else launch_sweep_3d_math<false, true>(math, grid, block, stream, a);
     }
     return hipGetLastError();
 }

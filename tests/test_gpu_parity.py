@@ -437,7 +437,7 @@ def redblack_env():
     del os.environ["EPIC_HIP_SCHEME"]
 
 
-SMALL_2D = [n for n in SMALL if n.startswith("g2d")]
+SMALL_2D = SMALL  # 2-D and 3-D: both have the reference colouring on the device
 
 
 @pytest.mark.parametrize("name", SMALL_2D)
