@@ -95,11 +95,22 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                      % (args.gpus, args.gpus))
         args.gpus = world
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("EPIC_BENCH_BACKEND", "nccl")   # "gloo": ranks may share a GPU (1-GPU smoke of the N > 1 path)
+    if ndev < 1:
+        sys.exit("bench.py: no GPU visible")
+    if backend == "nccl" and local >= ndev:
+        sys.exit("bench.py: rank %d has no GPU of its own (%d visible)" % (local, ndev))
+    local = local % ndev
     torch.cuda.set_device(local)
+    red_dev = "cuda" if backend == "nccl" else "cpu"          # where the few scalar reductions of this script live
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from epic_amd import epic_harmonic as eh
     from epic_amd.synthetic import synthetic_grid
@@ -167,10 +178,10 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(t[0]), float(t[1])
-        f = torch.tensor([free_cells], dtype=torch.int64, device="cuda")
+        f = torch.tensor([free_cells], dtype=torch.int64, device=red_dev)
         dist.all_reduce(f)
         free_cells = int(f[0])
 

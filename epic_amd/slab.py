@@ -168,7 +168,27 @@ class SlabSolver:
         return self.buf[self.cur][self.first:self.last + 1, :self.cols].cpu().numpy()
 
     # ---- sweeps ------------------------------------------------------------------------------------------
+    def _exchange_staged(self, dst):
+        """Device tensors over a host-only process group (gloo): the rows are staged through host memory.  Only for
+        exercising the multi-process path on a box with a single GPU; on a multi-GPU node the group is RCCL."""
+        torch.cuda.current_stream().synchronize()
+        ops, recvs = [], []
+        for has, mine, ghost, peer in ((self.ghost_top, self.first, 0, self.rank - 1),
+                                       (self.ghost_bottom, self.last, self.rows - 1, self.rank + 1)):
+            if has:
+                buf = torch.empty(self.pitch, dtype=torch.float32)
+                ops.append(dist.P2POp(dist.isend, dst[mine].cpu(), peer, self.group))
+                ops.append(dist.P2POp(dist.irecv, buf, peer, self.group))
+                recvs.append((ghost, buf))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        for ghost, buf in recvs:
+            dst[ghost].copy_(buf)
+        return []
+
     def _exchange(self, dst):
+        if self.cuda and self.world > 1 and dist.get_backend(self.group) == "gloo":
+            return self._exchange_staged(dst)
         ops = []
         if self.ghost_top:
             ops.append(dist.P2POp(dist.isend, dst[self.first], self.rank - 1, self.group))
@@ -215,6 +235,8 @@ class SlabSolver:
         """Global max |du| of the last check sweep (one MAX all-reduce of one float)."""
         t = self.delta_bits.view(torch.float32).clone()
         if self.world > 1:
+            if self.cuda and dist.get_backend(self.group) == "gloo":
+                t = t.cpu()
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         self.delta = float(t.item())
         return self.delta
