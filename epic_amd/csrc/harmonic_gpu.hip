@@ -18,7 +18,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 #include <mutex>
+#include <tuple>
 #include <unordered_map>
 
 #include "../../include/epic/epic_abi.h"
@@ -44,6 +46,9 @@ struct Ctx {
     hipStream_t stream = nullptr;
     int rows_per_task = 0;         // 0 = automatic
     int math = 0;                  // 0 = precise (default), 1 = fast; EPIC_HIP_MATH / epic_hip_set_math_mode
+    // Launch-bound grids replay the plain sweeps between two checks from a captured hipGraph; key = (count, starting
+    // buffer, starting parity, math, scheme, rows_per_task) -- everything a captured launch sequence depends on.
+    std::map<std::tuple<unsigned, int, int, int, int, int>, hipGraphExec_t> graphs;
     bool redblack = false;         // 2-D scheme: false = Jacobi ping-pong (default), true = in-place red-black (EPIC_HIP_SCHEME)
     size_t u_bytes() const { return (size_t)rows * pitch * sizeof(float); }
     size_t mask_bytes() const
@@ -54,6 +59,8 @@ struct Ctx {
 
 std::mutex g_mu;
 std::unordered_map<Harmonic *, Ctx *> g_ctx;
+
+void drop_graphs(Ctx *c);  // captured launch sequences hold the buffer addresses: drop them whenever a buffer goes away
 
 void report(const char *fn, const char *msg) { fprintf(stderr, "Error[%s]: %s\n", fn, msg); }
 
@@ -98,6 +105,7 @@ Ctx *get_ctx(Harmonic *h, bool create)
         // caller without uninitialize: drop the stale device state.
         if (h->d_m == nullptr && h->d_u == nullptr && h->d_locked == nullptr && h->d_delta == nullptr &&
             (c->buf[0] || c->maskw || c->d_m || c->d_delta)) {
+            drop_graphs(c);
             for (float *&b : c->buf) { if (b) (void)hipFree(b); b = nullptr; }
             if (c->maskw) (void)hipFree(c->maskw);
             if (c->d_m) (void)hipFree(c->d_m);
@@ -137,6 +145,7 @@ void drop_ctx_if_empty(Harmonic *h)
     if (it == g_ctx.end()) return;
     Ctx *c = it->second;
     if (c->buf[0] || c->maskw || c->d_m || c->d_delta) return;
+    drop_graphs(c);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->h_delta) (void)hipHostFree(c->h_delta);
     delete c;
@@ -149,9 +158,14 @@ int auto_rows_per_task(const Ctx *c)
     const long long nstrips = (c->pitch + 255) / 256;
     // The kernel is VALU-bound (precise math), so what matters is keeping every SIMD at 8 resident waves with a
     // short tail: aim at >= 16384 wave-tasks (2 rounds of 8192 resident waves); 2 extra halo rows per task are cheap.
+    // Small grids (the ROS maps are 0.1-1 Mcell) cannot fill the chip at all: there one row per wave is best
+    // (310 x 940: 4.3 us per sweep at 1 row per task vs 11.4 us at 8, both measured).
     long long r = (long long)c->rows * nstrips / 16384;
-    r = r / 8 * 8;
-    return (int)std::min<long long>(64, std::max<long long>(8, r));
+    if (r >= 8) r = r / 8 * 8;
+    else if (r >= 4) r = 4;
+    else if (r >= 2) r = 2;
+    else r = 1;
+    return (int)std::min<long long>(64, r);
 }
 
 bool ready(const Harmonic *h, const Ctx *c)
@@ -185,6 +199,49 @@ hipError_t enqueue_sweep(Ctx *c, bool check, unsigned iteration)
         e = epic_hip::launch_sweep_3d(in, out, c->maskw, c->m[0], c->m[1], c->pitch, 0, c->m[0], c->math, -1,
                                       check ? c->d_delta : nullptr, c->stream);
     if (e == hipSuccess) c->cur ^= 1;
+    return e;
+}
+
+void drop_graphs(Ctx *c)
+{
+    for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.second);
+    c->graphs.clear();
+}
+
+// `count` plain (unchecked) iterations starting at iteration number `first`.  Kernels of a few microseconds are
+// bound by the host's launch rate (~4 us each); for those the sequence is captured once into a hipGraph and replayed
+// (inter-kernel gap ~1.5 us, MI355X_MICROARCH.md "boundary" row).  Large grids keep the plain launches.
+hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
+{
+    const bool small = (long long)c->rows * c->pitch <= (1ll << 22);
+    static const bool no_graph = getenv("EPIC_HIP_NO_GRAPH") != nullptr;
+    if (!small || count < 8 || no_graph) {
+        for (unsigned i = 0; i < count; i++) {
+            hipError_t e = enqueue_sweep(c, false, first + i);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    const auto key = std::make_tuple(count, c->cur, (int)(first & 1u), c->math, (int)c->redblack, auto_rows_per_task(c));
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) {
+        const int cur0 = c->cur;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) return e;
+        for (unsigned i = 0; i < count && e == hipSuccess; i++) e = enqueue_sweep(c, false, first + i);
+        hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
+        c->cur = cur0;  // nothing has run yet
+        if (e == hipSuccess) e = e2;
+        if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) return e;
+        if (c->graphs.size() >= 16) drop_graphs(c);
+        it = c->graphs.emplace(key, exec).first;
+    }
+    hipError_t e = hipGraphLaunch(it->second, c->stream);
+    if (e == hipSuccess && !c->redblack && (count & 1u)) c->cur ^= 1;
     return e;
 }
 
@@ -323,6 +380,7 @@ int harmonic_initialize_potential_values_gpu(Harmonic *harmonic)  // harmonic_mo
         report(fn, "Invalid input (dimensions differ from the locked cells already on the device).");
         return EPIC_ERROR_INVALID_DATA;
     }
+    drop_graphs(c);
     for (float *&b : c->buf) { if (b) (void)hipFree(b); b = nullptr; }
     dims_from(harmonic, c);
     for (int b = 0; b < 2; b++) {
@@ -345,6 +403,7 @@ int harmonic_uninitialize_potential_values_gpu(Harmonic *harmonic)  // harmonic_
     Ctx *c = find_ctx(harmonic);
     if (c) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
+        drop_graphs(c);
         for (float *&b : c->buf) {
             if (b && hipFree(b) != hipSuccess) {
                 report("harmonic_uninitialize_potential_values_gpu", "Failed to free device-side memory for the potential values.");
@@ -379,6 +438,7 @@ int harmonic_initialize_locked_gpu(Harmonic *harmonic)  // harmonic_model_gpu.cu
         report(fn, "Invalid input (dimensions differ from the potential values already on the device).");
         return EPIC_ERROR_INVALID_DATA;
     }
+    drop_graphs(c);
     if (c->maskw) { (void)hipFree(c->maskw); c->maskw = nullptr; }
     dims_from(harmonic, c);
     if (hipMalloc((void **)&c->maskw, c->mask_bytes()) != hipSuccess) {
@@ -400,6 +460,7 @@ int harmonic_uninitialize_locked_gpu(Harmonic *harmonic)  // harmonic_model_gpu.
     Ctx *c = find_ctx(harmonic);
     if (c && c->maskw) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
+        drop_graphs(c);
         if (hipFree(c->maskw) != hipSuccess) {
             report("harmonic_uninitialize_locked_gpu", "Failed to free device-side memory for the locked cells.");
             rc = EPIC_ERROR_DEVICE_FREE;
@@ -581,11 +642,16 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
                 return result;
             }
         } else {
-            result = harmonic_update_gpu(harmonic, numThreads);
-            if (result != EPIC_SUCCESS) {
+            // every plain iteration returns SUCCESS (which clears a previous CONVERGED), so the ones up to the next
+            // check need no host decision in between: enqueue them as one batch
+            const unsigned batch = stagger - harmonic->currentIteration % stagger;
+            if (enqueue_plain_batch(c, batch, harmonic->currentIteration) != hipSuccess) {
                 report(fn, "Failed to perform the Jacobi update step.");
-                return result;
+                return EPIC_ERROR_KERNEL_EXECUTION;
             }
+            harmonic->d_u = c->buf[c->cur];
+            harmonic->currentIteration += batch;
+            result = EPIC_SUCCESS;
         }
     }
 
@@ -693,14 +759,13 @@ int epic_hip_update_n_gpu(Harmonic *harmonic, unsigned int sweeps, int check_las
         report(fn, "Invalid data.");
         return EPIC_ERROR_INVALID_DATA;
     }
-    for (unsigned s = 0; s < sweeps; s++) {
-        const bool check = check_last && s + 1 == sweeps;
-        if (enqueue_sweep(c, check, harmonic->currentIteration) != hipSuccess) {
-            report(fn, "Failed to execute the 'Jacobi update' kernel.");
-            return EPIC_ERROR_KERNEL_EXECUTION;
-        }
-        if (!check) harmonic->currentIteration++;
+    const unsigned plain = sweeps - ((check_last && sweeps > 0) ? 1u : 0u);
+    if (enqueue_plain_batch(c, plain, harmonic->currentIteration) != hipSuccess ||
+        (plain < sweeps && enqueue_sweep(c, true, harmonic->currentIteration + plain) != hipSuccess)) {
+        report(fn, "Failed to execute the 'Jacobi update' kernel.");
+        return EPIC_ERROR_KERNEL_EXECUTION;
     }
+    harmonic->currentIteration += plain;
     harmonic->d_u = c->buf[c->cur];
     if (check_last && sweeps > 0) {
         int rc = read_delta(harmonic, c, fn);
