@@ -54,11 +54,9 @@ constexpr int kMathTraffic = 2;  // diagnostic: neighbours averaged with 3 adds 
 constexpr int kMathDf32 = 3;     // packed-f32 double-float exp/log (2-D kernel), see below
 
 // ---- libm-equivalent expf / logf in f64 (glibc 2.35 algorithm, see header) --------------------------------
-// LDS image (160 doubles = 1.25 KiB per workgroup): [0, 32) exp table; [32, 160) log table, 64 x {invc, y0}.
-constexpr int kMathLdsDoubles = 160;
 
 // glibc's tab[i] = bits(2^(i/32)) - (i << 47) (e_exp2f_data.c, EXP2F_TABLE_BITS = 5); the kernel wants the plain
-// 2^(i/32), so math_tables_to_lds() adds the i << 47 back.
+// 2^(i/32), so math_tables_load() adds the i << 47 back.
 __constant__ const uint64_t kExpTab[32] = {
     0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51, 0x3fef72b83c7d517b,
     0x3fef54873168b9aa, 0x3fef387a6e756238, 0x3fef1e9df51fdee1, 0x3fef06fe0a31b715, 0x3feef1a7373aa9cb,
@@ -80,19 +78,37 @@ __constant__ const double kLogTab[32] = {
     0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2,  0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2,
 };
 
-// Stage the tables into LDS; call from every thread of a >= 128-thread workgroup, then __syncthreads().
-// The log table is expanded over the binade index k = 0..3 (arguments in [0.7, 11.2) cover the sums of 4 or 6 terms
-// <= 1 with one term == 1): entry (k, i) = {invc_i, logc_i + k ln2}, so the kernel needs neither k nor a multiply.
-__device__ __forceinline__ void math_tables_to_lds(double *lds)
+// The tables live in registers, one entry per lane, and are fetched with ds_bpermute_b32 (the LDS crossbar, no LDS
+// memory, no staging pass or barrier at kernel start): lane L holds exp entry L & 31 (2 dwords) and log entry L (4
+// dwords).  The log table is expanded over the binade index k = 0..3 (arguments in [0.7, 11.2) cover the sums of 4 or 6
+// terms <= 1 with one term == 1): entry 16 k + i = {invc_i, logc_i + k ln2}, so the kernel needs neither k nor a
+// multiply.  ds_bpermute reads the SOURCE lane's register, so every lane of the wave must be active where it is used:
+// the kernels keep all 64 lanes live (pitch is a multiple of 256 floats).
+struct MathTab {
+    int e_lo, e_hi;          // 2^((L & 31)/32)
+    int i_lo, i_hi;          // invc of log entry L
+    int y_lo, y_hi;          // logc + k ln2 of log entry L
+};
+
+__device__ __forceinline__ MathTab math_tables_load()
 {
-    const int t = threadIdx.x;
-    if (t < 32) {
-        lds[t] = __builtin_bit_cast(double, kExpTab[t] + ((uint64_t)t << 47));
-    } else if (t < 32 + 64) {
-        const int e = t - 32, k = e >> 4, i = e & 15;
-        lds[32 + 2 * e] = kLogTab[2 * i];
-        lds[32 + 2 * e + 1] = kLogTab[2 * i + 1] + (double)k * 0x1.62e42fefa39efp-1;
-    }
+    const int lane = threadIdx.x & 63;
+    const uint64_t e = kExpTab[lane & 31] + ((uint64_t)(lane & 31) << 47);
+    const int k = lane >> 4, i = lane & 15;
+    const uint64_t inv = __builtin_bit_cast(uint64_t, kLogTab[2 * i]);
+    const uint64_t y0 = __builtin_bit_cast(uint64_t, kLogTab[2 * i + 1] + (double)k * 0x1.62e42fefa39efp-1);
+    MathTab t;
+    t.e_lo = (int)(uint32_t)e; t.e_hi = (int)(uint32_t)(e >> 32);
+    t.i_lo = (int)(uint32_t)inv; t.i_hi = (int)(uint32_t)(inv >> 32);
+    t.y_lo = (int)(uint32_t)y0; t.y_hi = (int)(uint32_t)(y0 >> 32);
+    return t;
+}
+
+__device__ __forceinline__ double bperm_f64(int byte_addr, int lo, int hi)
+{
+    const uint32_t l = (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, lo);
+    const uint32_t h = (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, hi);
+    return __builtin_bit_cast(double, ((uint64_t)h << 32) | l);
 }
 
 // e^x for x <= 0.  glibc e_expf.c: z = x N/ln2, k = round(z), r = z - k, s = 2^(k/N) from the table, cubic in r,
@@ -100,7 +116,7 @@ __device__ __forceinline__ void math_tables_to_lds(double *lds)
 // (the double result carries ~2^-30 of slack, checked exhaustively by test_device_libm_replica): k is taken from the
 // low word of fma(x, N/ln2, 1.5 * 2^52) (glibc's own non-intrinsic path does the same with an add), r comes from a
 // second fma instead of a rounded product, the cubic is in Horner form.
-__device__ __forceinline__ float precise_exp(float x, const double *lds)
+__device__ __forceinline__ float precise_exp(float x, const MathTab &tab)
 {
     const double xd = (double)x;
     const double kInvLn2N = 0x1.71547652b82fep+5, kShift = 0x1.8p+52;
@@ -110,7 +126,8 @@ __device__ __forceinline__ float precise_exp(float x, const double *lds)
     const double r = __builtin_fma(xd, kInvLn2N, -kd);
     // glibc forms s = 2^(k/N) by adding k << 47 to the table word; 2^((k mod N)/N) scaled by ldexp is the same number
     // and, unlike the integer add, degrades to 0 for the x = -1e6 terms (neighbours that are obstacles) without a clamp.
-    const double s0 = lds[ki & 31];
+    // Lane (k mod 64) holds entry k mod 32: the permute takes the lane from address bits 7..2, so k << 2 needs no mask.
+    const double s0 = bperm_f64(ki << 2, tab.e_lo, tab.e_hi);
     double y = __builtin_fma(0x1.c6af84b912394p-20, r, 0x1.ebfce50fac4f3p-13);
     y = __builtin_fma(y, r, 0x1.62e42ff0c52d6p-6);
     y = __builtin_fma(y, r, 1.0);
@@ -119,13 +136,13 @@ __device__ __forceinline__ float precise_exp(float x, const double *lds)
 
 // ln(s) for s in [0.7, 11.2).  glibc e_logf.c: s = 2^k z with z in [OFF, 2 OFF) split into 16 sub-intervals,
 // r = z invc - 1, ln s = log1p(r) + logc + k ln2 with a cubic for log1p, all in double.
-__device__ __forceinline__ float precise_ln(float sf, const double *lds)
+__device__ __forceinline__ float precise_ln(float sf, const MathTab &tab)
 {
     const uint32_t ix = __builtin_bit_cast(uint32_t, sf);
     const uint32_t tmp = ix - 0x3f330000u;
-    const uint32_t e = tmp >> 19;                    // 16 k + i
+    const int addr = (int)((tmp >> 17) & 0xfcu);     // 4 * (16 k + i): lane of the table entry
     const uint32_t iz = ix - (tmp & 0xff800000u);    // z = s / 2^k
-    const double invc = lds[32 + 2 * e], y0 = lds[32 + 2 * e + 1];
+    const double invc = bperm_f64(addr, tab.i_lo, tab.i_hi), y0 = bperm_f64(addr, tab.y_lo, tab.y_hi);
     const double z = (double)__builtin_bit_cast(float, iz);
     const double r = __builtin_fma(z, invc, -1.0);
     const double r2 = r * r;
@@ -213,18 +230,18 @@ __device__ __forceinline__ v2f df_pair_update_2d(v2f up, v2f dn, v2f lf, v2f rt,
 }
 
 template <int MATH>
-__device__ __forceinline__ float m_exp(float x, const double *lds)
+__device__ __forceinline__ float m_exp(float x, const MathTab &lds)
 {
     return MATH == kMathFast ? hw_exp(x) : precise_exp(x, lds);
 }
 template <int MATH>
-__device__ __forceinline__ float m_ln(float s, const double *lds)
+__device__ __forceinline__ float m_ln(float s, const MathTab &lds)
 {
     return MATH == kMathFast ? hw_ln(s) : precise_ln(s, lds);
 }
 
 template <int MATH>
-__device__ __forceinline__ float cell_update_2d(float up, float down, float left, float right, const double *lds)
+__device__ __forceinline__ float cell_update_2d(float up, float down, float left, float right, const MathTab &lds)
 {
     if (MATH == kMathTraffic) return ((up + down) + left) + right;
     float mx = max2(max2(max2(up, down), left), right);
@@ -237,7 +254,7 @@ __device__ __forceinline__ float cell_update_2d(float up, float down, float left
 
 template <int MATH>
 __device__ __forceinline__ float cell_update_3d(float a0, float a1, float b0, float b1, float c0, float c1,
-                                                const double *lds)
+                                                const MathTab &lds)
 {
     float mx = max2(max2(max2(max2(max2(a0, a1), b0), b1), c0), c1);
     float s = m_exp<MATH>(a0 - mx, lds) + m_exp<MATH>(a1 - mx, lds);

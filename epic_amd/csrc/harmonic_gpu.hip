@@ -857,7 +857,7 @@ unsigned int epic_hip_pitch_for_cols(unsigned int cols) { return (unsigned)epic_
 int epic_hip_pack_mask_2d(const uint32_t *d_locked, unsigned int rows, unsigned int cols, unsigned int pitch,
                           int ghost_top, int ghost_bottom, uint32_t *d_maskw, void *stream)
 {
-    if (!d_locked || !d_maskw || rows < 3 || cols < 3 || pitch < cols || pitch % 64 != 0) return EPIC_ERROR_INVALID_DATA;
+    if (!d_locked || !d_maskw || rows < 3 || cols < 3 || pitch < cols || pitch % 256 != 0) return EPIC_ERROR_INVALID_DATA;
     return epic_hip::launch_pack_mask_2d(d_locked, (int)rows, (int)cols, (int)pitch, ghost_top, ghost_bottom, d_maskw,
                                          (hipStream_t)stream) == hipSuccess
                ? EPIC_SUCCESS
@@ -868,7 +868,7 @@ int epic_hip_sweep_2d(const float *d_in, float *d_out, const uint32_t *d_maskw, 
                       unsigned int row_begin, unsigned int row_end, unsigned int rows_per_task, int math_mode,
                       uint32_t *d_delta_bits, void *stream)
 {
-    if (!d_in || !d_out || !d_maskw || d_in == d_out || rows < 3 || pitch % 64 != 0 || pitch == 0 || row_end > rows ||
+    if (!d_in || !d_out || !d_maskw || d_in == d_out || rows < 3 || pitch % 256 != 0 || pitch == 0 || row_end > rows ||
         row_begin > row_end)
         return EPIC_ERROR_INVALID_DATA;
     if (rows_per_task == 0) rows_per_task = 32;

@@ -21,7 +21,8 @@ hipError_t launch_fill(float *p, size_t n, float v, hipStream_t stream);
 hipError_t launch_set_cells_2d(float *u, uint32_t *maskw, int rows, int cols, int pitch, unsigned k,
                                const unsigned *v, const unsigned *types, hipStream_t stream);
 
-inline int pitch_for_cols(int cols) { return (cols + 63) / 64 * 64; }
+// rows are padded to whole wave-strips (256 floats = 1 KiB): every lane of every wave is in bounds, always
+inline int pitch_for_cols(int cols) { return (cols + 255) / 256 * 256; }
 inline size_t mask_words_2d(int rows, int pitch) { return (size_t)((rows + 7) / 8) * (size_t)(pitch / 4); }
 
 // ---- 3-D (kernels_3d.hip) -------------------------------------------------------------------

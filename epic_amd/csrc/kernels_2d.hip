@@ -42,7 +42,7 @@ struct Sweep2dArgs {
     const uint32_t *maskw;  // tiled bits: word (r>>3, c>>2), bit 4*(r&7) + (c&3); 1 = locked
     unsigned *delta_bits;   // max |du| as float bits (atomicMax), used when CHECK
     int rows;               // rows of the (local) grid, including ghost rows in slab mode
-    int pitch;              // floats per row, multiple of 64
+    int pitch;              // floats per row, multiple of 256
     int row_begin, row_end; // rows swept by this launch
     int rows_per_task;
     int nstrips;            // ceil(pitch / 256)
@@ -67,12 +67,9 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nblk)
 template <bool CHECK, int MATH, bool RB>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2dArgs a)
 {
-    __shared__ double lds[kMathLdsDoubles];  // libm tables (precise math only)
     __shared__ __attribute__((aligned(16))) float ldsf[kDfLdsFloats];  // df32 tables (df32 math only)
-    if (MATH == kMathPrecise) {
-        math_tables_to_lds(lds);
-        __syncthreads();
-    }
+    MathTab lds = {};  // libm tables, one entry per lane (precise math only)
+    if (MATH == kMathPrecise) lds = math_tables_load();
     if (MATH == kMathDf32) {
         df_tables_to_lds(ldsf);
         __syncthreads();
@@ -89,8 +86,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
 
     const int col0 = strip * kStripCols;
     const int col = col0 + lane * kColsPerLane;
-    const bool active = col < a.pitch;                       // pitch % 64 == 0: whole 16-lane groups drop out
-    const int lcol = active ? col : a.pitch - kColsPerLane;  // every lane keeps loading (DPP wants all lanes live)
+    const int lcol = col;  // pitch % 256 == 0: every lane of every strip is in bounds (DPP / bpermute want all lanes live)
     const int hcol = (lane == 0) ? max(col0 - 1, 0) : min(col0 + kStripCols, a.pitch - 1);
     const bool edge_lane = (lane == 0) | (lane == kWave - 1);
     const int rlast = a.rows - 1;
@@ -187,10 +183,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
             dmax = max2(dmax, fabsf(c.w - o.w));
         }
         float *orow = a.out + (size_t)r * pitch;
-        if (active) {
-            if (a.flags & 2) __builtin_nontemporal_store(vf4{o.x, o.y, o.z, o.w}, reinterpret_cast<vf4 *>(orow + col));
-            else *reinterpret_cast<float4 *>(orow + col) = o;
-        }
+        if (a.flags & 2) __builtin_nontemporal_store(vf4{o.x, o.y, o.z, o.w}, reinterpret_cast<vf4 *>(orow + col));
+        else *reinterpret_cast<float4 *>(orow + col) = o;
     };
 
     // Software pipeline, rotated by hand over a 4-row register ring so that no register moves (and hence no
@@ -214,7 +208,6 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
     }
 
     if (CHECK) {
-        if (!active) dmax = 0.0f;
         dmax = wave_max(dmax);
         if (lane == 0 && dmax > 0.0f) atomicMax(a.delta_bits, __float_as_uint(dmax));
     }
@@ -274,15 +267,18 @@ __global__ void set_cells_2d_kernel(float *u, uint32_t *maskw, int rows, int col
 // libm-replica check: out[i] = which ? ln(in[i]) : exp(in[i]) with the PRECISE device routines (test hook).
 __global__ void eval_math_kernel(const float *in, float *out, size_t n, int which)
 {
-    __shared__ double lds[kMathLdsDoubles];
     __shared__ __attribute__((aligned(16))) float ldsf[kDfLdsFloats];
-    math_tables_to_lds(lds);
+    const MathTab lds = math_tables_load();
     df_tables_to_lds(ldsf);
     __syncthreads();
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // the table fetch is a cross-lane permute: all 64 lanes must stay active, so the loop count is wave-uniform and
+    // out-of-range lanes work on a clamped index and skip the store
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
-        const float x = in[i];
+    const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t trips = (n + stride - 1) / stride;
+    for (size_t t = 0; t < trips; t++) {
+        const size_t i = first + t * stride;
+        const float x = in[i < n ? i : n - 1];
         float r;
         if (which == 0) r = precise_exp(x, lds);
         else if (which == 1) r = precise_ln(x, lds);
@@ -290,7 +286,7 @@ __global__ void eval_math_kernel(const float *in, float *out, size_t n, int whic
         else if (which == 3) r = df_ln2(v2f{x, 2.5f}, ldsf).x;
         else if (which == 4) r = df_exp2(v2f{0.0f, x}, ldsf).y;         // second component, first one at the other extreme
         else r = df_ln2(v2f{4.0f, x}, ldsf).y;
-        out[i] = r;
+        if (i < n) out[i] = r;
     }
 }
 
@@ -332,7 +328,7 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, i
                            hipStream_t stream)
 {
     if (row_end <= row_begin) return hipSuccess;
-    if (pitch <= 0 || (pitch % 64) != 0 || rows <= 0 || row_begin < 0 || row_end > rows || rows_per_task <= 0)
+    if (pitch <= 0 || (pitch % 256) != 0 || rows <= 0 || row_begin < 0 || row_end > rows || rows_per_task <= 0)
         return hipErrorInvalidValue;
     if ((parity >= 0) != (in == out)) return hipErrorInvalidValue;
     Sweep2dArgs a;

@@ -41,11 +41,8 @@ struct Sweep3dArgs {
 template <bool CHECK, int MATH, bool RB>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3dArgs a)
 {
-    __shared__ double lds[kMathLdsDoubles];  // libm tables (precise math only)
-    if (MATH == kMathPrecise) {
-        math_tables_to_lds(lds);
-        __syncthreads();
-    }
+    MathTab lds = {};  // libm tables, one entry per lane (precise math only)
+    if (MATH == kMathPrecise) lds = math_tables_load();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int b = blockIdx.x;
@@ -60,8 +57,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3d
 
     const int col0 = strip * kStripCols;
     const int col = col0 + lane * 4;
-    const bool active = col < a.pitch;
-    const int lcol = active ? col : a.pitch - 4;
+    const int lcol = col;  // pitch % 256 == 0: every lane is in bounds
     const int hcol = (lane == 0) ? max(col0 - 1, 0) : min(col0 + kStripCols, a.pitch - 1);
     const bool edge_lane = (lane == 0) | (lane == 63);
     const size_t pitch = (size_t)a.pitch;
@@ -134,7 +130,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3d
             dmax = max2(dmax, fabsf(c.z - o.z));
             dmax = max2(dmax, fabsf(c.w - o.w));
         }
-        if (active) *reinterpret_cast<float4 *>(a.out + (size_t)x0 * plane + (size_t)r * pitch + col) = o;
+        *reinterpret_cast<float4 *>(a.out + (size_t)x0 * plane + (size_t)r * pitch + col) = o;
 
         up = c; c = d1; d1 = d2;
         a1 = a2; b1 = b2;
@@ -143,7 +139,6 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3d
     }
 
     if (CHECK) {
-        if (!active) dmax = 0.0f;
         dmax = wave_max(dmax);
         if (lane == 0 && dmax > 0.0f) atomicMax(a.delta_bits, __float_as_uint(dmax));
     }
@@ -188,7 +183,7 @@ hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, i
                            hipStream_t stream)
 {
     if (plane_end <= plane_begin) return hipSuccess;
-    if (pitch <= 0 || (pitch % 64) != 0 || m0 <= 0 || m1 <= 0 || plane_begin < 0 || plane_end > m0)
+    if (pitch <= 0 || (pitch % 256) != 0 || m0 <= 0 || m1 <= 0 || plane_begin < 0 || plane_end > m0)
         return hipErrorInvalidValue;
     if ((parity >= 0) != (in == out)) return hipErrorInvalidValue;
     Sweep3dArgs a;
