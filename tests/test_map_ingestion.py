@@ -1,0 +1,57 @@
+"""the ROS ingestion rules restated on the host side (epic_amd/harmonic_map.py)."""
+import os
+
+import numpy as np
+
+import _oracle as O
+from epic_amd import harmonic_map as hm
+
+MAPS = os.path.join(O.ROOT, "tests", "golden", "maps")
+
+
+def test_trinary_rule_and_vertical_flip():
+    px = np.array([[0, 255, 150], [90, 200, 204], [254, 89, 1]], dtype=np.uint8)
+    occ = hm.occupancy_from_image(px)            # p = (255 - v) / 255; > 0.65 -> 100; < 0.196 -> 0; else -1
+    want_top_down = np.array([[100, 0, -1], [-1, -1, -1], [0, 100, 100]], dtype=np.int8)
+    want_top_down[1, 0] = -1                      # v = 90: p = 0.647, not above 0.65
+    want_top_down[1, 1] = -1                      # v = 200: p = 0.2157
+    want_top_down[1, 2] = -1                      # v = 204: p = 0.2, not below 0.196
+    assert np.array_equal(occ, want_top_down[::-1])
+    assert np.array_equal(hm.occupancy_from_image(px, negate=1), np.array([[0, 100, -1], [-1, 100, 100], [100, -1, 0]],
+                                                                            dtype=np.int8)[::-1])
+
+
+def test_navigation_node_rule():
+    occ = np.array([[0, 0, 0, 0, 0], [0, 100, -1, 49, 0], [0, 50, -2, 0, 0], [0, 0, 0, 0, 0]], dtype=np.int8)
+    prev_u = np.full((4, 5), 7.0, np.float32)
+    prev_l = np.zeros((4, 5), np.uint32)
+    m, u, lk = hm.grid_from_occupancy(occ, goals=[(3, 2)], previous=(prev_u, prev_l))
+    assert m == [4, 5]
+    assert lk[0].all() and lk[-1].all() and lk[:, 0].all() and lk[:, -1].all() and (u[0] == -1e6).all()
+    assert (u[1, 1], lk[1, 1]) == (-1e6, 1)       # 100 -> obstacle
+    assert (u[1, 2], lk[1, 2]) == (-1e6, 0)       # unknown -> free
+    assert (u[1, 3], lk[1, 3]) == (-1e6, 0)       # 49 -> free
+    assert (u[2, 1], lk[2, 1]) == (-1e6, 1)       # 50 -> obstacle
+    assert (u[2, 2], lk[2, 2]) == (7.0, 0)        # -2 -> unchanged
+    assert (u[2, 3], lk[2, 3]) == (0.0, 1)        # the goal survives the map update
+
+
+def test_costmap_rule():
+    cost = np.array([[0, 0, 0, 0], [0, 249, 250, 0], [0, 254, 0, 0], [0, 0, 0, 0]], dtype=np.uint8)
+    m, u, lk = hm.grid_from_costmap(cost, goals=[(2, 2)])
+    assert (lk[1, 1], lk[1, 2], lk[2, 1]) == (0, 1, 1) and lk[0].all() and lk[:, -1].all()
+    assert u[2, 2] == 0.0 and lk[2, 2] == 1 and u[1, 1] == np.float32(-1e6)
+
+
+def test_yaml_route_agrees_with_png_route_on_the_reference_maps():
+    """maps/maze.yaml and maps/umass.yaml: the obstacle set that map_server + the node derive equals the python
+    wrapper's pixel == 0 set (the maps are pure 0 / 150 / 255 gray), up to map_server's vertical flip."""
+    for name in ("maze", "umass"):
+        h = hm.load_yaml_map(os.path.join(MAPS, name + ".yaml"))
+        m, u_png, lk_png = O.load_png_reference_rule(os.path.join(MAPS, name + ".png"))
+        px_obstacle = (np.asarray(h.image) == 0)[::-1]
+        px_obstacle[0] = px_obstacle[-1] = True
+        px_obstacle[:, 0] = px_obstacle[:, -1] = True
+        assert list(h.shape) == m
+        assert np.array_equal(h.locked_array() == 1, px_obstacle)
+        assert h.meta["resolution"] > 0 and len(h.meta["origin"]) == 3
