@@ -46,6 +46,7 @@ def parse():
                     help="precise = libm-equivalent exp/log (the parity mode, default); fast = v_exp_f32/v_log_f32")
     ap.add_argument("--scheme", choices=("jacobi", "redblack"), default="jacobi",
                     help="jacobi = ping-pong sweep of every cell (default); redblack = the reference's in-place half-sweeps")
+    ap.add_argument("--halo", type=int, default=8, help="N > 1: ghost rows per side = sweeps between two halo exchanges")
     ap.add_argument("--slab", action="store_true", help="use the slab-decomposition driver even on one GPU")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-relax", action="store_true")
@@ -161,7 +162,7 @@ def main():
         from epic_amd.slab import SlabSolver
 
         solver = SlabSolver(grid, rank, world, device=torch.device("cuda", local), stagger=args.stagger,
-                            rows_per_task=args.rows_per_task, math=args.math)
+                            rows_per_task=args.rows_per_task, math=args.math, halo=args.halo)
         free_cells = solver.load_synthetic()
         upload_s = None
 
@@ -224,7 +225,7 @@ def main():
             "math": args.math,
             "scheme": args.scheme if use_abi else "jacobi",
             "free_cells": free_cells,
-            "parallelism": "1 GPU" if world == 1 else "row slabs x%d, 1-row halo exchange per sweep over RCCL" % world,
+            "parallelism": "1 GPU" if world == 1 else "row slabs x%d, %d halo rows exchanged every %d sweeps over RCCL" % (world, args.halo, args.halo),
         },
         "roofline": {
             "bound": "hbm",

@@ -64,12 +64,12 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, grid, seed, sweeps, mode, out_dir):
+def _worker(rank, world, port, grid, seed, sweeps, mode, out_dir, halo=8):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        s = SlabSolver(grid, rank, world, device="cpu", stagger=10, epsilon=1e-6, backend=OracleBackend())
+        s = SlabSolver(grid, rank, world, device="cpu", stagger=10, epsilon=1e-6, backend=OracleBackend(), halo=halo)
         free = s.load_synthetic(seed=seed, density=0.08)
         if mode == "fixed":
             for i in range(sweeps):
@@ -83,8 +83,8 @@ def _worker(rank, world, port, grid, seed, sweeps, mode, out_dir):
         dist.destroy_process_group()
 
 
-def _run(world, grid, seed, sweeps, mode, tmp_path):
-    mp.spawn(_worker, args=(world, _free_port(), grid, seed, sweeps, mode, str(tmp_path)), nprocs=world, join=True)
+def _run(world, grid, seed, sweeps, mode, tmp_path, halo=8):
+    mp.spawn(_worker, args=(world, _free_port(), grid, seed, sweeps, mode, str(tmp_path), halo), nprocs=world, join=True)
     parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
     field = np.concatenate([p["u"] for p in parts], axis=0)
     return field, parts
@@ -99,10 +99,12 @@ def test_partition_and_row_generator():
         assert np.array_equal(ur, u.reshape(m)[lo:hi].ravel()) and np.array_equal(lr, lk.reshape(m)[lo:hi].ravel())
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_fixed_sweeps_equal_single_domain(world, tmp_path):
+@pytest.mark.parametrize("world,halo", [(2, 1), (2, 8), (3, 1), (3, 3), (3, 5)])
+def test_fixed_sweeps_equal_single_domain(world, halo, tmp_path):
+    """halo = ghost depth G: G rows are traded every G sweeps (1 = a row every sweep).  25 sweeps is not a multiple of
+    3, 5 or 8, so the run ends between two exchanges, on partly stale ghost rows but exact owned rows."""
     grid, seed, sweeps = [37, 50], 5, 25
-    field, parts = _run(world, grid, seed, sweeps, "fixed", tmp_path)
+    field, parts = _run(world, grid, seed, sweeps, "fixed", tmp_path, halo)
     u0, locked = synthetic_grid(grid, seed, 0.08)
     p = O.Problem(grid, u0, locked)
     assert O.oracle().oracle_jacobi_run(ct.byref(p.h), sweeps) == 0
