@@ -48,6 +48,10 @@ def parse():
                     help="jacobi = ping-pong sweep of every cell (default); redblack = the reference's in-place half-sweeps")
     ap.add_argument("--halo", type=int, default=8, help="N > 1: ghost rows per side = sweeps between two halo exchanges")
     ap.add_argument("--slab", action="store_true", help="use the slab-decomposition driver even on one GPU")
+    ap.add_argument("--develop", type=int, default=20000,
+                    help="untimed sweeps before the timed region, so that it runs on a developed field: on the constant "
+                         "initial field (u = -1e6 almost everywhere) the same VALU-bound kernel runs ~15 %% faster "
+                         "(measured 152 vs 181 us per sweep; the traffic-only build is unaffected), which would flatter it")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-relax", action="store_true")
     return ap.parse_args()
@@ -169,6 +173,14 @@ def main():
         def step():
             return solver.timed_step()
 
+    # let the wavefront from the goal cover the grid first (untimed); a multiple of stagger keeps the check cadence
+    develop = max(0, args.develop) // args.stagger * args.stagger
+    if develop:
+        if use_abi:
+            assert E.epic_hip_update_n_gpu(h, develop, 0) == 0
+        else:
+            for _ in range(develop):
+                solver.sweep(False)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -196,7 +208,7 @@ def main():
         even_it = (iterations + (1 - first % 2)) // 2      # iterations with even index update (row + col) odd
         return even_it * free_by_colour[0] + (iterations - even_it) * free_by_colour[1]
 
-    value = updates_in(sweeps, args.warmup * args.stagger) / wall / 1e6
+    value = updates_in(sweeps, develop + args.warmup * args.stagger) / wall / 1e6
     launch_us = dev_ms * 1e3 / sweeps
     # algorithmic bytes per launch: 8 B per cell the launch recomputes-or-copies.  A Jacobi sweep touches every cell of
     # the grid; a red-black half-sweep recomputes one colour, i.e. half the grid (its row-major in-place layout still
@@ -222,6 +234,7 @@ def main():
             "grid": grid,
             "sweeps_per_step": args.stagger,
             "check_every": args.stagger,
+            "developed_sweeps": develop,
             "math": args.math,
             "scheme": args.scheme if use_abi else "jacobi",
             "free_cells": free_cells,

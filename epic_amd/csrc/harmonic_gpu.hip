@@ -211,17 +211,41 @@ void drop_graphs(Ctx *c)
 // `count` plain (unchecked) iterations starting at iteration number `first`.  Kernels of a few microseconds are
 // bound by the host's launch rate (~4 us each); for those the sequence is captured once into a hipGraph and replayed
 // (inter-kernel gap ~1.5 us, MI355X_MICROARCH.md "boundary" row).  Large grids keep the plain launches.
+// Red-black, 2-D, large grids: two consecutive plain iterations run as ONE fused pass (kernels_2d.hip,
+// rb_fused2d_kernel: 4 B of HBM traffic per cell-update instead of 16); an odd iteration left over is an in-place
+// half-sweep.  Small grids keep the half-sweeps (a fused task recomputes 2 extra rows, too much at 1-2 rows per task).
+int fused_rows_per_task(const Ctx *c)
+{
+    if (c->rows_per_task > 0) return std::max(c->rows_per_task, 4);
+    const long long nstrips = (c->pitch + 247) / 248;
+    long long r = (long long)c->rows * nstrips / 8192 / 8 * 8;
+    return (int)std::min<long long>(64, std::max<long long>(16, r));
+}
+
+hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
+{
+    static const bool no_fuse = getenv("EPIC_HIP_NO_FUSE") != nullptr;
+    const bool fuse = c->redblack && c->n == 2 && !no_fuse && (long long)c->rows * c->pitch >= (1ll << 22);
+    unsigned i = 0;
+    while (fuse && count - i >= 2) {
+        hipError_t e = epic_hip::launch_rb_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch,
+                                                    fused_rows_per_task(c), c->math, (int)((first + i) & 1u), c->stream);
+        if (e != hipSuccess) return e;
+        c->cur ^= 1;
+        i += 2;
+    }
+    for (; i < count; i++) {
+        hipError_t e = enqueue_sweep(c, false, first + i);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
 {
     const bool small = (long long)c->rows * c->pitch <= (1ll << 22);
     static const bool no_graph = getenv("EPIC_HIP_NO_GRAPH") != nullptr;
-    if (!small || count < 8 || no_graph) {
-        for (unsigned i = 0; i < count; i++) {
-            hipError_t e = enqueue_sweep(c, false, first + i);
-            if (e != hipSuccess) return e;
-        }
-        return hipSuccess;
-    }
+    if (!small || count < 8 || no_graph) return enqueue_plain_run(c, count, first);
     const auto key = std::make_tuple(count, c->cur, (int)(first & 1u), c->math, (int)c->redblack, auto_rows_per_task(c));
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
@@ -789,15 +813,23 @@ int epic_hip_timed_sweeps_gpu(Harmonic *harmonic, unsigned int sweeps, unsigned 
     int rc = EPIC_SUCCESS;
     (void)hipEventRecord(e0, c->stream);
     bool checked = false;
-    for (unsigned s = 0; s < sweeps && rc == EPIC_SUCCESS; s++) {
-        const bool check = check_every && (harmonic->currentIteration % check_every == 0);
-        if (enqueue_sweep(c, check, harmonic->currentIteration) != hipSuccess) {
-            report(fn, "Failed to execute the 'Jacobi update' kernel.");
-            rc = EPIC_ERROR_KERNEL_EXECUTION;
+    unsigned done = 0;
+    while (done < sweeps && rc == EPIC_SUCCESS) {
+        const unsigned it = harmonic->currentIteration;
+        if (check_every && it % check_every == 0) {
+            if (enqueue_sweep(c, true, it) != hipSuccess) rc = EPIC_ERROR_KERNEL_EXECUTION;
+            checked = true;
+            harmonic->currentIteration++;
+            done++;
+        } else {
+            unsigned run = sweeps - done;
+            if (check_every) run = std::min(run, check_every - it % check_every);
+            if (enqueue_plain_run(c, run, it) != hipSuccess) rc = EPIC_ERROR_KERNEL_EXECUTION;
+            harmonic->currentIteration += run;
+            done += run;
         }
-        checked |= check;
-        harmonic->currentIteration++;
     }
+    if (rc != EPIC_SUCCESS) report(fn, "Failed to execute the 'update' kernel.");
     (void)hipEventRecord(e1, c->stream);
     harmonic->d_u = c->buf[c->cur];
     if (rc == EPIC_SUCCESS) {

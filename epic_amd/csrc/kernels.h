@@ -14,6 +14,9 @@ namespace epic_hip {
 hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int row_begin,
                            int row_end, int rows_per_task, int math, int parity, unsigned *delta_bits,
                            hipStream_t stream);
+// two red-black iterations fused into one in -> out pass (first colour = parity); see kernels_2d.hip
+hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
+                              int math, int parity, hipStream_t stream);
 hipError_t launch_eval_math(const float *in, float *out, size_t n, int which, hipStream_t stream);
 hipError_t launch_pack_mask_2d(const uint32_t *locked, int rows, int cols, int pitch, int ghost_top,
                                int ghost_bottom, uint32_t *maskw, hipStream_t stream);

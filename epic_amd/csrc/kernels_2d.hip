@@ -213,6 +213,118 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
     }
 }
 
+// ---- fused red-black sweep: two reference iterations (both colours) in ONE pass over the data --------------------
+// The in-place half-sweep above moves every cell through HBM to recompute half of them (16 B per cell-update).  This
+// kernel reads u_in once and writes u_out once per FULL red-black sweep (4 B per cell-update): while a wave marches down
+// its strip it first recomputes the first colour ("A") of row r+1 from old values, then the second colour ("B") of row
+// r from the fresh A values of rows r-1, r, r+1 -- exactly the values the second half-sweep of the reference would
+// read -- and stores row r.  Waves stay independent because each one recomputes the A cells its B cells need itself:
+//   * columns: a wave loads 256 columns but owns only the 248 in lanes 1..62; lanes 0 and 63 are halo lanes whose
+//     innermost A cell feeds the neighbouring owned lane through the same DPP shift (strip stride 248, ~3 % lanes);
+//   * rows: a task recomputes A of the row above and below its chunk (4 extra row loads, 2 extra A rows per chunk).
+// Ping-pong (in != out) is required: a neighbouring task must still find the OLD values of the rows/columns it
+// recomputes.  Arithmetic per cell is the half-sweep's, so results are bit-identical to two in-place half-sweeps
+// (and, with the precise math, to two iterations of the reference CPU solver).
+constexpr int kFusedOut = 248;  // owned columns per wave
+
+template <int MATH>
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Sweep2dArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float ldsf[kDfLdsFloats];
+    MathTab lds = {};
+    if (MATH == kMathPrecise) lds = math_tables_load();
+    if (MATH == kMathDf32) {
+        df_tables_to_lds(ldsf);
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int task = xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
+    if (task >= a.ntasks) return;
+    const int strip = task % a.nstrips;
+    const int chunk = task / a.nstrips;
+    const int r0 = a.row_begin + chunk * a.rows_per_task;
+    const int r1 = min(r0 + a.rows_per_task, a.row_end);
+    const int col = strip * kFusedOut - kColsPerLane + lane * kColsPerLane;  // lane 0 = left halo lane
+    const int lcol = min(max(col, 0), a.pitch - kColsPerLane);
+    const bool owner = lane >= 1 && lane <= kWave - 2 && col < a.pitch;
+    const int rlast = a.rows - 1;
+    const size_t pitch = (size_t)a.pitch;
+    const int qpitch = a.pitch >> 2;
+    const int glast = rlast >> 3;
+    const int it = a.parity;  // colour A = cells with (row + col + it) odd; col is even for .x
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+
+    auto ld = [&](int r) -> float4 {
+        r = min(max(r, 0), rlast);
+        return *reinterpret_cast<const float4 *>(a.in + (size_t)r * pitch + lcol);
+    };
+    // mask nibble of row r; one cached word per stage (each stage walks the rows in order)
+    int gA = -1, gB = -1;
+    uint32_t wA = 0, wB = 0;
+    auto nibble = [&](int r, int &g, uint32_t &w) -> uint32_t {
+        const int rr = min(max(r, 0), rlast);
+        if ((rr >> 3) != g) {  // scalar branch
+            g = rr >> 3;
+            w = a.maskw[(size_t)min(g, glast) * qpitch + (lcol >> 2)];
+        }
+        return w >> ((rr & 7) * 4);
+    };
+    // One colour of one row.  second = false: colour A (iteration it), true: colour B (iteration it + 1).
+    auto stage = [&](int r, bool second, const float4 &up, const float4 &c, const float4 &dn, uint32_t nib) -> float4 {
+        float4 o = c;
+        const bool odd_cols = ((((r + it) & 1) == 0) != second);  // scalar
+        if (odd_cols) {
+            const float rt = wave_from_right(c.x, 0.0f);
+            float ny, nw;
+            if (MATH == kMathDf32) {
+                const v2f n = df_pair_update_2d(v2f{up.y, up.w}, v2f{dn.y, dn.w}, v2f{c.x, c.z}, v2f{c.z, rt}, ldsf);
+                ny = n.x; nw = n.y;
+            } else {
+                ny = cell_update_2d<MATH>(up.y, dn.y, c.x, c.z, lds);
+                nw = cell_update_2d<MATH>(up.w, dn.w, c.z, rt, lds);
+            }
+            o.y = (nib & 2u) ? c.y : ny;
+            o.w = (nib & 8u) ? c.w : nw;
+        } else {
+            const float lf = wave_from_left(c.w, 0.0f);
+            float nx, nz;
+            if (MATH == kMathDf32) {
+                const v2f n = df_pair_update_2d(v2f{up.x, up.z}, v2f{dn.x, dn.z}, v2f{lf, c.y}, v2f{c.y, c.w}, ldsf);
+                nx = n.x; nz = n.y;
+            } else {
+                nx = cell_update_2d<MATH>(up.x, dn.x, lf, c.y, lds);
+                nz = cell_update_2d<MATH>(up.z, dn.z, c.y, c.w, lds);
+            }
+            o.x = (nib & 1u) ? c.x : nx;
+            o.z = (nib & 4u) ? c.z : nz;
+        }
+        return o;
+    };
+
+    // prologue: colour A of rows r0-1 and r0 (old neighbours only: the other colour has not moved yet)
+    const float4 om2 = ld(r0 - 2), om1 = ld(r0 - 1), o0 = ld(r0);
+    float4 onext = ld(r0 + 1), onext2 = ld(r0 + 2);
+    float4 mprev = stage(r0 - 1, false, om2, om1, o0, nibble(r0 - 1, gA, wA));
+    float4 mcur = stage(r0, false, om1, o0, onext, nibble(r0, gA, wA));
+    for (int r = r0; r < r1; ++r) {
+        const float4 opre = ld(r + 3);
+        // colour A of row r+1: up = row r (its B cells are still old in mcur), centre / down old
+        const float4 mnext = stage(r + 1, false, mcur, onext, onext2, nibble(r + 1, gA, wA));
+        // colour B of row r from the fresh A cells around it
+        const float4 x = stage(r, true, mprev, mcur, mnext, nibble(r, gB, wB));
+        if (owner) {
+            float *orow = a.out + (size_t)r * pitch;
+            if (a.flags & 2) __builtin_nontemporal_store(vf4{x.x, x.y, x.z, x.w}, reinterpret_cast<vf4 *>(orow + col));
+            else *reinterpret_cast<float4 *>(orow + col) = x;
+        }
+        mprev = mcur;
+        mcur = mnext;
+        onext = onext2;
+        onext2 = opre;
+    }
+}
+
 // uint32-per-cell mask (the ABI's format, rows x cols, unpitched) -> tiled bits.  Border cells and the
 // padding beyond `cols` / `rows` are forced locked (harmonic.h:35-37 "assumes border values are locked").
 __global__ void pack_mask_2d_kernel(const uint32_t *locked, int rows, int cols, int pitch, int ghost_top,
@@ -354,6 +466,33 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, i
         if (delta_bits) launch_sweep_2d_math<true, true>(math, nblocks, stream, a);
         else launch_sweep_2d_math<false, true>(math, nblocks, stream, a);
     }
+    return hipGetLastError();
+}
+
+// Two consecutive red-black iterations (first one = `parity`) in one pass, in -> out (in != out).
+hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
+                              int math, int parity, hipStream_t stream)
+{
+    if (pitch <= 0 || (pitch % 256) != 0 || rows <= 0 || rows_per_task <= 0 || in == out) return hipErrorInvalidValue;
+    Sweep2dArgs a;
+    a.in = in;
+    a.out = out;
+    a.maskw = maskw;
+    a.delta_bits = nullptr;
+    a.rows = rows;
+    a.pitch = pitch;
+    a.row_begin = 0;
+    a.row_end = rows;
+    a.rows_per_task = rows_per_task;
+    a.nstrips = (pitch + kFusedOut - 1) / kFusedOut;
+    a.ntasks = a.nstrips * ((rows + rows_per_task - 1) / rows_per_task);
+    a.parity = parity & 1;
+    a.flags = sweep_flags();
+    const dim3 grid((a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
+    if (math == kMathFast) hipLaunchKernelGGL((rb_fused2d_kernel<kMathFast>), grid, block, 0, stream, a);
+    else if (math == kMathTraffic) hipLaunchKernelGGL((rb_fused2d_kernel<kMathTraffic>), grid, block, 0, stream, a);
+    else if (math == kMathDf32) hipLaunchKernelGGL((rb_fused2d_kernel<kMathDf32>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((rb_fused2d_kernel<kMathPrecise>), grid, block, 0, stream, a);
     return hipGetLastError();
 }
 

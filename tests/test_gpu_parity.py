@@ -493,3 +493,31 @@ def test_redblack_random_vs_checker_and_tiling():
             for i in range(37):
                 (lib.oracle_update_and_check if i == 36 else lib.oracle_update)(ct.byref(p.h))
         assert np.array_equal(h.u_array().ravel(), p.u) and h.delta == p.h.delta and h.currentIteration == 37
+
+
+@pytest.mark.parametrize("m,rpt", [([2048, 2048], 0), ([2050, 2100], 16), ([1100, 4000], 5), ([4200, 1000], 64)])
+def test_redblack_fused_pairs_equal_the_checker(m, rpt):
+    """Grids >= 4 Mcell run two plain red-black iterations per launch (rb_fused2d_kernel: halo lanes, recomputed halo
+    rows, ping-pong).  13 iterations = 1 check + 6 fused pairs, 14 = 1 check + 6 pairs + 1 in-place half-sweep; both
+    must equal the checker's red-black half-sweeps bit for bit."""
+    u0, locked = synthetic_grid(m, 23, 0.06)
+    free = np.flatnonzero(locked == 0)
+    for idx in (free[7], free[free.size // 3], free[-9]):   # extra goals away from the centre: every strip seam moves
+        u0[idx] = 0.0
+        locked[idx] = 1
+    lib = O.oracle()
+    for k in (13, 14):
+        h = make(m, u0, locked)
+        gpu_init(h)
+        assert E.epic_hip_set_scheme(h, 1) == 0
+        if rpt:
+            assert E.epic_hip_set_rows_per_task(h, rpt) == 0
+        assert E.harmonic_update_and_check_gpu(h, NT) in (0, 1)
+        assert E.epic_hip_update_n_gpu(h, k - 1, 0) == 0
+        assert h.currentIteration == k
+        assert E.harmonic_get_potential_values_gpu(h) == 0
+        gpu_fini(h)
+        p = O.Problem(m, u0, locked)
+        for i in range(k):
+            (lib.oracle_update_and_check if i == 0 else lib.oracle_update)(ct.byref(p.h))
+        assert np.array_equal(h.u_array().ravel(), p.u), f"{m} after {k} iterations"
