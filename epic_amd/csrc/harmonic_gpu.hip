@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <map>
+#include <vector>
 #include <mutex>
 #include <tuple>
 #include <unordered_map>
@@ -49,6 +50,12 @@ struct Ctx {
     // Launch-bound grids replay the plain sweeps between two checks from a captured hipGraph; key = (count, starting
     // buffer, starting parity, math, scheme, rows_per_task) -- everything a captured launch sequence depends on.
     std::map<std::tuple<unsigned, int, int, int, int, int>, hipGraphExec_t> graphs;
+    // Activity tracking (2-D): per-tile "changed in the previous iteration" flags, ping-pong; tiles whose inputs did not
+    // change are skipped (bit-identical results, see kernels_2d.hip).  force > 0: the next `force` iterations run every tile.
+    bool track = true;             // EPIC_HIP_TRACK=0 / epic_hip_set_activity_tracking(h, 0) turns it off
+    uint8_t *act[2] = {nullptr, nullptr};
+    int act_cur = 0, act_rpt = 0, force = 2;
+    size_t act_tiles = 0;
     bool redblack = false;         // 2-D scheme: false = Jacobi ping-pong (default), true = in-place red-black (EPIC_HIP_SCHEME)
     size_t u_bytes() const { return (size_t)rows * pitch * sizeof(float); }
     size_t mask_bytes() const
@@ -134,6 +141,8 @@ Ctx *get_ctx(Harmonic *h, bool create)
     if (e && strcmp(e, "df32") == 0) c->math = 3;
     e = getenv("EPIC_HIP_SCHEME");
     if (e && strcmp(e, "redblack") == 0) c->redblack = true;
+    e = getenv("EPIC_HIP_TRACK");
+    if (e && strcmp(e, "0") == 0) c->track = false;
     g_ctx[h] = c;
     return c;
 }
@@ -146,6 +155,7 @@ void drop_ctx_if_empty(Harmonic *h)
     Ctx *c = it->second;
     if (c->buf[0] || c->maskw || c->d_m || c->d_delta) return;
     drop_graphs(c);
+    for (uint8_t *&p : c->act) { if (p) (void)hipFree(p); p = nullptr; }
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->h_delta) (void)hipHostFree(c->h_delta);
     delete c;
@@ -184,17 +194,48 @@ hipError_t enqueue_sweep(Ctx *c, bool check, unsigned iteration)
     }
     const float *in = c->buf[c->cur];
     float *out = c->buf[c->cur ^ 1];
+    // activity flags for this iteration (2-D only); (re)allocated when the tiling changes
+    epic_hip::Activity act = {nullptr, nullptr, 1};
+    if (c->n == 2 && c->track) {
+        const int rpt = auto_rows_per_task(c);
+        const size_t tiles = epic_hip::sweep_2d_tiles(c->rows, c->pitch, rpt);
+        if (tiles != c->act_tiles || rpt != c->act_rpt) {
+            for (uint8_t *&p : c->act) { if (p) (void)hipFree(p); p = nullptr; }
+            c->act_tiles = 0;
+            if (hipMalloc((void **)&c->act[0], tiles) == hipSuccess && hipMalloc((void **)&c->act[1], tiles) == hipSuccess) {
+                c->act_tiles = tiles;
+                c->act_rpt = rpt;
+                c->force = 2;
+            } else {
+                (void)hipGetLastError();
+                for (uint8_t *&p : c->act) { if (p) (void)hipFree(p); p = nullptr; }
+            }
+        }
+        if (c->act_tiles) {
+            act.in = c->act[c->act_cur];
+            act.out = c->act[c->act_cur ^ 1];
+            act.force = c->force;
+        }
+    }
+    auto advance = [&](hipError_t e) {
+        if (e == hipSuccess && act.out) {
+            c->act_cur ^= 1;
+            if (c->force > 0) c->force--;
+        }
+        return e;
+    };
     if (c->redblack) {
         float *inout = c->buf[c->cur];
         if (c->n == 2)
-            return epic_hip::launch_sweep_2d(inout, inout, c->maskw, c->rows, c->pitch, 0, c->rows, auto_rows_per_task(c),
-                                             c->math, (int)(iteration & 1u), check ? c->d_delta : nullptr, c->stream);
+            return advance(epic_hip::launch_sweep_2d(inout, inout, c->maskw, c->rows, c->pitch, 0, c->rows,
+                                                     auto_rows_per_task(c), c->math, (int)(iteration & 1u),
+                                                     check ? c->d_delta : nullptr, c->stream, &act));
         return epic_hip::launch_sweep_3d(inout, inout, c->maskw, c->m[0], c->m[1], c->pitch, 0, c->m[0], c->math,
                                          (int)(iteration & 1u), check ? c->d_delta : nullptr, c->stream);
     }
     if (c->n == 2)
-        e = epic_hip::launch_sweep_2d(in, out, c->maskw, c->rows, c->pitch, 0, c->rows, auto_rows_per_task(c), c->math,
-                                      -1, check ? c->d_delta : nullptr, c->stream);
+        e = advance(epic_hip::launch_sweep_2d(in, out, c->maskw, c->rows, c->pitch, 0, c->rows, auto_rows_per_task(c),
+                                              c->math, -1, check ? c->d_delta : nullptr, c->stream, &act));
     else
         e = epic_hip::launch_sweep_3d(in, out, c->maskw, c->m[0], c->m[1], c->pitch, 0, c->m[0], c->math, -1,
                                       check ? c->d_delta : nullptr, c->stream);
@@ -225,7 +266,8 @@ int fused_rows_per_task(const Ctx *c)
 hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
 {
     static const bool no_fuse = getenv("EPIC_HIP_NO_FUSE") != nullptr;
-    const bool fuse = c->redblack && c->n == 2 && !no_fuse && (long long)c->rows * c->pitch >= (1ll << 22);
+    // (the fused pass has its own 248-column tiling and no activity flags: it is used when tracking is off)
+    const bool fuse = c->redblack && c->n == 2 && !no_fuse && !c->track && (long long)c->rows * c->pitch >= (1ll << 22);
     unsigned i = 0;
     while (fuse && count - i >= 2) {
         hipError_t e = epic_hip::launch_rb_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch,
@@ -245,11 +287,14 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
 {
     const bool small = (long long)c->rows * c->pitch <= (1ll << 22);
     static const bool no_graph = getenv("EPIC_HIP_NO_GRAPH") != nullptr;
-    if (!small || count < 8 || no_graph) return enqueue_plain_run(c, count, first);
-    const auto key = std::make_tuple(count, c->cur, (int)(first & 1u), c->math, (int)c->redblack, auto_rows_per_task(c));
+    // a captured sequence bakes in the flag buffers and force = 0: run eagerly until the forced iterations are over
+    if (!small || count < 8 || no_graph || (c->track && c->n == 2 && (c->force > 0 || c->act_tiles == 0)))
+        return enqueue_plain_run(c, count, first);
+    const auto key = std::make_tuple(count, c->cur + 2 * c->act_cur + (c->track ? 4 : 0), (int)(first & 1u), c->math,
+                                     (int)c->redblack, auto_rows_per_task(c));
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
-        const int cur0 = c->cur;
+        const int cur0 = c->cur, act0 = c->act_cur;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
@@ -257,6 +302,7 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
         for (unsigned i = 0; i < count && e == hipSuccess; i++) e = enqueue_sweep(c, false, first + i);
         hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
         c->cur = cur0;  // nothing has run yet
+        c->act_cur = act0;
         if (e == hipSuccess) e = e2;
         if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         if (graph) (void)hipGraphDestroy(graph);
@@ -266,6 +312,7 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
     }
     hipError_t e = hipGraphLaunch(it->second, c->stream);
     if (e == hipSuccess && !c->redblack && (count & 1u)) c->cur ^= 1;
+    if (e == hipSuccess && c->track && c->n == 2 && (count & 1u)) c->act_cur ^= 1;
     return e;
 }
 
@@ -285,6 +332,7 @@ int read_delta(Harmonic *h, Ctx *c, const char *fn)
 
 int upload_u(Harmonic *h, Ctx *c, const char *fn)
 {
+    c->force = 2;  // new values: no tile may be skipped on the old flags
     // padding columns hold the obstacle seed; both buffers, so that whichever is read first is complete
     if (c->pitch != c->cols) {
         for (int b = 0; b < 2; b++)
@@ -306,6 +354,7 @@ int upload_u(Harmonic *h, Ctx *c, const char *fn)
 
 int upload_locked(Harmonic *h, Ctx *c, const char *fn)
 {
+    c->force = 2;
     const size_t cells = (size_t)c->rows * c->cols;
     uint32_t *tmp = nullptr;
     if (hipMalloc((void **)&tmp, cells * sizeof(uint32_t)) != hipSuccess) {
@@ -732,6 +781,7 @@ int harmonic_utilities_set_cells_2d_gpu(Harmonic *harmonic, unsigned int numThre
     }
     unsigned *d_v = nullptr, *d_types = nullptr;
     int rc = EPIC_SUCCESS;
+    c->force = 2;  // cells and mask bits change under the activity flags
     if (hipMalloc((void **)&d_v, 2 * (size_t)k * sizeof(unsigned)) != hipSuccess ||
         hipMalloc((void **)&d_types, (size_t)k * sizeof(unsigned)) != hipSuccess) {
         (void)hipGetLastError();
@@ -847,6 +897,7 @@ int epic_hip_set_rows_per_task(Harmonic *harmonic, unsigned int rows_per_task)
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
     if (!c || rows_per_task > 65536) return EPIC_ERROR_INVALID_DATA;
     c->rows_per_task = (int)rows_per_task;
+    c->force = 2;
     return EPIC_SUCCESS;
 }
 
@@ -855,6 +906,7 @@ int epic_hip_set_math_mode(Harmonic *harmonic, int mode)
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
     if (!c || mode < 0 || mode > 3) return EPIC_ERROR_INVALID_DATA;  // 2 = traffic-only diagnostic, 3 = df32 (2-D)
     c->math = mode;
+    c->force = 2;
     return EPIC_SUCCESS;
 }
 
@@ -863,6 +915,33 @@ int epic_hip_set_scheme(Harmonic *harmonic, int scheme)
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
     if (!c || (scheme != 0 && scheme != 1)) return EPIC_ERROR_INVALID_DATA;
     c->redblack = scheme == 1;
+    c->force = 2;
+    return EPIC_SUCCESS;
+}
+
+int epic_hip_set_activity_tracking(Harmonic *harmonic, int on)
+{
+    Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
+    if (!c || (on != 0 && on != 1)) return EPIC_ERROR_INVALID_DATA;
+    c->track = on == 1;
+    c->force = 2;
+    return EPIC_SUCCESS;
+}
+
+int epic_hip_activity_stats(Harmonic *harmonic, unsigned long long *active_tiles, unsigned long long *tiles)
+{
+    Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
+    if (!c || !active_tiles || !tiles) return EPIC_ERROR_INVALID_DATA;
+    *active_tiles = *tiles = 0;
+    if (!c->track || c->n != 2 || c->act_tiles == 0) return EPIC_SUCCESS;
+    std::vector<uint8_t> flags(c->act_tiles);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return EPIC_ERROR_DEVICE_SYNCHRONIZE;
+    if (hipMemcpy(flags.data(), c->act[c->act_cur], c->act_tiles, hipMemcpyDeviceToHost) != hipSuccess)
+        return EPIC_ERROR_MEMCPY_TO_HOST;
+    unsigned long long n = 0;
+    for (uint8_t f : flags) n += f != 0;
+    *active_tiles = c->force > 0 ? c->act_tiles : n;
+    *tiles = c->act_tiles;
     return EPIC_SUCCESS;
 }
 

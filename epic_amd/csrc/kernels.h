@@ -10,10 +10,21 @@ namespace epic_hip {
 // One Jacobi sweep of rows [row_begin, row_end) of a pitched rows x pitch grid.  delta_bits == nullptr
 // selects the plain kernel; otherwise max |du| is atomicMax'ed into *delta_bits (float bits, zero it first).
 // math: 0 = precise (libm-equivalent exp/log in f64, the default), 1 = fast (v_exp_f32 / v_log_f32).
+// Activity tracking of full-grid launches (kernels_2d.hip, Sweep2dArgs): one byte per (strip, chunk) task tile,
+// tiles = sweep_2d_tiles(rows, pitch, rows_per_task).
+struct Activity {
+    const uint8_t *in;   // flags written by the previous iteration
+    uint8_t *out;        // flags this iteration writes
+    int force;           // != 0: run every tile (first two iterations after any edit of u / mask / mode)
+};
+inline size_t sweep_2d_tiles(int rows, int pitch, int rows_per_task)
+{
+    return (size_t)((pitch + 255) / 256) * (size_t)((rows + rows_per_task - 1) / rows_per_task);
+}
 // parity < 0: Jacobi (in != out); parity 0 / 1: red-black half-sweep of that colour, in place (in == out).
 hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int row_begin,
                            int row_end, int rows_per_task, int math, int parity, unsigned *delta_bits,
-                           hipStream_t stream);
+                           hipStream_t stream, const Activity *act = nullptr);
 // two red-black iterations fused into one in -> out pass (first colour = parity); see kernels_2d.hip
 hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
                               int math, int parity, hipStream_t stream);

@@ -49,6 +49,16 @@ struct Sweep2dArgs {
     int ntasks;             // nstrips * nchunks
     int parity;             // red-black scheme only: currentIteration & 1 (which colour this half-sweep updates)
     int flags;              // tuning, never results: bit 0 = odd row-chunks march upwards, bit 1 = non-temporal stores
+    // Activity tracking (full-grid launches only; act_out == nullptr turns it off).  One byte per task tile:
+    // act_in[t] != 0 = "some cell of tile t changed in the previous iteration".  A tile whose own flag and whose four
+    // edge neighbours' flags are all clear has bit-for-bit the inputs it had last time, so its update is a no-op and
+    // the wave leaves at once (Jacobi: the output buffer already holds these values from two sweeps ago, because the
+    // tile itself did not change either).  `force` != 0 makes every tile run (first two iterations after any edit).
+    const uint8_t *act_in;
+    uint8_t *act_out;
+    int nchunks;
+    int force;
+    int band;               // blocks per XCD band (0 = one contiguous range per XCD)
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (b % 8 labels the XCD group).  Give each group a
@@ -60,6 +70,18 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nblk)
     return x * q + (x < rem ? x : rem) + i;
 }
 
+// The same, in bands of `k` blocks: XCD x takes bands x, x + 8, x + 16, ... of the logical block range.  Within a band
+// neighbouring tasks still share an L2, and the work of a sweep whose active tiles cluster (activity tracking: the
+// converged region around a goal is skipped) stays spread over all eight XCDs instead of idling the ones that own it.
+__device__ __forceinline__ int xcd_banded_block(int b, int nblk, int k)
+{
+    if (k <= 0) return xcd_contiguous_block(b, nblk);
+    const int full = nblk / (kNumXcd * k) * (kNumXcd * k);  // multiple of 8: blocks past it keep their XCD label
+    if (b >= full) return full + xcd_contiguous_block(b - full, nblk - full);
+    const int x = b % kNumXcd, i = b / kNumXcd;
+    return ((i / k) * kNumXcd + x) * k + i % k;
+}
+
 // RB = false: Jacobi, in -> out.  RB = true: the reference's red-black half-sweep, IN PLACE (in == out): only the
 // cells with (row + col + currentIteration) odd are recomputed (harmonic_cpu.cpp:46-51), from neighbours that all have
 // the other colour and therefore do not change during this launch -- no ordering between waves is needed, and with
@@ -68,8 +90,6 @@ template <bool CHECK, int MATH, bool RB>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2dArgs a)
 {
     __shared__ __attribute__((aligned(16))) float ldsf[kDfLdsFloats];  // df32 tables (df32 math only)
-    MathTab lds = {};  // libm tables, one entry per lane (precise math only)
-    if (MATH == kMathPrecise) lds = math_tables_load();
     if (MATH == kMathDf32) {
         df_tables_to_lds(ldsf);
         __syncthreads();
@@ -77,8 +97,22 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
     const int lane = threadIdx.x & (kWave - 1);
     // wave-uniform quantities are forced into SGPRs: the row loop, its addresses and branches are scalar
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int task = xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
+    const int task = xcd_banded_block(blockIdx.x, gridDim.x, a.band) * kWavesPerBlock + wave;
     if (task >= a.ntasks) return;
+    if (a.act_out && a.force == 0) {  // everything here is wave-uniform (scalar loads, scalar branch)
+        const int st = task % a.nstrips, ch = task / a.nstrips;
+        unsigned any = a.act_in[task];
+        if (st > 0) any |= a.act_in[task - 1];
+        if (st + 1 < a.nstrips) any |= a.act_in[task + 1];
+        if (ch > 0) any |= a.act_in[task - a.nstrips];
+        if (ch + 1 < a.nchunks) any |= a.act_in[task + a.nstrips];
+        if (any == 0) {  // nothing this tile reads has changed: its values stand
+            if (lane == 0) a.act_out[task] = 0;
+            return;
+        }
+    }
+    MathTab lds = {};  // libm tables, one entry per lane (precise math only)
+    if (MATH == kMathPrecise) lds = math_tables_load();
     const int strip = task % a.nstrips;
     const int chunk = task / a.nstrips;
     const int r0 = a.row_begin + chunk * a.rows_per_task;
@@ -121,6 +155,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
     typedef float vf4 __attribute__((ext_vector_type(4)));
 
     float dmax = 0.0f;
+    bool changed = false;  // any cell of this lane rewritten with different bits (activity tracking)
     int gcur = rfirst >> 3;
     uint32_t mw = ldm(gcur), mw_next = ldm(max(gcur + dir, 0));
 
@@ -182,6 +217,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
             dmax = max2(dmax, fabsf(c.z - o.z));
             dmax = max2(dmax, fabsf(c.w - o.w));
         }
+        changed |= (f2u(o.x) != f2u(c.x)) | (f2u(o.y) != f2u(c.y)) | (f2u(o.z) != f2u(c.z)) | (f2u(o.w) != f2u(c.w));
         float *orow = a.out + (size_t)r * pitch;
         if (a.flags & 2) __builtin_nontemporal_store(vf4{o.x, o.y, o.z, o.w}, reinterpret_cast<vf4 *>(orow + col));
         else *reinterpret_cast<float4 *>(orow + col) = o;
@@ -210,6 +246,10 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
     if (CHECK) {
         dmax = wave_max(dmax);
         if (lane == 0 && dmax > 0.0f) atomicMax(a.delta_bits, __float_as_uint(dmax));
+    }
+    if (a.act_out) {
+        const bool any = __ballot(changed) != 0;
+        if (lane == 0) a.act_out[task] = any ? 1 : 0;
     }
 }
 
@@ -437,7 +477,7 @@ void launch_sweep_2d_math(int math, int nblocks, hipStream_t stream, const Sweep
 // parity < 0: Jacobi sweep in -> out.  parity = 0 / 1: red-black half-sweep in place (in == out required).
 hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int row_begin,
                            int row_end, int rows_per_task, int math, int parity, unsigned *delta_bits,
-                           hipStream_t stream)
+                           hipStream_t stream, const Activity *act)
 {
     if (row_end <= row_begin) return hipSuccess;
     if (pitch <= 0 || (pitch % 256) != 0 || rows <= 0 || row_begin < 0 || row_end > rows || rows_per_task <= 0)
@@ -458,6 +498,21 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, i
     a.ntasks = a.nstrips * nchunks;
     a.parity = parity < 0 ? 0 : (parity & 1);
     a.flags = sweep_flags();
+    a.act_in = nullptr;
+    a.act_out = nullptr;
+    a.nchunks = nchunks;
+    a.force = 1;
+    a.band = 0;
+    if (act && act->out && row_begin == 0 && row_end == rows) {
+        a.act_in = act->in;
+        a.act_out = act->out;
+        a.force = act->force;
+        static const int band_chunks = [] {
+            const char *e = getenv("EPIC_HIP_BAND");
+            return e ? atoi(e) : 4;
+        }();
+        a.band = (band_chunks * a.nstrips + kWavesPerBlock - 1) / kWavesPerBlock;
+    }
     const int nblocks = (a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock;
     if (parity < 0) {
         if (delta_bits) launch_sweep_2d_math<true, false>(math, nblocks, stream, a);
@@ -488,6 +543,11 @@ hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw
     a.ntasks = a.nstrips * ((rows + rows_per_task - 1) / rows_per_task);
     a.parity = parity & 1;
     a.flags = sweep_flags();
+    a.act_in = nullptr;
+    a.act_out = nullptr;
+    a.nchunks = 0;
+    a.force = 1;
+    a.band = 0;
     const dim3 grid((a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
     if (math == kMathFast) hipLaunchKernelGGL((rb_fused2d_kernel<kMathFast>), grid, block, 0, stream, a);
     else if (math == kMathTraffic) hipLaunchKernelGGL((rb_fused2d_kernel<kMathTraffic>), grid, block, 0, stream, a);

@@ -60,6 +60,17 @@ int epic_hip_set_math_mode(EpicHarmonicT *harmonic, int mode);
  * harmonic_complete_cpu.  Also EPIC_HIP_SCHEME=jacobi|redblack in the environment at initialisation. */
 int epic_hip_set_scheme(EpicHarmonicT *harmonic, int scheme);
 
+/* Activity tracking of the 2-D solver (on by default; EPIC_HIP_TRACK=0 in the environment at initialisation turns it
+ * off).  Each sweep records, per tile of rows_per_task x 256 cells, whether any value changed; the next sweep skips a
+ * tile when neither it nor its four edge neighbours changed -- the update would reproduce the values already held, so
+ * fields, delta and iteration counts are bit-identical with tracking on or off.  Any upload, set_cells or mode change
+ * forces the next two iterations to run every tile.  bench.py times the kernel with tracking off. */
+int epic_hip_set_activity_tracking(EpicHarmonicT *harmonic, int on);
+
+/* Diagnostic: the number of tiles whose values changed in the latest iteration and the number of tiles (both 0 when
+ * tracking is off or the grid is 3-D).  Synchronises the stream and copies the flag bytes to the host. */
+int epic_hip_activity_stats(EpicHarmonicT *harmonic, unsigned long long *active_tiles, unsigned long long *tiles);
+
 /* Test hook: d_out[i] = which ? ln(d_in[i]) : exp(d_in[i]) with the precise device routines. */
 int epic_hip_eval_math(const float *d_in, float *d_out, size_t n, int which, void *stream);
 

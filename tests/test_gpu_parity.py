@@ -510,6 +510,7 @@ def test_redblack_fused_pairs_equal_the_checker(m, rpt):
         h = make(m, u0, locked)
         gpu_init(h)
         assert E.epic_hip_set_scheme(h, 1) == 0
+        assert E.epic_hip_set_activity_tracking(h, 0) == 0   # the fused pass is the tracking-off path
         if rpt:
             assert E.epic_hip_set_rows_per_task(h, rpt) == 0
         assert E.harmonic_update_and_check_gpu(h, NT) in (0, 1)
@@ -521,3 +522,92 @@ def test_redblack_fused_pairs_equal_the_checker(m, rpt):
         for i in range(k):
             (lib.oracle_update_and_check if i == 0 else lib.oracle_update)(ct.byref(p.h))
         assert np.array_equal(h.u_array().ravel(), p.u), f"{m} after {k} iterations"
+
+
+# ---- activity tracking (on by default, so every test above already runs with it): tiles whose inputs did not change
+# are skipped.  It must be invisible: same bits, same delta, same iteration counts as with tracking off and as the
+# checker, across uploads, set_cells edits and mode changes; and it must actually skip something.
+def _activity(h):
+    a, t = ct.c_ulonglong(0), ct.c_ulonglong(0)
+    assert E.epic_hip_activity_stats(h, ct.byref(a), ct.byref(t)) == 0
+    return a.value, t.value
+
+
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_activity_tracking_is_invisible_and_skips(scheme):
+    m = [260, 1100]
+    u0, locked = synthetic_grid(m, 31, 0.05)
+    lib = O.oracle()
+    p = O.Problem(m, u0, locked)
+    run = lib.oracle_jacobi_run if scheme == 0 else None
+    fields = {}
+    for track in (1, 0):
+        h = make(m, u0, locked)
+        gpu_init(h)
+        assert E.epic_hip_set_scheme(h, scheme) == 0 and E.epic_hip_set_rows_per_task(h, 4) == 0
+        assert E.epic_hip_set_activity_tracking(h, track) == 0
+        assert E.epic_hip_update_n_gpu(h, 60, 1) in (0, 1)
+        if track:
+            act, tiles = _activity(h)
+            assert tiles == 65 * 5 and 0 < act < tiles, (act, tiles)   # the front has not reached the far strips yet
+        else:
+            assert _activity(h) == (0, 0)
+        # an edit in a quiet corner: a new goal far from the front must start spreading at once
+        v = np.array([250, 1050], dtype=np.uint32)
+        types = np.array([eh.EPIC_CELL_TYPE_GOAL], dtype=np.uint32)
+        assert E.harmonic_utilities_set_cells_2d_gpu(h, NT, 1, v.ctypes.data_as(eh._UP), types.ctypes.data_as(eh._UP)) == 0
+        assert E.epic_hip_update_n_gpu(h, 41, 1) in (0, 1)
+        d1 = float(h.delta)
+        # a mode change mid-run: every tile must be recomputed under the new update rule
+        assert E.epic_hip_set_math_mode(h, eh.MATH_FAST) == 0
+        assert E.epic_hip_update_n_gpu(h, 3, 0) == 0
+        assert E.epic_hip_set_math_mode(h, eh.MATH_PRECISE) == 0
+        assert E.epic_hip_update_n_gpu(h, 700, 1) in (0, 1)
+        assert E.harmonic_get_potential_values_gpu(h) == 0
+        fields[track] = (h.u_array().ravel().copy(), d1, float(h.delta), int(h.currentIteration))
+        gpu_fini(h)
+    assert np.array_equal(fields[1][0], fields[0][0]) and fields[1][1:] == fields[0][1:]
+    # and against the checker up to the mode change (the fast mode has no CPU twin)
+    h = make(m, u0, locked)
+    gpu_init(h)
+    assert E.epic_hip_set_scheme(h, scheme) == 0 and E.epic_hip_set_rows_per_task(h, 4) == 0
+    assert E.epic_hip_update_n_gpu(h, 60, 1) in (0, 1)
+    v = np.array([250, 1050], dtype=np.uint32)
+    types = np.array([eh.EPIC_CELL_TYPE_GOAL], dtype=np.uint32)
+    assert E.harmonic_utilities_set_cells_2d_gpu(h, NT, 1, v.ctypes.data_as(eh._UP), types.ctypes.data_as(eh._UP)) == 0
+    assert E.epic_hip_update_n_gpu(h, 400, 1) in (0, 1)
+    assert E.harmonic_get_potential_values_gpu(h) == 0
+    gpu_fini(h)
+    if scheme == 0:
+        assert lib.oracle_jacobi_run(ct.byref(p.h), 60) == 0
+    else:
+        for _ in range(60):
+            lib.oracle_update(ct.byref(p.h))
+    assert lib.oracle_set_cells_2d(ct.byref(p.h), 1, v.ctypes.data_as(eh._UP), types.ctypes.data_as(eh._UP)) == 0
+    if scheme == 0:
+        assert lib.oracle_jacobi_run(ct.byref(p.h), 400) == 0
+    else:
+        for i in range(400):
+            (lib.oracle_update_and_check if i == 399 else lib.oracle_update)(ct.byref(p.h))
+    assert np.array_equal(h.u_array().ravel(), p.u) and float(h.delta) == float(p.h.delta)
+
+
+def test_activity_tracking_survives_model_reupload_and_graph_replay():
+    """A small grid runs its plain sweeps as captured hipGraphs (which bake in the flag buffers); re-uploading the model
+    must force full sweeps again, and the replayed graphs must keep the flag ping-pong in step."""
+    m = [96, 700]
+    u0, locked = synthetic_grid(m, 77, 0.06)
+    lib = O.oracle()
+    h = make(m, u0, locked)
+    gpu_init(h)
+    for rounds in range(2):
+        for n in (100, 33, 100, 8, 100):   # odd and even batch lengths, repeated so that graphs are replayed
+            assert E.epic_hip_update_n_gpu(h, n, 1) in (0, 1)
+        assert E.harmonic_get_potential_values_gpu(h) == 0
+        p = O.Problem(m, u0, locked)
+        assert lib.oracle_jacobi_run(ct.byref(p.h), 341) == 0
+        assert np.array_equal(h.u_array().ravel(), p.u) and float(h.delta) == float(p.h.delta)
+        h.u_array().ravel()[:] = u0   # start over from the host copy
+        h.currentIteration = 0
+        assert E.harmonic_update_model_gpu(h) == 0
+    gpu_fini(h)
