@@ -153,6 +153,7 @@ class SlabSolver:
             b.fill_(-1e6)
             b[:, :self.cols] = torch.from_numpy(u_rows).to(self.device)
         lk = torch.from_numpy(locked_rows.astype(np.int32)).to(self.device)
+        self.locked_rows = lk  # kept for set_cells(): the packed mask format is the backend's business
         # only the outermost ghost row is pinned (it has nothing above it to be computed from)
         self.backend.pack_mask(lk, self.rows, self.cols, self.pitch, self.ghost_top, self.ghost_bottom, self.maskw)
         if self.cuda:
@@ -173,6 +174,44 @@ class SlabSolver:
     def load_synthetic(self, seed=DEFAULT_SEED, density=0.05):
         u, lk = synthetic_rows(self.grid, self.lo - self.g_top, self.hi + self.g_bot, seed, density)
         return self.load_rows(u, lk)
+
+    def set_cells(self, v, types):
+        """The slab form of harmonic_utilities_set_cells_2d_gpu (harmonic_utilities_gpu.cu:38-138): `v` holds k GLOBAL
+        (x = column, y = row) pairs, `types` k cell types (0 goal: u = 0, locked; 1 obstacle: u = -1e6, locked; 2 free:
+        u = -1e6, unlocked; border cells stay locked).  Every rank gets the whole list and applies the edits that fall
+        into its local rows -- owned AND ghost rows, so that neighbours agree without an exchange -- to both ping-pong
+        buffers, then repacks its mask.  Returns the number of edits this rank OWNS."""
+        v = np.asarray(v, dtype=np.int64).reshape(-1, 2)
+        types = np.asarray(types, dtype=np.int64).reshape(-1)
+        if v.shape[0] != types.shape[0]:
+            raise ValueError("set_cells: one type per (x, y) pair")
+        top = self.lo - self.g_top                      # global row of local row 0
+        x, y = v[:, 0], v[:, 1]
+        ok = (types >= 0) & (types <= 2) & (x >= 0) & (x < self.cols) & (y >= 0) & (y < self.grid[0])
+        here = ok & (y >= top) & (y < top + self.rows)
+        owned = int((ok & (y >= self.lo) & (y < self.hi)).sum())
+        if not here.any():
+            return owned
+        # later edits of the same cell win, as in a sequential loop: keep the last occurrence of each cell
+        xs, ys, ts = x[here], y[here] - top, types[here]
+        key = ys * self.cols + xs
+        _, last = np.unique(key[::-1], return_index=True)
+        keep = key.size - 1 - last
+        xs, ys, ts = xs[keep], ys[keep], ts[keep]
+        gy = ys + top
+        border = (xs == 0) | (xs == self.cols - 1) | (gy == 0) | (gy == self.grid[0] - 1)
+        val = torch.from_numpy(np.where(ts == 0, 0.0, -1e6).astype(np.float32)).to(self.device)
+        lock = torch.from_numpy(((ts != 2) | border).astype(np.int32)).to(self.device)
+        iy = torch.from_numpy(ys).to(self.device)
+        ix = torch.from_numpy(xs).to(self.device)
+        for b in self.buf:
+            b[iy, ix] = val
+        self.locked_rows[iy, ix] = lock
+        self.backend.pack_mask(self.locked_rows, self.rows, self.cols, self.pitch, self.ghost_top, self.ghost_bottom,
+                               self.maskw)
+        if self.cuda:
+            torch.cuda.synchronize(self.device)
+        return owned
 
     def owned(self):
         """This rank's owned rows of the current field, (hi - lo, cols), on the host."""

@@ -23,7 +23,15 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, grid, seed, sweeps, out_dir):
+def _edits(grid):
+    rows, cols = grid
+    v = [(cols // 2, rows // 2 - 1), (9, rows // 2), (cols - 7, rows // 3), (200, rows // 3 + 1), (17, 2 * rows // 3),
+         (300, rows // 2 + 3), (300, rows // 2 + 3)]
+    t = [1, 0, 1, 0, 2, 1, 2]
+    return np.array(v, dtype=np.uint32), np.array(t, dtype=np.uint32)
+
+
+def _worker(rank, world, port, grid, seed, sweeps, out_dir, edit=False):
     import torch
     import torch.distributed as dist
 
@@ -36,6 +44,10 @@ def _worker(rank, world, port, grid, seed, sweeps, out_dir):
     try:
         s = SlabSolver(grid, rank, world, device=torch.device("cuda:0"), stagger=10)
         s.load_synthetic(seed=seed, density=0.06)
+        if edit:
+            for i in range(sweeps):
+                s.sweep()
+            s.set_cells(*_edits(grid))
         for i in range(sweeps):
             s.sweep(check=(i == sweeps - 1))
         delta = s.reduce_delta()
@@ -53,5 +65,23 @@ def test_two_and_three_ranks_on_one_gpu_equal_single_domain(world, tmp_path):
     u0, locked = synthetic_grid(grid, seed, 0.06)
     p = O.Problem(grid, u0, locked)
     assert O.oracle().oracle_jacobi_run(ct.byref(p.h), sweeps) == 0
+    assert np.array_equal(field.ravel(), p.u)
+    assert all(float(q["delta"]) == float(p.h.delta) for q in parts)
+
+
+def test_set_cells_on_slabs_equals_single_domain(tmp_path):
+    """Live-map edits on and around the slab seams, HIP mask repack on every rank that holds the cell."""
+    world, grid, seed, sweeps = 2, [211, 530], 12, 21
+    mp.spawn(_worker, args=(world, _free_port(), grid, seed, sweeps, str(tmp_path), True), nprocs=world, join=True)
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    field = np.concatenate([p["u"] for p in parts], axis=0)
+    u0, locked = synthetic_grid(grid, seed, 0.06)
+    p = O.Problem(grid, u0, locked)
+    lib = O.oracle()
+    assert lib.oracle_jacobi_run(ct.byref(p.h), sweeps) == 0
+    v, t = _edits(grid)
+    assert lib.oracle_set_cells_2d(ct.byref(p.h), len(t), v.ctypes.data_as(ct.POINTER(ct.c_uint)),
+                                   t.ctypes.data_as(ct.POINTER(ct.c_uint))) == 0
+    assert lib.oracle_jacobi_run(ct.byref(p.h), sweeps) == 0
     assert np.array_equal(field.ravel(), p.u)
     assert all(float(q["delta"]) == float(p.h.delta) for q in parts)

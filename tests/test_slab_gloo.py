@@ -75,12 +75,40 @@ def _worker(rank, world, port, grid, seed, sweeps, mode, out_dir, halo=8):
             for i in range(sweeps):
                 s.sweep(check=(i == sweeps - 1))
             s.reduce_delta()
+        elif mode == "edit":
+            for i in range(sweeps):
+                s.sweep()
+            v, types = _edits(grid, seed)
+            free = s.set_cells(v, types)   # reported in place of the free-cell count: edits this rank owns
+            for i in range(sweeps + 3):
+                s.sweep(check=(i == sweeps + 2))
+            s.reduce_delta()
         else:
             s.solve()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), u=s.owned(), lo=s.lo, hi=s.hi, delta=s.delta,
                  iteration=s.iteration, free=free)
     finally:
         dist.destroy_process_group()
+
+
+def _edits(grid, seed):
+    """A live-map update (epic_navigation_node_harmonic.cpp:357-380): new goals, new obstacles, freed cells -- placed on
+    and around the slab seams of a 2- and a 3-way split, with a repeated cell (the later edit wins) and junk entries."""
+    _, locked = synthetic_grid(grid, seed, 0.08)
+    lk = locked.reshape(grid)
+    rows, cols = grid
+    v, t = [], []
+    for r in sorted({rows // 2 - 1, rows // 2, rows // 2 + 1, rows // 3, rows // 3 + 1, 2 * rows // 3, 5, rows - 3}):
+        v += [(7 + r % 5, r), (cols // 2, r), (cols - 4, r)]
+        t += [1, 0, 1]
+    blocked = np.argwhere(lk[1:-1, 1:-1] == 1)[::7] + 1          # some obstacles become free space
+    v += [(int(c), int(r)) for r, c in blocked]
+    t += [2] * len(blocked)
+    v += [(cols // 2, rows // 2), (cols // 2, rows // 2)]        # same cell twice: obstacle, then goal
+    t += [1, 0]
+    v += [(cols + 5, 3), (3, rows + 9), (4, 4)]                  # out of range / unknown type: ignored
+    t += [0, 1, 7]
+    return np.array(v, dtype=np.uint32), np.array(t, dtype=np.uint32)
 
 
 def _run(world, grid, seed, sweeps, mode, tmp_path, halo=8):
@@ -121,3 +149,24 @@ def test_solve_equals_single_domain_jacobi(tmp_path):
     assert O.oracle().oracle_jacobi_complete(ct.byref(p.h)) == 0
     assert all(int(q["iteration"]) == int(p.h.currentIteration) for q in parts)
     assert np.array_equal(field.ravel(), p.u)
+
+
+@pytest.mark.parametrize("world,halo,sweeps", [(2, 1, 11), (2, 8, 11), (3, 4, 10), (3, 5, 13)])
+def test_set_cells_between_sweeps_equals_single_domain(world, halo, sweeps, tmp_path):
+    """edits are routed to the slab(s) holding the cell (owned or ghost) and applied to both
+    ping-pong buffers; the exchange cadence (edits land between, on and off an exchange sweep) must not matter."""
+    grid, seed = [37, 50], 5
+    field, parts = _run(world, grid, seed, sweeps, "edit", tmp_path, halo)
+    u0, locked = synthetic_grid(grid, seed, 0.08)
+    p = O.Problem(grid, u0, locked)
+    lib = O.oracle()
+    assert lib.oracle_jacobi_run(ct.byref(p.h), sweeps) == 0
+    v, types = _edits(grid, seed)
+    ok = types <= 2
+    assert lib.oracle_set_cells_2d(ct.byref(p.h), int(ok.sum()), np.ascontiguousarray(v[ok]).ctypes.data_as(
+        ct.POINTER(ct.c_uint)), np.ascontiguousarray(types[ok]).ctypes.data_as(ct.POINTER(ct.c_uint))) == 0
+    assert lib.oracle_jacobi_run(ct.byref(p.h), sweeps + 3) == 0
+    assert np.array_equal(field.ravel(), p.u)
+    assert all(float(q["delta"]) == float(p.h.delta) for q in parts)
+    in_range = (v[:, 0] < grid[1]) & (v[:, 1] < grid[0]) & ok
+    assert sum(int(q["free"]) for q in parts) == int(in_range.sum())
