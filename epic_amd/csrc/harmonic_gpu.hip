@@ -8,7 +8,7 @@
 //    room for a second ping-pong buffer, a stream or pinned readback memory).  The struct's d_* fields are
 //    still set non-null / nulled exactly where the reference does, because callers and the library itself
 //    null-test them (harmonic_gpu.cu:208, :232-235; harmonic_model_gpu.cu:174-176);
-//  * u is kept pitched (row length padded to 64 floats) in two buffers; d_u points at the current one;
+//  * u is kept pitched (row length padded to 256 floats) in two buffers; d_u points at the current one;
 //  * locked is kept bit-packed (d_locked points at the packed words);
 //  * sweeps are enqueued on one non-blocking stream; only the check sweeps, the readbacks and the edits
 //    synchronise (the reference synchronises the whole device after every kernel).
@@ -925,6 +925,87 @@ int epic_hip_set_activity_tracking(Harmonic *harmonic, int on)
     if (!c || (on != 0 && on != 1)) return EPIC_ERROR_INVALID_DATA;
     c->track = on == 1;
     c->force = 2;
+    return EPIC_SUCCESS;
+}
+
+// Streamlines on the resident field.  starts: n_paths (x, y) pairs; k / rc: n_paths entries; paths: n_paths rows of
+// 2 * maxLength floats (row i holds 2 * k[i] values).  All host pointers.
+int epic_hip_compute_paths_2d_gpu(Harmonic *harmonic, unsigned int n_paths, const float *starts, float stepSize,
+                                  float cdPrecision, unsigned int maxLength, unsigned int *k, int *rc_out, float *paths)
+{
+    static const char *fn = "epic_hip_compute_paths_2d_gpu";
+    Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
+    if (!harmonic || !ready(harmonic, c) || c->n != 2 || n_paths == 0 || !starts || !k || !rc_out || !paths) {
+        report(fn, "Invalid data.");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    // the host walk stops at size() < 2u * maxLength values (unsigned product, harmonic_path_cpu.cpp:185)
+    const unsigned max_points = (2u * maxLength) / 2u;
+    const size_t row = 2 * (size_t)max_points;
+    float *d_starts = nullptr, *d_pts = nullptr;
+    unsigned *d_k = nullptr;
+    int *d_rc = nullptr;
+    int rc = EPIC_SUCCESS;
+    if (hipMalloc((void **)&d_starts, 2 * (size_t)n_paths * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&d_pts, std::max<size_t>(row * n_paths, 1) * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&d_k, (size_t)n_paths * sizeof(unsigned)) != hipSuccess ||
+        hipMalloc((void **)&d_rc, (size_t)n_paths * sizeof(int)) != hipSuccess) {
+        (void)hipGetLastError();
+        report(fn, "Failed to allocate device-side memory for the paths.");
+        rc = EPIC_ERROR_DEVICE_MALLOC;
+    } else if (hipMemcpyAsync(d_starts, starts, 2 * (size_t)n_paths * sizeof(float), hipMemcpyHostToDevice, c->stream) !=
+               hipSuccess) {
+        report(fn, "Failed to copy memory from host to device for the start points.");
+        rc = EPIC_ERROR_MEMCPY_TO_DEVICE;
+    } else if (epic_hip::launch_follow_paths_2d(c->buf[c->cur], c->maskw, c->rows, c->cols, c->pitch, n_paths, d_starts,
+                                                stepSize, cdPrecision, max_points, d_pts, d_k, d_rc, c->stream) != hipSuccess) {
+        report(fn, "Failed to execute the 'follow paths' kernel.");
+        rc = EPIC_ERROR_KERNEL_EXECUTION;
+    } else if (hipMemcpyAsync(k, d_k, (size_t)n_paths * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+               hipMemcpyAsync(rc_out, d_rc, (size_t)n_paths * sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+               hipStreamSynchronize(c->stream) != hipSuccess) {
+        report(fn, "Failed to copy memory from device to host for the path lengths.");
+        rc = EPIC_ERROR_MEMCPY_TO_HOST;
+    } else {
+        for (unsigned i = 0; i < n_paths; i++)  // only the way-points that exist come back
+            if (k[i] > 0 && hipMemcpyAsync(paths + i * row, d_pts + i * row, 2 * (size_t)k[i] * sizeof(float),
+                                           hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+                rc = EPIC_ERROR_MEMCPY_TO_HOST;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) rc = EPIC_ERROR_MEMCPY_TO_HOST;
+        if (rc != EPIC_SUCCESS) report(fn, "Failed to copy memory from device to host for the paths.");
+    }
+    if (rc != EPIC_SUCCESS) (void)hipStreamSynchronize(c->stream);
+    for (void *p : {(void *)d_starts, (void *)d_pts, (void *)d_k, (void *)d_rc})
+        if (p) (void)hipFree(p);
+    return rc;
+}
+
+// harmonic_compute_path_2d_cpu's contract (harmonic_path_cpu.cpp:154-221) on the resident field: *path must be null on
+// entry and receives a new[] array of 2 * *k floats that harmonic_free_path_cpu (or delete[]) releases.
+int epic_hip_compute_path_2d_gpu(Harmonic *harmonic, float x, float y, float stepSize, float cdPrecision,
+                                 unsigned int maxLength, unsigned int *k, float **path)
+{
+    static const char *fn = "epic_hip_compute_path_2d_gpu";
+    if (!harmonic || !k || !path || *path != nullptr) {
+        report(fn, "Invalid data.");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    const size_t row = 2 * (size_t)((2u * maxLength) / 2u);
+    std::vector<float> pts(std::max<size_t>(row, 1));
+    const float start[2] = {x, y};
+    unsigned n = 0;
+    int walk = EPIC_SUCCESS;
+    int rc = epic_hip_compute_paths_2d_gpu(harmonic, 1, start, stepSize, cdPrecision, maxLength, &n, &walk, pts.data());
+    if (rc != EPIC_SUCCESS) return rc;
+    if (walk != EPIC_SUCCESS) {
+        report(fn, walk == EPIC_ERROR_INVALID_LOCATION ? "Invalid location."
+                   : walk == EPIC_ERROR_INVALID_GRADIENT ? "Could not compute gradient."
+                                                         : "Could not compute a valid path.");
+        return walk;
+    }
+    *k = n;
+    *path = new float[2 * (size_t)n];
+    std::copy(pts.begin(), pts.begin() + 2 * (size_t)n, *path);
     return EPIC_SUCCESS;
 }
 

@@ -35,6 +35,12 @@ hipError_t launch_fill(float *p, size_t n, float v, hipStream_t stream);
 hipError_t launch_set_cells_2d(float *u, uint32_t *maskw, int rows, int cols, int pitch, unsigned k,
                                const unsigned *v, const unsigned *types, hipStream_t stream);
 
+// ---- streamlines on the resident field (path_2d.hip): one lane per start point ----------------
+// d_pts: n_paths x 2 * max_points floats; d_k: points per path (0 on failure); d_rc: EPIC_* code per path.
+hipError_t launch_follow_paths_2d(const float *u, const uint32_t *maskw, int rows, int cols, int pitch, unsigned n_paths,
+                                  const float *d_starts, float step, float cd, unsigned max_points, float *d_pts,
+                                  unsigned *d_k, int *d_rc, hipStream_t stream);
+
 // rows are padded to whole wave-strips (256 floats = 1 KiB): every lane of every wave is in bounds, always
 inline int pitch_for_cols(int cols) { return (cols + 255) / 256 * 256; }
 inline size_t mask_words_2d(int rows, int pitch) { return (size_t)((rows + 7) / 8) * (size_t)(pitch / 4); }

@@ -125,6 +125,10 @@ _SIGNATURES = {
     "epic_hip_set_math_mode": (_H, ct.c_int),
     "epic_hip_set_scheme": (_H, ct.c_int),
     "epic_hip_set_activity_tracking": (_H, ct.c_int),
+    "epic_hip_compute_paths_2d_gpu": (_H, ct.c_uint, ct.POINTER(ct.c_float), ct.c_float, ct.c_float, ct.c_uint, _UP,
+                                      ct.POINTER(ct.c_int), ct.POINTER(ct.c_float)),
+    "epic_hip_compute_path_2d_gpu": (_H, ct.c_float, ct.c_float, ct.c_float, ct.c_float, ct.c_uint, _UP,
+                                     ct.POINTER(ct.POINTER(ct.c_float))),
     "epic_hip_activity_stats": (_H, ct.POINTER(ct.c_ulonglong), ct.POINTER(ct.c_ulonglong)),
     "epic_hip_eval_math": (ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_int, ct.c_void_p),
     "epic_hip_get_layout": (_H, _UP, ct.POINTER(ct.c_size_t), ct.POINTER(ct.c_size_t)),

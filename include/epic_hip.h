@@ -67,6 +67,21 @@ int epic_hip_set_scheme(EpicHarmonicT *harmonic, int scheme);
  * forces the next two iterations to run every tile.  bench.py times the kernel with tracking off. */
 int epic_hip_set_activity_tracking(EpicHarmonicT *harmonic, int on);
 
+/* Streamline extraction on the device-resident field (the path step that follows the relaxation).
+ * The reference copies the whole field to the host for every request (src/epic_navigation_node_harmonic.cpp:621-626) and
+ * walks it with harmonic_compute_path_2d_cpu (libepic/src/harmonic/harmonic_path_cpu.cpp:154-221); these walk it in HBM,
+ * one lane per start point, and return only the way-points -- bit-identical to the host walk on the same field.
+ *   starts  n_paths (x, y) pairs in cell units;  k / rc  n_paths entries (rc: EPIC_SUCCESS, EPIC_ERROR_INVALID_LOCATION,
+ *   EPIC_ERROR_INVALID_GRADIENT or EPIC_ERROR_INVALID_PATH per path, k = 0 unless EPIC_SUCCESS);
+ *   paths   n_paths rows of 2 * maxLength floats, row i holding k[i] (x, y) pairs.  All pointers are host pointers.
+ * The device mask treats the grid border as locked (harmonic.h:35-37 makes that a precondition of the solver). */
+int epic_hip_compute_paths_2d_gpu(EpicHarmonicT *harmonic, unsigned int n_paths, const float *starts, float stepSize,
+                                  float cdPrecision, unsigned int maxLength, unsigned int *k, int *rc, float *paths);
+/* One path, with harmonic_compute_path_2d_cpu's contract: *path must be NULL, receives a new[] array of 2 * *k floats
+ * (release with harmonic_free_path_cpu), the return value is the walk's code. */
+int epic_hip_compute_path_2d_gpu(EpicHarmonicT *harmonic, float x, float y, float stepSize, float cdPrecision,
+                                 unsigned int maxLength, unsigned int *k, float **path);
+
 /* Diagnostic: the number of tiles whose values changed in the latest iteration and the number of tiles (both 0 when
  * tracking is off or the grid is 3-D).  Synchronises the stream and copies the flag bytes to the host. */
 int epic_hip_activity_stats(EpicHarmonicT *harmonic, unsigned long long *active_tiles, unsigned long long *tiles);

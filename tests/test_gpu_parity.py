@@ -611,3 +611,74 @@ def test_activity_tracking_survives_model_reupload_and_graph_replay():
         h.currentIteration = 0
         assert E.harmonic_update_model_gpu(h) == 0
     gpu_fini(h)
+
+
+# ---- streamlines on the device-resident field (epic_amd/csrc/path_2d.hip) ----------------------
+def _resident_reference_field(goldens, name):
+    """The REFERENCE's converged field of a map, uploaded as is: what the walk sees is exactly what the golden paths saw."""
+    m, _, locked = O.load_png_reference_rule(os.path.join(O.ROOT, "tests", "golden", "maps", name + ".png"))
+    h = make(m, goldens["maps"][name + "/converged_1e-06"], locked)
+    gpu_init(h)
+    return h
+
+
+@pytest.mark.parametrize("name", ["basic", "umass", "maze"])
+def test_device_streamlines_match_reference_goldens(goldens, name):
+    import hashlib
+    paths = np.load(os.path.join(O.ROOT, "tests", "golden", "paths.npz"))
+    h = _resident_reference_field(goldens, name)
+    PF = ct.POINTER(ct.c_float)
+    for j in range(6):
+        sx, sy, step, cd = (float(v) for v in paths[f"{name}/path{j}_start"])
+        k, raw = ct.c_uint(0), PF()
+        rc = E.epic_hip_compute_path_2d_gpu(h, sx, sy, step, cd, 1000000, ct.byref(k), ct.byref(raw))
+        assert rc == int(paths[f"{name}/path{j}_rc"])
+        if rc != 0:
+            assert not raw
+            continue
+        pts = np.ctypeslib.as_array(raw, shape=(2 * k.value,)).copy()
+        assert E.harmonic_free_path_cpu(ct.byref(raw)) == 0 and not raw
+        key = f"{name}/path{j}"
+        assert pts.size // 2 == int(paths[key + "_k"])
+        assert np.array_equal(np.frombuffer(hashlib.sha256(pts.tobytes()).digest(), dtype=np.uint8), paths[key + "_sha256"])
+    # a non-null *path is refused, as by the host function
+    junk = (ct.c_float * 2)()
+    raw = ct.cast(junk, PF)
+    assert E.epic_hip_compute_path_2d_gpu(h, 5.0, 5.0, 0.5, 0.5, 10, ct.byref(ct.c_uint(0)), ct.byref(raw)) == eh.EPIC_ERROR_INVALID_DATA
+    gpu_fini(h)
+
+
+@pytest.mark.parametrize("name", ["umass", "maze"])
+def test_device_streamline_batch_equals_host_walk(goldens, name):
+    """300 random start points in one launch (free cells, obstacles, off-grid points) against harmonic_compute_path_2d_cpu
+    on the same field: same code, same number of way-points, same bits."""
+    h = _resident_reference_field(goldens, name)
+    rows, cols = h.locked_array().shape
+    rng = np.random.default_rng(99)
+    n, max_len = 300, 6000
+    starts = np.empty((n, 2), dtype=np.float32)
+    starts[:, 0] = rng.uniform(-3.0, cols + 2.0, n)
+    starts[:, 1] = rng.uniform(-3.0, rows + 2.0, n)
+    k = np.zeros(n, dtype=np.uint32)
+    rc = np.full(n, -1, dtype=np.int32)
+    out = np.full((n, 2 * max_len), np.nan, dtype=np.float32)
+    PF = ct.POINTER(ct.c_float)
+    step, cd = 0.45, 0.5
+    assert E.epic_hip_compute_paths_2d_gpu(h, n, starts.ctypes.data_as(PF), step, cd, max_len, k.ctypes.data_as(eh._UP),
+                                           rc.ctypes.data_as(ct.POINTER(ct.c_int)), out.ctypes.data_as(PF)) == 0
+    ok = 0
+    for i in range(n):
+        kk, raw = ct.c_uint(0), PF()
+        want = E.harmonic_compute_path_2d_cpu(h, float(starts[i, 0]), float(starts[i, 1]), step, cd, max_len,
+                                              ct.byref(kk), ct.byref(raw))
+        assert rc[i] == want, (i, starts[i], rc[i], want)
+        if want != 0:
+            assert k[i] == 0
+            continue
+        pts = np.ctypeslib.as_array(raw, shape=(2 * kk.value,)).copy()
+        E.harmonic_free_path_cpu(ct.byref(raw))
+        assert k[i] == kk.value
+        assert out[i, :2 * k[i]].tobytes() == pts.tobytes(), f"path {i} from {starts[i]}"
+        ok += 1
+    assert ok > 50   # the batch really walked a good number of paths
+    gpu_fini(h)
