@@ -39,6 +39,26 @@ class HarmonicMap(Harmonic):
         self.set_grid(m, u, locked)
         return self
 
+    def compute_streamline(self, x, y, step_size=0.2, cd_precision=0.4, max_length=int(1e6)):
+        """The way-points from the "float pixel" (x, y) to a goal on the host copy of the relaxed field, as a list of
+        (x, y) tuples: the reference's HarmonicMap._compute_streamline (harmonic_map.py:103-131), same defaults, through
+        harmonic_compute_path_2d_cpu / harmonic_free_path_cpu.  Raises RuntimeError with the library's code on failure."""
+        import ctypes as ct
+
+        from . import epic_harmonic as eh
+
+        k = ct.c_uint(0)
+        raw = ct.POINTER(ct.c_float)()
+        rc = eh._epic.harmonic_compute_path_2d_cpu(self, float(x), float(y), float(step_size), float(cd_precision),
+                                                   int(max_length), ct.byref(k), ct.byref(raw))
+        if rc != 0:
+            raise RuntimeError("harmonic_compute_path_2d_cpu failed with code %d" % rc)
+        path = [(raw[2 * i], raw[2 * i + 1]) for i in range(int(k.value))]
+        eh._epic.harmonic_free_path_cpu(ct.byref(raw))
+        return path
+
+    _compute_streamline = compute_streamline  # the reference's (private) name
+
 
 # ---- the ROS ingestion routes (SURVEY.md §8f-3) ------------------------------------------------------------------
 # maps/*.yaml + image --map_server--> nav_msgs/OccupancyGrid --navigation node--> Harmonic arrays, and

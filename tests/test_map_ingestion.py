@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 
 import _oracle as O
 from epic_amd import harmonic_map as hm
@@ -55,3 +56,22 @@ def test_yaml_route_agrees_with_png_route_on_the_reference_maps():
         assert list(h.shape) == m
         assert np.array_equal(h.locked_array() == 1, px_obstacle)
         assert h.meta["resolution"] > 0 and len(h.meta["origin"]) == 3
+
+
+def test_harmonic_map_streamline_helper(goldens):
+    """HarmonicMap._compute_streamline (reference harmonic_map.py:103-131): defaults 0.2 / 0.4 / 1e6, list of tuples,
+    ends in a goal cell; an obstacle start raises."""
+    import os
+
+    import _oracle as O
+    from epic_amd.harmonic_map import HarmonicMap
+
+    h = HarmonicMap().load(os.path.join(O.ROOT, "tests", "golden", "maps", "umass.png"))
+    h.u_array().ravel()[:] = goldens["maps"]["umass/converged_1e-06"]
+    path = h._compute_streamline(541.0, 54.0)   # golden path 0's start, golden parameters = the defaults
+    assert len(path) > 100 and path[0] == (541.0, 54.0)
+    assert len(path) == int(np.load(os.path.join(O.ROOT, 'tests', 'golden', 'paths.npz'))['umass/path0_k'])
+    ex, ey = int(path[-1][0] + 0.5), int(path[-1][1] + 0.5)
+    assert h.locked_array()[ey, ex] == 1 and h.u_array()[ey, ex] == 0.0
+    with pytest.raises(RuntimeError):
+        h.compute_streamline(0.0, 0.0)
