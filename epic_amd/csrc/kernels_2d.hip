@@ -86,6 +86,8 @@ __device__ __forceinline__ int xcd_banded_block(int b, int nblk, int k)
 // cells with (row + col + currentIteration) odd are recomputed (harmonic_cpu.cpp:46-51), from neighbours that all have
 // the other colour and therefore do not change during this launch -- no ordering between waves is needed, and with
 // the precise math the result is the reference CPU solver's, bit for bit, half-sweep for half-sweep.
+// (88 VGPRs = 5 waves per SIMD with the precise math.  Asking the allocator for 6 or 7 waves -- amdgpu_waves_per_eu --
+// spills and is slower: 196 / 191 us against 188 us per 8192^2 sweep, profiles/r01_experiments.txt.)
 template <bool CHECK, int MATH, bool RB>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2dArgs a)
 {
