@@ -14,10 +14,13 @@ Prints ONE JSON line on rank 0.  Extra objects:
   roofline      dominant kernel (sweep2d) vs the HBM roofline: 8 algorithmic bytes per grid cell per sweep
                 (read u once, write u once) / mean launch-to-launch device time, measured with HIP
                 events on the stream the kernels run on (epic_hip_timed_sweeps_gpu).
-  cpu_baseline  the CPU restatement of the reference solver (oracle/liboracle.so, kind "port", 1 thread -- the
-                reference is single-threaded) timed on this host for a bounded number of red-black half-sweeps of
-                the same grid.  Rank 0, N = 1 only.
-  relax         (N = 1) the complete relaxation to epsilon = 1e-6 through harmonic_execute_gpu: sweeps, seconds.
+  cpu_baseline  the reference's own harmonic_cpu.cpp compiled by oracle/Makefile (oracle/_ref/libepic_ref.so, kind
+                "reference") or, when that did not travel with the repo, its C restatement (oracle/liboracle.so, kind
+                "port"); 1 thread -- the reference is single-threaded -- timed on this host for a bounded number of
+                red-black half-sweeps of the same grid.  Rank 0, N = 1 only.
+  relax*        (N = 1) the complete relaxation to epsilon = 1e-6 through harmonic_execute_gpu: iterations, seconds --
+                Jacobi and red-black with the library defaults (activity tracking on), Jacobi also with tracking off.
+The timed region itself runs with activity tracking OFF: every sweep recomputes every unlocked cell.
 """
 import argparse
 import ctypes as ct
@@ -61,23 +64,30 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(m, u0, locked, half_sweeps):
-    """Checker leg: the reference's red-black half-sweep (port in oracle/), single thread, bounded sample."""
+def cpu_baseline(m, u0, locked, half_sweeps, free_by_colour):
+    """Checker leg: the reference's red-black half-sweeps on one host thread, bounded sample.  When the compiled reference
+    travelled with the repo (oracle/_ref/libepic_ref.so, built by oracle/Makefile from the reference's own
+    harmonic_cpu.cpp) that is what is timed (kind "reference"); otherwise the C restatement in oracle/ (kind "port")."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
 
-    lib = O.oracle()
     p = O.Problem(m, u0, locked, 1e-6, 100)
-    lib.oracle_reset_counters()
+    ref = O.ref()
+    if ref is not None:
+        kind, plain, check = "reference", ref.harmonic_update_cpu, ref.harmonic_update_and_check_cpu
+    else:
+        lib = O.oracle()
+        kind, plain, check = "port", lib.oracle_update, lib.oracle_update_and_check
     t0 = time.perf_counter()
     for i in range(half_sweeps):
-        (lib.oracle_update_and_check if i % 100 == 0 else lib.oracle_update)(ct.byref(p.h))
+        (check if i % 100 == 0 else plain)(ct.byref(p.h))
     dt = time.perf_counter() - t0
-    updates = int(lib.oracle_cell_updates())
+    # iteration i recomputes the unlocked cells with (row + col + i) odd (harmonic_cpu.cpp:46-51)
+    updates = sum(free_by_colour[i % 2] for i in range(half_sweeps))
     return dict(value=round(updates / dt / 1e6, 3), unit="Mcell-updates/s", cores=1, host_cores=os.cpu_count(),
-                kind="port", seconds=round(dt, 2),
-                sample="%d red-black half-sweeps of the same %dx%d grid (full relaxation needs ~5e4, ~15 h on one core)"
-                       % (half_sweeps, m[0], m[1]))
+                kind=kind, seconds=round(dt, 2),
+                sample="%d red-black half-sweeps (harmonic_update_cpu, one of them with the convergence check) of the "
+                       "same %dx%d grid (full relaxation needs ~5e4, ~15 h on one core)" % (half_sweeps, m[0], m[1]))
 
 
 def measured_traffic(n, math, scheme):
@@ -300,7 +310,7 @@ def main():
                    E.harmonic_uninitialize_locked_gpu):
             fn(h)
         if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(grid, u0, locked, args.cpu_half_sweeps)
+            out["cpu_baseline"] = cpu_baseline(grid, u0, locked, args.cpu_half_sweeps, free_by_colour)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
