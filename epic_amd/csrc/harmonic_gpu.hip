@@ -200,6 +200,7 @@ hipError_t enqueue_sweep(Ctx *c, bool check, unsigned iteration)
         const int rpt = auto_rows_per_task(c);
         const size_t tiles = epic_hip::sweep_2d_tiles(c->rows, c->pitch, rpt);
         if (tiles != c->act_tiles || rpt != c->act_rpt) {
+            drop_graphs(c);  // captured sequences hold the old flag buffers (never reached during a capture: force > 0)
             for (uint8_t *&p : c->act) { if (p) (void)hipFree(p); p = nullptr; }
             c->act_tiles = 0;
             if (hipMalloc((void **)&c->act[0], tiles) == hipSuccess && hipMalloc((void **)&c->act[1], tiles) == hipSuccess) {

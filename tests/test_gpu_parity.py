@@ -610,6 +610,14 @@ def test_activity_tracking_survives_model_reupload_and_graph_replay():
         h.u_array().ravel()[:] = u0   # start over from the host copy
         h.currentIteration = 0
         assert E.harmonic_update_model_gpu(h) == 0
+    # changing the tiling re-allocates the flags: graphs captured for the old tiling must not be replayed afterwards
+    for rpt, n in ((2, 64), (3, 64), (2, 64), (0, 64)):
+        assert E.epic_hip_set_rows_per_task(h, rpt) == 0
+        assert E.epic_hip_update_n_gpu(h, n, 1) in (0, 1)
+    assert E.harmonic_get_potential_values_gpu(h) == 0
+    p = O.Problem(m, u0, locked)
+    assert lib.oracle_jacobi_run(ct.byref(p.h), 256) == 0
+    assert np.array_equal(h.u_array().ravel(), p.u) and float(h.delta) == float(p.h.delta)
     gpu_fini(h)
 
 
