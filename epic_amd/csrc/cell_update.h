@@ -245,6 +245,27 @@ __device__ __forceinline__ float cell_update_2d(float up, float down, float left
 {
     if (MATH == kMathTraffic) return ((up + down) + left) + right;
     float mx = max2(max2(max2(up, down), left), right);
+    if (MATH == kMathPrecise) {
+        // One of the four terms is expf(0) = 1 exactly -- the neighbour that IS the maximum (the first one, if several
+        // tie: the others go through the exp and come out as 1 as well).  Evaluating only the other three saves one of
+        // the four f64 exps (10 of the 51 four-cycle instructions per cell) for ten selects and compares.  With
+        // P_k = "the maximum is among the first k + 1 neighbours", the three arguments in order are
+        //   w0 = P0 ? down : up,  w1 = P1 ? left : down,  w2 = P2 ? right : left
+        // and the reference's sum ((e_up + e_down) + e_left) + e_right has its 1 at position p:
+        //   p = 0, 1: (1 + E0) + E1 + E2   (the first add commutes, so the two cases coincide)
+        //   p = 2   : (E0 + E1) + 1 + E2        p = 3: (E0 + E1) + E2 + 1
+        // i.e. E0 + (P1 ? 1 : E1), then + (P1 ? E1 : P2 ? 1 : E2), then + (P2 ? E2 : 1) -- the same f32 additions of
+        // the same values in the same order as the four-exp form, hence the same bits.
+        const bool p0 = up == mx, p1 = p0 | (down == mx), p2 = p1 | (left == mx);
+        const float e0 = precise_exp((p0 ? down : up) - mx, lds);
+        const float e1 = precise_exp((p1 ? left : down) - mx, lds);
+        const float e2 = precise_exp((p2 ? right : left) - mx, lds);
+        float s = e0 + (p1 ? 1.0f : e1);
+        s = s + (p1 ? e1 : (p2 ? 1.0f : e2));
+        s = s + (p2 ? e2 : 1.0f);
+        const float t = mx + precise_ln(s, lds);
+        return (float)((double)t - kLn4);
+    }
     float s = m_exp<MATH>(up - mx, lds) + m_exp<MATH>(down - mx, lds);
     s = s + m_exp<MATH>(left - mx, lds);
     s = s + m_exp<MATH>(right - mx, lds);
