@@ -166,11 +166,14 @@ int auto_rows_per_task(const Ctx *c)
 {
     if (c->rows_per_task > 0) return c->rows_per_task;
     const long long nstrips = (c->pitch + 255) / 256;
-    // The kernel is VALU-bound (precise math), so what matters is keeping every SIMD at 8 resident waves with a
-    // short tail: aim at >= 16384 wave-tasks (2 rounds of 8192 resident waves); 2 extra halo rows per task are cheap.
+    // The kernel is VALU-bound (precise math): a full sweep of 8192^2 takes the same time with 8 to 32 rows per task
+    // (2 extra halo rows per task are cheap).  With activity tracking the tile is also the unit of skipping, and a sweep
+    // with few active tiles costs what its slowest SIMD costs: shorter tasks spread better (8192^2 at 10 % activity:
+    // 61 us with 16 rows, 46 us with 8 or 4; whole relaxation 4.76 -> 4.60 s), while below 4 rows the waves that only
+    // test their flags start to cost (profiles/r01_experiments.txt).  Aim at >= 32768 wave-tasks.
     // Small grids (the ROS maps are 0.1-1 Mcell) cannot fill the chip at all: there one row per wave is best
     // (310 x 940: 4.3 us per sweep at 1 row per task vs 11.4 us at 8, both measured).
-    long long r = (long long)c->rows * nstrips / 16384;
+    long long r = (long long)c->rows * nstrips / 32768;
     if (r >= 8) r = r / 8 * 8;
     else if (r >= 4) r = 4;
     else if (r >= 2) r = 2;
@@ -289,7 +292,11 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
     const bool small = (long long)c->rows * c->pitch <= (1ll << 22);
     static const bool no_graph = getenv("EPIC_HIP_NO_GRAPH") != nullptr;
     // a captured sequence bakes in the flag buffers and force = 0: run eagerly until the forced iterations are over
-    if (!small || count < 8 || no_graph || (c->track && c->n == 2 && (c->force > 0 || c->act_tiles == 0)))
+    // Large grids are replayed from a graph only with activity tracking: a sweep that skips most of its tiles is as
+    // launch-bound as a small grid (8192^2 at < 1 % activity: 23 us per eager launch, measured).
+    static const bool graph_tracked = getenv("EPIC_HIP_GRAPH_TRACKED") == nullptr || atoi(getenv("EPIC_HIP_GRAPH_TRACKED")) != 0;
+    const bool graphable = small || (graph_tracked && c->track && c->n == 2);
+    if (!graphable || count < 8 || no_graph || (c->track && c->n == 2 && (c->force > 0 || c->act_tiles == 0)))
         return enqueue_plain_run(c, count, first);
     const auto key = std::make_tuple(count, c->cur + 2 * c->act_cur + (c->track ? 4 : 0), (int)(first & 1u), c->math,
                                      (int)c->redblack, auto_rows_per_task(c));
@@ -1012,17 +1019,33 @@ int epic_hip_compute_path_2d_gpu(Harmonic *harmonic, float x, float y, float ste
 
 int epic_hip_activity_stats(Harmonic *harmonic, unsigned long long *active_tiles, unsigned long long *tiles)
 {
+    return epic_hip_activity_stats2(harmonic, active_tiles, nullptr, tiles);
+}
+
+int epic_hip_activity_stats2(Harmonic *harmonic, unsigned long long *active_tiles, unsigned long long *due_tiles,
+                             unsigned long long *tiles)
+{
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
     if (!c || !active_tiles || !tiles) return EPIC_ERROR_INVALID_DATA;
     *active_tiles = *tiles = 0;
+    if (due_tiles) *due_tiles = 0;
     if (!c->track || c->n != 2 || c->act_tiles == 0) return EPIC_SUCCESS;
     std::vector<uint8_t> flags(c->act_tiles);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return EPIC_ERROR_DEVICE_SYNCHRONIZE;
     if (hipMemcpy(flags.data(), c->act[c->act_cur], c->act_tiles, hipMemcpyDeviceToHost) != hipSuccess)
         return EPIC_ERROR_MEMCPY_TO_HOST;
-    unsigned long long n = 0;
-    for (uint8_t f : flags) n += f != 0;
+    const long long ns = (c->pitch + 255) / 256, nc = (long long)(c->act_tiles / ns);
+    unsigned long long n = 0, due = 0;
+    for (long long ch = 0; ch < nc; ch++)
+        for (long long st = 0; st < ns; st++) {
+            const long long t = ch * ns + st;
+            n += flags[t] != 0;
+            // the rule of the kernel's skip test (kernels_2d.hip)
+            due += (flags[t] & 1) || (st > 0 && (flags[t - 1] & 4)) || (st + 1 < ns && (flags[t + 1] & 2)) ||
+                   (ch > 0 && (flags[t - ns] & 16)) || (ch + 1 < nc && (flags[t + ns] & 8));
+        }
     *active_tiles = c->force > 0 ? c->act_tiles : n;
+    if (due_tiles) *due_tiles = c->force > 0 ? c->act_tiles : due;
     *tiles = c->act_tiles;
     return EPIC_SUCCESS;
 }

@@ -49,11 +49,14 @@ struct Sweep2dArgs {
     int ntasks;             // nstrips * nchunks
     int parity;             // red-black scheme only: currentIteration & 1 (which colour this half-sweep updates)
     int flags;              // tuning, never results: bit 0 = odd row-chunks march upwards, bit 1 = non-temporal stores
-    // Activity tracking (full-grid launches only; act_out == nullptr turns it off).  One byte per task tile:
-    // act_in[t] != 0 = "some cell of tile t changed in the previous iteration".  A tile whose own flag and whose four
-    // edge neighbours' flags are all clear has bit-for-bit the inputs it had last time, so its update is a no-op and
-    // the wave leaves at once (Jacobi: the output buffer already holds these values from two sweeps ago, because the
-    // tile itself did not change either).  `force` != 0 makes every tile run (first two iterations after any edit).
+    // Activity tracking (full-grid launches only; act_out == nullptr turns it off).  One byte per task tile, written by
+    // the previous iteration: bit 0 "some cell of the tile changed", bits 1 / 2 "a cell of its first / last column
+    // changed", bits 3 / 4 "a cell of its first / last row changed".  A tile is recomputed when its own bit 0 is set or a
+    // neighbour changed along the shared edge (left neighbour's last column, right neighbour's first column, upper
+    // neighbour's last row, lower neighbour's first row): those are all the values a 5-point update of the tile reads.
+    // Otherwise the tile has bit-for-bit the inputs it had last time, so its update is a no-op and the wave leaves at
+    // once (Jacobi: the output buffer already holds these values from two sweeps ago, because the tile itself did not
+    // change either).  `force` != 0 makes every tile run (first two iterations after any edit).
     const uint8_t *act_in;
     uint8_t *act_out;
     int nchunks;
@@ -88,7 +91,7 @@ __device__ __forceinline__ int xcd_banded_block(int b, int nblk, int k)
 // the precise math the result is the reference CPU solver's, bit for bit, half-sweep for half-sweep.
 // (88 VGPRs = 5 waves per SIMD with the precise math.  Asking the allocator for 6 or 7 waves -- amdgpu_waves_per_eu --
 // spills and is slower: 196 / 191 us against 188 us per 8192^2 sweep, profiles/r01_experiments.txt.)
-template <bool CHECK, int MATH, bool RB>
+template <bool CHECK, int MATH, bool RB, bool TRACK>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2dArgs a)
 {
     __shared__ __attribute__((aligned(16))) float ldsf[kDfLdsFloats];  // df32 tables (df32 math only)
@@ -101,14 +104,18 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int task = xcd_banded_block(blockIdx.x, gridDim.x, a.band) * kWavesPerBlock + wave;
     if (task >= a.ntasks) return;
-    if (a.act_out && a.force == 0) {  // everything here is wave-uniform (scalar loads, scalar branch)
+    if (TRACK && a.force == 0) {
+        // own flag and the four edge neighbours' flags, one lane each: a single round trip to memory
         const int st = task % a.nstrips, ch = task / a.nstrips;
-        unsigned any = a.act_in[task];
-        if (st > 0) any |= a.act_in[task - 1];
-        if (st + 1 < a.nstrips) any |= a.act_in[task + 1];
-        if (ch > 0) any |= a.act_in[task - a.nstrips];
-        if (ch + 1 < a.nchunks) any |= a.act_in[task + a.nstrips];
-        if (any == 0) {  // nothing this tile reads has changed: its values stand
+        int t = task;
+        unsigned bit = 1u;          // own tile: anything changed
+        bool valid = lane == 0;
+        if (lane == 1) { t = task - 1; bit = 4u; valid = st > 0; }                      // left neighbour's last column
+        if (lane == 2) { t = task + 1; bit = 2u; valid = st + 1 < a.nstrips; }          // right neighbour's first column
+        if (lane == 3) { t = task - a.nstrips; bit = 16u; valid = ch > 0; }             // upper neighbour's last row
+        if (lane == 4) { t = task + a.nstrips; bit = 8u; valid = ch + 1 < a.nchunks; }  // lower neighbour's first row
+        const bool hit = lane < 5 && valid && (a.act_in[t] & bit) != 0;
+        if (__ballot(hit) == 0) {  // nothing this tile reads has changed: its values stand
             if (lane == 0) a.act_out[task] = 0;
             return;
         }
@@ -157,7 +164,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
     typedef float vf4 __attribute__((ext_vector_type(4)));
 
     float dmax = 0.0f;
-    bool changed = false;  // any cell of this lane rewritten with different bits (activity tracking)
+    // activity tracking: cells of this lane rewritten with different bits -- anywhere, in its first / last column
+    // (meaningful in lane 0 / lane 63), in the task's first / last row
+    bool chg_any = false, chg_x = false, chg_w = false, chg_top = false, chg_bot = false;
     int gcur = rfirst >> 3;
     uint32_t mw = ldm(gcur), mw_next = ldm(max(gcur + dir, 0));
 
@@ -219,7 +228,15 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
             dmax = max2(dmax, fabsf(c.z - o.z));
             dmax = max2(dmax, fabsf(c.w - o.w));
         }
-        changed |= (f2u(o.x) != f2u(c.x)) | (f2u(o.y) != f2u(c.y)) | (f2u(o.z) != f2u(c.z)) | (f2u(o.w) != f2u(c.w));
+        if (TRACK) {
+            const bool cx = f2u(o.x) != f2u(c.x), cw = f2u(o.w) != f2u(c.w);
+            const bool rc = cx | cw | (f2u(o.y) != f2u(c.y)) | (f2u(o.z) != f2u(c.z));
+            chg_any |= rc;
+            chg_x |= cx;
+            chg_w |= cw;
+            if (r == r0) chg_top = rc;      // scalar conditions
+            if (r == r1 - 1) chg_bot = rc;
+        }
         float *orow = a.out + (size_t)r * pitch;
         if (a.flags & 2) __builtin_nontemporal_store(vf4{o.x, o.y, o.z, o.w}, reinterpret_cast<vf4 *>(orow + col));
         else *reinterpret_cast<float4 *>(orow + col) = o;
@@ -249,9 +266,11 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
         dmax = wave_max(dmax);
         if (lane == 0 && dmax > 0.0f) atomicMax(a.delta_bits, __float_as_uint(dmax));
     }
-    if (a.act_out) {
-        const bool any = __ballot(changed) != 0;
-        if (lane == 0) a.act_out[task] = any ? 1 : 0;
+    if (TRACK) {
+        const unsigned flags = (__ballot(chg_any) != 0 ? 1u : 0u) | ((__ballot(chg_x) & 1ull) ? 2u : 0u) |
+                               ((__ballot(chg_w) >> 63) ? 4u : 0u) | (__ballot(chg_top) != 0 ? 8u : 0u) |
+                               (__ballot(chg_bot) != 0 ? 16u : 0u);
+        if (lane == 0) a.act_out[task] = (uint8_t)flags;
     }
 }
 
@@ -465,14 +484,20 @@ int sweep_flags()
     return flags;
 }
 
-template <bool CHECK, bool RB>
+template <bool CHECK, bool RB, bool TRACK>
 void launch_sweep_2d_math(int math, int nblocks, hipStream_t stream, const Sweep2dArgs &a)
 {
     const dim3 grid(nblocks), block(kWave * kWavesPerBlock);
-    if (math == kMathFast) hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathFast, RB>), grid, block, 0, stream, a);
-    else if (math == kMathTraffic) hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathTraffic, RB>), grid, block, 0, stream, a);
-    else if (math == kMathDf32) hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathDf32, RB>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathPrecise, RB>), grid, block, 0, stream, a);
+    if (math == kMathFast) hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathFast, RB, TRACK>), grid, block, 0, stream, a);
+    else if (math == kMathTraffic) hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathTraffic, RB, TRACK>), grid, block, 0, stream, a);
+    else if (math == kMathDf32) hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathDf32, RB, TRACK>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathPrecise, RB, TRACK>), grid, block, 0, stream, a);
+}
+template <bool CHECK, bool RB>
+void launch_sweep_2d_track(int math, int nblocks, hipStream_t stream, const Sweep2dArgs &a)
+{
+    if (a.act_out) launch_sweep_2d_math<CHECK, RB, true>(math, nblocks, stream, a);
+    else launch_sweep_2d_math<CHECK, RB, false>(math, nblocks, stream, a);
 }
 }  // namespace
 
@@ -517,11 +542,11 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, i
     }
     const int nblocks = (a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock;
     if (parity < 0) {
-        if (delta_bits) launch_sweep_2d_math<true, false>(math, nblocks, stream, a);
-        else launch_sweep_2d_math<false, false>(math, nblocks, stream, a);
+        if (delta_bits) launch_sweep_2d_track<true, false>(math, nblocks, stream, a);
+        else launch_sweep_2d_track<false, false>(math, nblocks, stream, a);
     } else {
-        if (delta_bits) launch_sweep_2d_math<true, true>(math, nblocks, stream, a);
-        else launch_sweep_2d_math<false, true>(math, nblocks, stream, a);
+        if (delta_bits) launch_sweep_2d_track<true, true>(math, nblocks, stream, a);
+        else launch_sweep_2d_track<false, true>(math, nblocks, stream, a);
     }
     return hipGetLastError();
 }

@@ -130,6 +130,7 @@ _SIGNATURES = {
     "epic_hip_compute_path_2d_gpu": (_H, ct.c_float, ct.c_float, ct.c_float, ct.c_float, ct.c_uint, _UP,
                                      ct.POINTER(ct.POINTER(ct.c_float))),
     "epic_hip_activity_stats": (_H, ct.POINTER(ct.c_ulonglong), ct.POINTER(ct.c_ulonglong)),
+    "epic_hip_activity_stats2": (_H, ct.POINTER(ct.c_ulonglong), ct.POINTER(ct.c_ulonglong), ct.POINTER(ct.c_ulonglong)),
     "epic_hip_eval_math": (ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_int, ct.c_void_p),
     "epic_hip_get_layout": (_H, _UP, ct.POINTER(ct.c_size_t), ct.POINTER(ct.c_size_t)),
     "epic_hip_pack_mask_2d": (ct.c_void_p, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_int, ct.c_int, ct.c_void_p,

@@ -85,6 +85,10 @@ int epic_hip_compute_path_2d_gpu(EpicHarmonicT *harmonic, float x, float y, floa
 /* Diagnostic: the number of tiles whose values changed in the latest iteration and the number of tiles (both 0 when
  * tracking is off or the grid is 3-D).  Synchronises the stream and copies the flag bytes to the host. */
 int epic_hip_activity_stats(EpicHarmonicT *harmonic, unsigned long long *active_tiles, unsigned long long *tiles);
+/* The same, plus the number of tiles the NEXT iteration will recompute (the changed tiles and the neighbours that saw a
+ * change along the shared edge); due_tiles may be NULL. */
+int epic_hip_activity_stats2(EpicHarmonicT *harmonic, unsigned long long *active_tiles, unsigned long long *due_tiles,
+                             unsigned long long *tiles);
 
 /* Test hook: d_out[i] = which ? ln(d_in[i]) : exp(d_in[i]) with the precise device routines. */
 int epic_hip_eval_math(const float *d_in, float *d_out, size_t n, int which, void *stream);
