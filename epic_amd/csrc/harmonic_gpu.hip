@@ -50,12 +50,22 @@ struct Ctx {
     // Launch-bound grids replay the plain sweeps between two checks from a captured hipGraph; key = (count, starting
     // buffer, starting parity, math, scheme, rows_per_task) -- everything a captured launch sequence depends on.
     std::map<std::tuple<unsigned, int, int, int, int, int>, hipGraphExec_t> graphs;
-    // Activity tracking (2-D): per-tile "changed in the previous iteration" flags, ping-pong; tiles whose inputs did not
-    // change are skipped (bit-identical results, see kernels_2d.hip).  force > 0: the next `force` iterations run every tile.
-    bool track = true;             // EPIC_HIP_TRACK=0 / epic_hip_set_activity_tracking(h, 0) turns it off
-    uint8_t *act[2] = {nullptr, nullptr};
-    int act_cur = 0, act_rpt = 0, force = 2;
+    // Activity tracking (2-D): every iteration lists the tiles its successor has to recompute; tiles whose inputs did
+    // not change are never touched (bit-identical results, see kernels_2d.hip).  One device block `wake` holds 3 counter
+    // sets (L words each, L = kWakeListCount), the queued marks of both directions (act_tiles words each) and both
+    // directions' L lists (ceil(act_tiles / L) words each); `phase` (mod 6) says which direction (phase & 1) and which
+    // counter set (phase % 3) the next launch consumes.  force > 0: the next `force` iterations run every tile.
+    int track_mode = 2;            // 0 off, 1 on, 2 automatic (on for grids above 4 Mcell): EPIC_HIP_TRACK / epic_hip_set_activity_tracking
+    bool track = false;            // the mode resolved for the current dimensions (resolve_tracking)
+    uint32_t *wake = nullptr;
+    int phase = 0, act_rpt = 0, force = 2;
     size_t act_tiles = 0;
+    static constexpr size_t kL = epic_hip::kWakeListCount, kCS = epic_hip::kWakeCounterStride;
+    uint32_t *wake_counter(int set) const { return wake + kL * kCS * set; }
+    uint32_t *wake_queued(int i) const { return wake + 3 * kL * kCS + (size_t)i * act_tiles; }
+    uint32_t *wake_list(int i) const { return wake + 3 * kL * kCS + 2 * act_tiles + (size_t)i * kL * epic_hip::sweep_2d_list_cap(act_tiles); }
+    static size_t wake_words(size_t tiles) { return 3 * kL * kCS + 2 * tiles + 2 * kL * epic_hip::sweep_2d_list_cap(tiles); }
+    static size_t wake_zeroed_words(size_t tiles) { return 3 * kL * kCS + 2 * tiles; }  // counters and marks; lists need no init
     bool redblack = false;         // 2-D scheme: false = Jacobi ping-pong (default), true = in-place red-black (EPIC_HIP_SCHEME)
     size_t u_bytes() const { return (size_t)rows * pitch * sizeof(float); }
     size_t mask_bytes() const
@@ -67,6 +77,7 @@ struct Ctx {
 std::mutex g_mu;
 std::unordered_map<Harmonic *, Ctx *> g_ctx;
 
+void resolve_tracking(Ctx *c);
 void drop_graphs(Ctx *c);  // captured launch sequences hold the buffer addresses: drop them whenever a buffer goes away
 
 void report(const char *fn, const char *msg) { fprintf(stderr, "Error[%s]: %s\n", fn, msg); }
@@ -90,6 +101,7 @@ bool dims_from(const Harmonic *h, Ctx *c)
     if (rows > 0x7fffffffLL) return false;
     c->rows = (int)rows;
     c->pitch = epic_hip::pitch_for_cols(c->cols);
+    resolve_tracking(c);
     return true;
 }
 
@@ -142,7 +154,7 @@ Ctx *get_ctx(Harmonic *h, bool create)
     e = getenv("EPIC_HIP_SCHEME");
     if (e && strcmp(e, "redblack") == 0) c->redblack = true;
     e = getenv("EPIC_HIP_TRACK");
-    if (e && strcmp(e, "0") == 0) c->track = false;
+    if (e && (strcmp(e, "0") == 0 || strcmp(e, "1") == 0)) c->track_mode = atoi(e);
     g_ctx[h] = c;
     return c;
 }
@@ -155,11 +167,19 @@ void drop_ctx_if_empty(Harmonic *h)
     Ctx *c = it->second;
     if (c->buf[0] || c->maskw || c->d_m || c->d_delta) return;
     drop_graphs(c);
-    for (uint8_t *&p : c->act) { if (p) (void)hipFree(p); p = nullptr; }
+    if (c->wake) (void)hipFree(c->wake);
+    c->wake = nullptr;
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->h_delta) (void)hipHostFree(c->h_delta);
     delete c;
     g_ctx.erase(it);
+}
+
+// Tracking pays where a sweep is long enough to hide the list handling: grids above 4 Mcell.  The ROS maps (0.1-1 Mcell)
+// are launch-bound either way (3.2-4 us per sweep without, 5-6.7 us with lists, measured), so "automatic" leaves them alone.
+void resolve_tracking(Ctx *c)
+{
+    c->track = c->n == 2 && (c->track_mode == 1 || (c->track_mode == 2 && (long long)c->rows * c->pitch > (1ll << 22)));
 }
 
 int auto_rows_per_task(const Ctx *c)
@@ -197,33 +217,42 @@ hipError_t enqueue_sweep(Ctx *c, bool check, unsigned iteration)
     }
     const float *in = c->buf[c->cur];
     float *out = c->buf[c->cur ^ 1];
-    // activity flags for this iteration (2-D only); (re)allocated when the tiling changes
-    epic_hip::Activity act = {nullptr, nullptr, 1};
+    // wake lists of this iteration (2-D only); (re)allocated when the tiling changes
+    epic_hip::Activity act = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (c->n == 2 && c->track) {
         const int rpt = auto_rows_per_task(c);
         const size_t tiles = epic_hip::sweep_2d_tiles(c->rows, c->pitch, rpt);
         if (tiles != c->act_tiles || rpt != c->act_rpt) {
-            drop_graphs(c);  // captured sequences hold the old flag buffers (never reached during a capture: force > 0)
-            for (uint8_t *&p : c->act) { if (p) (void)hipFree(p); p = nullptr; }
+            drop_graphs(c);  // captured sequences hold the old lists (never reached during a capture: force > 0)
+            if (c->wake) (void)hipFree(c->wake);
+            c->wake = nullptr;
             c->act_tiles = 0;
-            if (hipMalloc((void **)&c->act[0], tiles) == hipSuccess && hipMalloc((void **)&c->act[1], tiles) == hipSuccess) {
+            if (hipMalloc((void **)&c->wake, Ctx::wake_words(tiles) * sizeof(uint32_t)) == hipSuccess &&
+                hipMemsetAsync(c->wake, 0, Ctx::wake_zeroed_words(tiles) * sizeof(uint32_t), c->stream) == hipSuccess) {
                 c->act_tiles = tiles;
                 c->act_rpt = rpt;
+                c->phase = 0;
                 c->force = 2;
             } else {
                 (void)hipGetLastError();
-                for (uint8_t *&p : c->act) { if (p) (void)hipFree(p); p = nullptr; }
+                if (c->wake) (void)hipFree(c->wake);
+                c->wake = nullptr;
             }
         }
         if (c->act_tiles) {
-            act.in = c->act[c->act_cur];
-            act.out = c->act[c->act_cur ^ 1];
-            act.force = c->force;
+            const int li = c->phase & 1, ci = c->phase % 3;
+            act.list_in = c->force > 0 ? nullptr : c->wake_list(li);
+            act.count_in = c->wake_counter(ci);
+            act.list_out = c->wake_list(li ^ 1);
+            act.count_out = c->wake_counter((ci + 1) % 3);
+            act.count_zero = c->wake_counter((ci + 2) % 3);
+            act.queued_in = c->wake_queued(li);
+            act.queued_out = c->wake_queued(li ^ 1);
         }
     }
     auto advance = [&](hipError_t e) {
-        if (e == hipSuccess && act.out) {
-            c->act_cur ^= 1;
+        if (e == hipSuccess && act.list_out) {
+            c->phase = (c->phase + 1) % 6;
             if (c->force > 0) c->force--;
         }
         return e;
@@ -292,17 +321,13 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
     const bool small = (long long)c->rows * c->pitch <= (1ll << 22);
     static const bool no_graph = getenv("EPIC_HIP_NO_GRAPH") != nullptr;
     // a captured sequence bakes in the flag buffers and force = 0: run eagerly until the forced iterations are over
-    // Large grids are replayed from a graph only with activity tracking: a sweep that skips most of its tiles is as
-    // launch-bound as a small grid (8192^2 at < 1 % activity: 23 us per eager launch, measured).
-    static const bool graph_tracked = getenv("EPIC_HIP_GRAPH_TRACKED") == nullptr || atoi(getenv("EPIC_HIP_GRAPH_TRACKED")) != 0;
-    const bool graphable = small || (graph_tracked && c->track && c->n == 2);
-    if (!graphable || count < 8 || no_graph || (c->track && c->n == 2 && (c->force > 0 || c->act_tiles == 0)))
+    if (!small || count < 8 || no_graph || (c->track && c->n == 2 && (c->force > 0 || c->act_tiles == 0)))
         return enqueue_plain_run(c, count, first);
-    const auto key = std::make_tuple(count, c->cur + 2 * c->act_cur + (c->track ? 4 : 0), (int)(first & 1u), c->math,
+    const auto key = std::make_tuple(count, c->cur + 2 * (c->track ? 1 + c->phase : 0), (int)(first & 1u), c->math,
                                      (int)c->redblack, auto_rows_per_task(c));
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
-        const int cur0 = c->cur, act0 = c->act_cur;
+        const int cur0 = c->cur, phase0 = c->phase;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
@@ -310,7 +335,7 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
         for (unsigned i = 0; i < count && e == hipSuccess; i++) e = enqueue_sweep(c, false, first + i);
         hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
         c->cur = cur0;  // nothing has run yet
-        c->act_cur = act0;
+        c->phase = phase0;
         if (e == hipSuccess) e = e2;
         if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         if (graph) (void)hipGraphDestroy(graph);
@@ -320,7 +345,7 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
     }
     hipError_t e = hipGraphLaunch(it->second, c->stream);
     if (e == hipSuccess && !c->redblack && (count & 1u)) c->cur ^= 1;
-    if (e == hipSuccess && c->track && c->n == 2 && (count & 1u)) c->act_cur ^= 1;
+    if (e == hipSuccess && c->track && c->n == 2) c->phase = (int)((c->phase + count) % 6);
     return e;
 }
 
@@ -930,8 +955,9 @@ int epic_hip_set_scheme(Harmonic *harmonic, int scheme)
 int epic_hip_set_activity_tracking(Harmonic *harmonic, int on)
 {
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
-    if (!c || (on != 0 && on != 1)) return EPIC_ERROR_INVALID_DATA;
-    c->track = on == 1;
+    if (!c || on < 0 || on > 2) return EPIC_ERROR_INVALID_DATA;
+    c->track_mode = on;
+    resolve_tracking(c);
     c->force = 2;
     return EPIC_SUCCESS;
 }
@@ -1030,22 +1056,16 @@ int epic_hip_activity_stats2(Harmonic *harmonic, unsigned long long *active_tile
     *active_tiles = *tiles = 0;
     if (due_tiles) *due_tiles = 0;
     if (!c->track || c->n != 2 || c->act_tiles == 0) return EPIC_SUCCESS;
-    std::vector<uint8_t> flags(c->act_tiles);
+    // the counter set the next launch will consume was filled by the latest one: the tiles it woke
+    std::vector<uint32_t> counts(Ctx::kL * Ctx::kCS);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return EPIC_ERROR_DEVICE_SYNCHRONIZE;
-    if (hipMemcpy(flags.data(), c->act[c->act_cur], c->act_tiles, hipMemcpyDeviceToHost) != hipSuccess)
+    if (hipMemcpy(counts.data(), c->wake_counter(c->phase % 3), counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
         return EPIC_ERROR_MEMCPY_TO_HOST;
-    const long long ns = (c->pitch + 255) / 256, nc = (long long)(c->act_tiles / ns);
-    unsigned long long n = 0, due = 0;
-    for (long long ch = 0; ch < nc; ch++)
-        for (long long st = 0; st < ns; st++) {
-            const long long t = ch * ns + st;
-            n += flags[t] != 0;
-            // the rule of the kernel's skip test (kernels_2d.hip)
-            due += (flags[t] & 1) || (st > 0 && (flags[t - 1] & 4)) || (st + 1 < ns && (flags[t + 1] & 2)) ||
-                   (ch > 0 && (flags[t - ns] & 16)) || (ch + 1 < nc && (flags[t + ns] & 8));
-        }
-    *active_tiles = c->force > 0 ? c->act_tiles : n;
-    if (due_tiles) *due_tiles = c->force > 0 ? c->act_tiles : due;
+    unsigned long long pair[2] = {0, 0};
+    for (size_t i = 0; i < Ctx::kL; i++) pair[0] += counts[i * Ctx::kCS];
+    pair[1] = pair[0];
+    *active_tiles = c->force > 0 ? c->act_tiles : pair[1];
+    if (due_tiles) *due_tiles = c->force > 0 ? c->act_tiles : pair[0];
     *tiles = c->act_tiles;
     return EPIC_SUCCESS;
 }

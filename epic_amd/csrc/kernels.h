@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace epic_hip {
 
@@ -10,16 +11,35 @@ namespace epic_hip {
 // One Jacobi sweep of rows [row_begin, row_end) of a pitched rows x pitch grid.  delta_bits == nullptr
 // selects the plain kernel; otherwise max |du| is atomicMax'ed into *delta_bits (float bits, zero it first).
 // math: 0 = precise (libm-equivalent exp/log in f64, the default), 1 = fast (v_exp_f32 / v_log_f32).
-// Activity tracking of full-grid launches (kernels_2d.hip, Sweep2dArgs): one byte per (strip, chunk) task tile,
-// tiles = sweep_2d_tiles(rows, pitch, rows_per_task).
+// Activity tracking of full-grid launches (kernels_2d.hip, Sweep2dArgs): tiles = sweep_2d_tiles(rows, pitch,
+// rows_per_task).  Per direction kWakeListCount lists of sweep_2d_list_cap(tiles) uint32 each and one uint32 of queued
+// mark per tile; counter sets of kWakeListCount uint32.
+constexpr int kWakeListCount = 256;
+constexpr int kWakeCounterStride = 32;  // uint32 words between two list counters (a 128-byte line each)
 struct Activity {
-    const uint8_t *in;   // flags written by the previous iteration
-    uint8_t *out;        // flags this iteration writes
-    int force;           // != 0: run every tile (first two iterations after any edit of u / mask / mode)
+    const uint32_t *list_in;   // nullptr: every tile runs (forced iteration)
+    const uint32_t *count_in;
+    uint32_t *list_out;
+    uint32_t *count_out;
+    uint32_t *count_zero;
+    uint32_t *queued_in;
+    uint32_t *queued_out;
 };
 inline size_t sweep_2d_tiles(int rows, int pitch, int rows_per_task)
 {
     return (size_t)((pitch + 255) / 256) * (size_t)((rows + rows_per_task - 1) / rows_per_task);
+}
+inline size_t sweep_2d_list_cap(size_t tiles) { return (tiles + kWakeListCount - 1) / kWakeListCount; }
+// blocks of a list-driven launch: enough waves to fill the chip (8192), or one per tile on small grids; a multiple of
+// the 8 XCDs
+inline int sweep_2d_list_blocks(size_t tiles)
+{
+    static const size_t waves = [] {
+        const char *e = getenv("EPIC_HIP_LIST_WAVES");
+        const long v = e ? atol(e) : 0;
+        return (size_t)(v >= 4 ? v : 8192);
+    }();
+    return (int)(((tiles < waves ? tiles : waves) + 31) / 32) * 8;
 }
 // parity < 0: Jacobi (in != out); parity 0 / 1: red-black half-sweep of that colour, in place (in == out).
 hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int row_begin,

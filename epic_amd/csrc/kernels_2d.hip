@@ -35,6 +35,8 @@ constexpr int kColsPerLane = 4;
 constexpr int kStripCols = kWave * kColsPerLane;  // 256
 constexpr int kWavesPerBlock = 4;
 constexpr int kNumXcd = 8;
+constexpr int kWakeLists = kWave * kWavesPerBlock;  // 256 work lists per tracked launch (see Sweep2dArgs)
+constexpr int kCounterStride = kWakeCounterStride;  // words between two list counters: one 128-byte line each
 
 struct Sweep2dArgs {
     const float *in;
@@ -49,19 +51,34 @@ struct Sweep2dArgs {
     int ntasks;             // nstrips * nchunks
     int parity;             // red-black scheme only: currentIteration & 1 (which colour this half-sweep updates)
     int flags;              // tuning, never results: bit 0 = odd row-chunks march upwards, bit 1 = non-temporal stores
-    // Activity tracking (full-grid launches only; act_out == nullptr turns it off).  One byte per task tile, written by
-    // the previous iteration: bit 0 "some cell of the tile changed", bits 1 / 2 "a cell of its first / last column
-    // changed", bits 3 / 4 "a cell of its first / last row changed".  A tile is recomputed when its own bit 0 is set or a
-    // neighbour changed along the shared edge (left neighbour's last column, right neighbour's first column, upper
-    // neighbour's last row, lower neighbour's first row): those are all the values a 5-point update of the tile reads.
-    // Otherwise the tile has bit-for-bit the inputs it had last time, so its update is a no-op and the wave leaves at
-    // once (Jacobi: the output buffer already holds these values from two sweeps ago, because the tile itself did not
-    // change either).  `force` != 0 makes every tile run (first two iterations after any edit).
-    const uint8_t *act_in;
-    uint8_t *act_out;
+    // Activity tracking (full-grid launches only; TRACK kernels).  A tile (= task: rows_per_task x 256 cells) has to be
+    // recomputed in iteration k + 1 only if iteration k changed one of the values it reads: one of its own cells, the
+    // last column of its left neighbour, the first column of its right neighbour, the last row of its upper neighbour
+    // or the first row of its lower neighbour (5-point stencil).  Otherwise its update would reproduce, bit for bit,
+    // the values already in place (Jacobi: in BOTH ping-pong buffers, because the tile itself did not change either).
+    // So every task that changed something WAKES the tiles that read it -- itself, and the neighbours across the edges
+    // it changed -- by appending them to the work lists of the next iteration (`queued` marks keep a tile from being
+    // listed twice).  Iteration k + 1 is then a fixed-size launch of persistent waves that walk those lists: no wave is
+    // spent on a tile that has nothing to do, and the listed tiles spread evenly over the chip however they cluster in
+    // space.  A single list with a single counter serialises on that counter (7 ns per atomicAdd: 460 us per 8192^2
+    // sweep, measured), so there are kWakeLists = 256 of them, each counter in a cache line of its own: tile t is always
+    // listed in list t / list_cap (list_cap = ceil(tiles / 256) consecutive tiles, a band of a few chunk-rows), so a list
+    // can never overflow and its tiles are neighbours in memory.  The consumer side sees the 256 lists as one sequence
+    // (entries of list 0, then list 1, ...): wave w takes elements w, w + W, w + 2 W ... of it (W = waves in the
+    // launch) after a prefix sum over the 256 counters -- perfectly even, whatever the lists hold, and waves that run
+    // side by side work on the same band, sharing its halo rows in L2.
+    // list_in == nullptr: every tile runs (the first two iterations after any edit of u, mask or mode) and the launch
+    // covers the grid like an untracked one, still waking tiles for its successor.  Three counter sets rotate: a launch
+    // reads count_in, fills count_out and resets count_zero, which the launch after next will fill.
+    const uint32_t *list_in;    // kWakeLists x list_cap tile ids; list i holds count_in[i] of them
+    const uint32_t *count_in;
+    uint32_t *list_out;         // tiles woken for the next launch
+    uint32_t *count_out;
+    uint32_t *count_zero;
+    uint32_t *queued_in;        // marks of the tiles listed for this launch: cleared as they are taken
+    uint32_t *queued_out;       // 1 = already in list_out
+    int list_cap;
     int nchunks;
-    int force;
-    int band;               // blocks per XCD band (0 = one contiguous range per XCD)
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (b % 8 labels the XCD group).  Give each group a
@@ -71,18 +88,6 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nblk)
     int x = b % kNumXcd, i = b / kNumXcd;
     int q = nblk / kNumXcd, rem = nblk % kNumXcd;
     return x * q + (x < rem ? x : rem) + i;
-}
-
-// The same, in bands of `k` blocks: XCD x takes bands x, x + 8, x + 16, ... of the logical block range.  Within a band
-// neighbouring tasks still share an L2, and the work of a sweep whose active tiles cluster (activity tracking: the
-// converged region around a goal is skipped) stays spread over all eight XCDs instead of idling the ones that own it.
-__device__ __forceinline__ int xcd_banded_block(int b, int nblk, int k)
-{
-    if (k <= 0) return xcd_contiguous_block(b, nblk);
-    const int full = nblk / (kNumXcd * k) * (kNumXcd * k);  // multiple of 8: blocks past it keep their XCD label
-    if (b >= full) return full + xcd_contiguous_block(b - full, nblk - full);
-    const int x = b % kNumXcd, i = b / kNumXcd;
-    return ((i / k) * kNumXcd + x) * k + i % k;
 }
 
 // RB = false: Jacobi, in -> out.  RB = true: the reference's red-black half-sweep, IN PLACE (in == out): only the
@@ -102,26 +107,54 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
     const int lane = threadIdx.x & (kWave - 1);
     // wave-uniform quantities are forced into SGPRs: the row loop, its addresses and branches are scalar
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int task = xcd_banded_block(blockIdx.x, gridDim.x, a.band) * kWavesPerBlock + wave;
-    if (task >= a.ntasks) return;
-    if (TRACK && a.force == 0) {
-        // own flag and the four edge neighbours' flags, one lane each: a single round trip to memory
-        const int st = task % a.nstrips, ch = task / a.nstrips;
-        int t = task;
-        unsigned bit = 1u;          // own tile: anything changed
-        bool valid = lane == 0;
-        if (lane == 1) { t = task - 1; bit = 4u; valid = st > 0; }                      // left neighbour's last column
-        if (lane == 2) { t = task + 1; bit = 2u; valid = st + 1 < a.nstrips; }          // right neighbour's first column
-        if (lane == 3) { t = task - a.nstrips; bit = 16u; valid = ch > 0; }             // upper neighbour's last row
-        if (lane == 4) { t = task + a.nstrips; bit = 8u; valid = ch + 1 < a.nchunks; }  // lower neighbour's first row
-        const bool hit = lane < 5 && valid && (a.act_in[t] & bit) != 0;
-        if (__ballot(hit) == 0) {  // nothing this tile reads has changed: its values stand
-            if (lane == 0) a.act_out[task] = 0;
-            return;
+    if (TRACK && blockIdx.x == 0) a.count_zero[threadIdx.x * kCounterStride] = 0;  // kWakeLists == block size
+    // list-driven launch: the 256 lists form one sequence, cut into eight equal segments, one per XCD (blocks are dealt
+    // round-robin over the XCDs, blockIdx % 8 labels them; the launcher makes gridDim a multiple of 8): the waves of an
+    // XCD take the elements of its segment in turn, so tiles of one band meet in one L2
+    const bool listed = TRACK && a.list_in != nullptr;
+    const int xcd = blockIdx.x % kNumXcd;
+    const int nwaves = (gridDim.x / kNumXcd) * kWavesPerBlock;          // per XCD
+    int g = (blockIdx.x / kNumXcd) * kWavesPerBlock + wave;             // index into the sequence, set below
+    int total = 0;                                                       // end of this XCD's segment
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, incl = 0;  // lane l: counters 4 l .. 4 l + 3 and their inclusive prefix sum
+    if (listed) {
+        const uint32_t *mine = a.count_in + (size_t)(4 * lane) * kCounterStride;
+        c0 = mine[0]; c1 = mine[kCounterStride]; c2 = mine[2 * kCounterStride]; c3 = mine[3 * kCounterStride];
+        incl = c0 + c1 + c2 + c3;
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d, kWave);
+            if (lane >= d) incl += up;
         }
+        const long long all = __builtin_amdgcn_readlane((int)incl, kWave - 1);
+        g += (int)(all * xcd / kNumXcd);
+        total = (int)(all * (xcd + 1) / kNumXcd);
+        if (g >= total) return;
     }
     MathTab lds = {};  // libm tables, one entry per lane (precise math only)
     if (MATH == kMathPrecise) lds = math_tables_load();
+    float dmax = 0.0f;
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    const int rlast = a.rows - 1;
+    const size_t pitch = (size_t)a.pitch;
+    const int qpitch = a.pitch >> 2;  // mask words per 8-row group
+    const int glast = rlast >> 3;
+
+    for (;;) {  // one pass per task: exactly one unless the launch is list-driven
+    int task;
+    if (listed) {
+        // element g of the sequence: the first lane whose inclusive prefix exceeds g holds its list among its four
+        const int L = __popcll(__ballot(incl <= (uint32_t)g));
+        const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)c0, L), l1 = (uint32_t)__builtin_amdgcn_readlane((int)c1, L);
+        const uint32_t l2 = (uint32_t)__builtin_amdgcn_readlane((int)c2, L), l3 = (uint32_t)__builtin_amdgcn_readlane((int)c3, L);
+        uint32_t r = (uint32_t)g - ((uint32_t)__builtin_amdgcn_readlane((int)incl, L) - (l0 + l1 + l2 + l3));
+        int list = 4 * L;
+        if (r >= l0) { r -= l0; list++; if (r >= l1) { r -= l1; list++; if (r >= l2) { r -= l2; list++; } } }
+        task = __builtin_amdgcn_readfirstlane((int)a.list_in[(size_t)list * a.list_cap + r]);
+    } else {
+        task = xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
+    }
+    if (task >= a.ntasks) break;
+    if (TRACK && lane == 0) a.queued_in[task] = 0;
     const int strip = task % a.nstrips;
     const int chunk = task / a.nstrips;
     const int r0 = a.row_begin + chunk * a.rows_per_task;
@@ -132,10 +165,6 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
     const int lcol = col;  // pitch % 256 == 0: every lane of every strip is in bounds (DPP / bpermute want all lanes live)
     const int hcol = (lane == 0) ? max(col0 - 1, 0) : min(col0 + kStripCols, a.pitch - 1);
     const bool edge_lane = (lane == 0) | (lane == kWave - 1);
-    const int rlast = a.rows - 1;
-    const size_t pitch = (size_t)a.pitch;
-    const int qpitch = a.pitch >> 2;  // mask words per 8-row group
-    const int glast = rlast >> 3;
 
     auto ld = [&](int r) -> float4 {
         r = min(max(r, 0), rlast);
@@ -161,9 +190,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
     const int dir = ((a.flags & 1) && (chunk & 1)) ? -1 : 1;
     const int rfirst = dir > 0 ? r0 : r1 - 1;
     const int nrows = r1 - r0;
-    typedef float vf4 __attribute__((ext_vector_type(4)));
 
-    float dmax = 0.0f;
     // activity tracking: cells of this lane rewritten with different bits -- anywhere, in its first / last column
     // (meaningful in lane 0 / lane 63), in the task's first / last row
     bool chg_any = false, chg_x = false, chg_w = false, chg_top = false, chg_bot = false;
@@ -262,15 +289,32 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
         row_step(row_at(i + 3), q3, q0, q1, h0);
     }
 
+    if (TRACK) {
+        // wake the tiles that read what this task changed: itself, and the neighbour across each edge that changed
+        const bool any = __ballot(chg_any) != 0;                       // (ballots first: all lanes take part)
+        const bool first_col = (__ballot(chg_x) & 1ull) != 0;         // lane 0 holds column 0 of the strip
+        const bool last_col = (__ballot(chg_w) >> 63) != 0;           // lane 63 holds column 255
+        const bool first_row = __ballot(chg_top) != 0, last_row = __ballot(chg_bot) != 0;
+        int t = task;
+        bool want = any;                                                                     // lane 0: the tile itself
+        if (lane == 1) { t = task - 1; want = strip > 0 && first_col; }                      // its left neighbour
+        if (lane == 2) { t = task + 1; want = strip + 1 < a.nstrips && last_col; }           // its right neighbour
+        if (lane == 3) { t = task - a.nstrips; want = chunk > 0 && first_row; }              // the tile above
+        if (lane == 4) { t = task + a.nstrips; want = chunk + 1 < a.nchunks && last_row; }   // the tile below
+        want = want && lane < 5;
+        if (want && atomicExch(&a.queued_out[t], 1u) == 0u) {  // first to wake tile t: append it to its list
+            const unsigned li = (unsigned)t / (unsigned)a.list_cap;
+            a.list_out[(size_t)li * a.list_cap + atomicAdd(&a.count_out[(size_t)li * kCounterStride], 1u)] = (uint32_t)t;
+        }
+    }
+    if (!listed) break;
+    g += nwaves;
+    if (g >= total) break;
+    }  // task loop
+
     if (CHECK) {
         dmax = wave_max(dmax);
         if (lane == 0 && dmax > 0.0f) atomicMax(a.delta_bits, __float_as_uint(dmax));
-    }
-    if (TRACK) {
-        const unsigned flags = (__ballot(chg_any) != 0 ? 1u : 0u) | ((__ballot(chg_x) & 1ull) ? 2u : 0u) |
-                               ((__ballot(chg_w) >> 63) ? 4u : 0u) | (__ballot(chg_top) != 0 ? 8u : 0u) |
-                               (__ballot(chg_bot) != 0 ? 16u : 0u);
-        if (lane == 0) a.act_out[task] = (uint8_t)flags;
     }
 }
 
@@ -496,7 +540,7 @@ void launch_sweep_2d_math(int math, int nblocks, hipStream_t stream, const Sweep
 template <bool CHECK, bool RB>
 void launch_sweep_2d_track(int math, int nblocks, hipStream_t stream, const Sweep2dArgs &a)
 {
-    if (a.act_out) launch_sweep_2d_math<CHECK, RB, true>(math, nblocks, stream, a);
+    if (a.list_out) launch_sweep_2d_math<CHECK, RB, true>(math, nblocks, stream, a);
     else launch_sweep_2d_math<CHECK, RB, false>(math, nblocks, stream, a);
 }
 }  // namespace
@@ -525,22 +569,25 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, i
     a.ntasks = a.nstrips * nchunks;
     a.parity = parity < 0 ? 0 : (parity & 1);
     a.flags = sweep_flags();
-    a.act_in = nullptr;
-    a.act_out = nullptr;
+    a.list_in = nullptr;
+    a.count_in = nullptr;
+    a.list_out = nullptr;
+    a.count_out = a.count_zero = nullptr;
+    a.queued_in = a.queued_out = nullptr;
+    a.list_cap = 0;
     a.nchunks = nchunks;
-    a.force = 1;
-    a.band = 0;
-    if (act && act->out && row_begin == 0 && row_end == rows) {
-        a.act_in = act->in;
-        a.act_out = act->out;
-        a.force = act->force;
-        static const int band_chunks = [] {
-            const char *e = getenv("EPIC_HIP_BAND");
-            return e ? atoi(e) : 4;
-        }();
-        a.band = (band_chunks * a.nstrips + kWavesPerBlock - 1) / kWavesPerBlock;
+    int nblocks = (a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (act && act->list_out && row_begin == 0 && row_end == rows) {
+        a.list_in = act->list_in;
+        a.count_in = act->count_in;
+        a.list_out = act->list_out;
+        a.count_out = act->count_out;
+        a.count_zero = act->count_zero;
+        a.queued_in = act->queued_in;
+        a.queued_out = act->queued_out;
+        a.list_cap = (a.ntasks + kWakeLists - 1) / kWakeLists;
+        if (a.list_in) nblocks = sweep_2d_list_blocks((size_t)a.ntasks);  // persistent waves walking the lists
     }
-    const int nblocks = (a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock;
     if (parity < 0) {
         if (delta_bits) launch_sweep_2d_track<true, false>(math, nblocks, stream, a);
         else launch_sweep_2d_track<false, false>(math, nblocks, stream, a);
@@ -570,11 +617,13 @@ hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw
     a.ntasks = a.nstrips * ((rows + rows_per_task - 1) / rows_per_task);
     a.parity = parity & 1;
     a.flags = sweep_flags();
-    a.act_in = nullptr;
-    a.act_out = nullptr;
+    a.list_in = nullptr;
+    a.count_in = nullptr;
+    a.list_out = nullptr;
+    a.count_out = a.count_zero = nullptr;
+    a.queued_in = a.queued_out = nullptr;
+    a.list_cap = 0;
     a.nchunks = 0;
-    a.force = 1;
-    a.band = 0;
     const dim3 grid((a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
     if (math == kMathFast) hipLaunchKernelGGL((rb_fused2d_kernel<kMathFast>), grid, block, 0, stream, a);
     else if (math == kMathTraffic) hipLaunchKernelGGL((rb_fused2d_kernel<kMathTraffic>), grid, block, 0, stream, a);

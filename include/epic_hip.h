@@ -60,11 +60,13 @@ int epic_hip_set_math_mode(EpicHarmonicT *harmonic, int mode);
  * harmonic_complete_cpu.  Also EPIC_HIP_SCHEME=jacobi|redblack in the environment at initialisation. */
 int epic_hip_set_scheme(EpicHarmonicT *harmonic, int scheme);
 
-/* Activity tracking of the 2-D solver (on by default; EPIC_HIP_TRACK=0 in the environment at initialisation turns it
- * off).  Each sweep records, per tile of rows_per_task x 256 cells, whether any value changed; the next sweep skips a
- * tile when neither it nor its four edge neighbours changed -- the update would reproduce the values already held, so
- * fields, delta and iteration counts are bit-identical with tracking on or off.  Any upload, set_cells or mode change
- * forces the next two iterations to run every tile.  bench.py times the kernel with tracking off. */
+/* Activity tracking of the 2-D solver: 0 off, 1 on, 2 automatic (default: on for grids above 4 Mcell; also
+ * EPIC_HIP_TRACK=0|1 in the environment at initialisation).  A tile of rows_per_task x 256 cells is recomputed in an
+ * iteration only if the previous iteration changed a value it reads (one of its own cells or the adjacent row / column of
+ * an edge neighbour); otherwise the update would reproduce the values already held, so fields, delta and iteration counts
+ * are bit-identical with tracking on or off.  Every iteration builds the work lists of its successor, which then runs as
+ * a fixed-size launch of persistent waves over exactly those tiles.  Any upload, set_cells or mode change makes the next
+ * two iterations run every tile.  bench.py times the kernel with tracking off. */
 int epic_hip_set_activity_tracking(EpicHarmonicT *harmonic, int on);
 
 /* Streamline extraction on the device-resident field (the path step that follows the relaxation).
@@ -82,11 +84,11 @@ int epic_hip_compute_paths_2d_gpu(EpicHarmonicT *harmonic, unsigned int n_paths,
 int epic_hip_compute_path_2d_gpu(EpicHarmonicT *harmonic, float x, float y, float stepSize, float cdPrecision,
                                  unsigned int maxLength, unsigned int *k, float **path);
 
-/* Diagnostic: the number of tiles whose values changed in the latest iteration and the number of tiles (both 0 when
- * tracking is off or the grid is 3-D).  Synchronises the stream and copies the flag bytes to the host. */
+/* Diagnostic: the number of tiles the next iteration will recompute and the number of tiles (both 0 when tracking is
+ * off or the grid is 3-D).  Synchronises the stream and copies the list counters to the host. */
 int epic_hip_activity_stats(EpicHarmonicT *harmonic, unsigned long long *active_tiles, unsigned long long *tiles);
-/* The same, plus the number of tiles the NEXT iteration will recompute (the changed tiles and the neighbours that saw a
- * change along the shared edge); due_tiles may be NULL. */
+/* The same with both outputs of the earlier flag-based scheme (active_tiles and due_tiles now report the same number:
+ * the tiles listed for the next iteration); due_tiles may be NULL. */
 int epic_hip_activity_stats2(EpicHarmonicT *harmonic, unsigned long long *active_tiles, unsigned long long *due_tiles,
                              unsigned long long *tiles);
 

@@ -29,6 +29,16 @@ FIXED_TOL = 0.0   # precise math: bit-identical to the checker's Jacobi, sweep f
 CONVERGED_TOL = 1e-5
 
 
+@pytest.fixture(autouse=True, params=["tracking_auto", "tracking_on"])
+def tracking_mode(request):
+    """Every test of this file runs twice: with the library default (activity tracking only above 4 Mcell, so not on
+    these grids) and with EPIC_HIP_TRACK=1 (work lists on every 2-D grid).  Results must not depend on it."""
+    if request.param == "tracking_on":
+        os.environ["EPIC_HIP_TRACK"] = "1"
+    yield request.param
+    os.environ.pop("EPIC_HIP_TRACK", None)
+
+
 def make(m, u, locked, eps=1e-6, stagger=100):
     h = Harmonic()
     h.set_grid(m, u, locked)
@@ -600,6 +610,7 @@ def test_activity_tracking_survives_model_reupload_and_graph_replay():
     lib = O.oracle()
     h = make(m, u0, locked)
     gpu_init(h)
+    assert E.epic_hip_set_activity_tracking(h, 1) == 0   # (automatic mode leaves a grid this small untracked)
     for rounds in range(2):
         for n in (100, 33, 100, 8, 100):   # odd and even batch lengths, repeated so that graphs are replayed
             assert E.epic_hip_update_n_gpu(h, n, 1) in (0, 1)
