@@ -18,7 +18,12 @@
 //  * blockIdx is remapped so that each XCD sweeps a contiguous band of rows: vertically adjacent tasks share
 //    their two halo rows through that XCD's L2.
 //
-// Roofline: HBM.  ~45 VALU-slots per cell (4 v_exp_f32 + 1 v_log_f32 at quarter rate) keep it memory-bound.
+//  * Optional activity tracking: a sweep lists the tiles its successor has to recompute and the successor runs as
+//    persistent waves over those lists (Sweep2dArgs); results do not depend on it.
+//
+// Roofline: the memory side is HBM-bound (8 B per cell, 97 us per 8192^2 sweep with trivial arithmetic).  With the
+// fast math (v_exp_f32 / v_log_f32) the kernel stays there; with the default precise math (expf / logf bit-identical to
+// glibc, evaluated in f64) it is bound by VALU issue: 41 four-cycle instructions per cell.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -94,8 +99,8 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nblk)
 // cells with (row + col + currentIteration) odd are recomputed (harmonic_cpu.cpp:46-51), from neighbours that all have
 // the other colour and therefore do not change during this launch -- no ordering between waves is needed, and with
 // the precise math the result is the reference CPU solver's, bit for bit, half-sweep for half-sweep.
-// (88 VGPRs = 5 waves per SIMD with the precise math.  Asking the allocator for 6 or 7 waves -- amdgpu_waves_per_eu --
-// spills and is slower: 196 / 191 us against 188 us per 8192^2 sweep, profiles/r01_experiments.txt.)
+// (68 VGPRs = 7 waves per SIMD with the precise math, untracked.  Forcing more waves per SIMD with amdgpu_waves_per_eu
+// spills and is slower, profiles/r01_experiments.txt.)
 template <bool CHECK, int MATH, bool RB, bool TRACK>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2dArgs a)
 {
