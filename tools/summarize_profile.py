@@ -54,8 +54,31 @@ def pmc(fetch_dir, write_dir):
     return read_b + write_b
 
 
+def sq(d):
+    """Mean of every SQ_* counter per sweep dispatch, plus the ratios the design notes quote."""
+    rows = list(csv.DictReader(open(find(d, "*_counter_collection.csv"))))
+    rows = [r for r in rows if "sweep" in r["Kernel_Name"]]
+    names = sorted({r["Counter_Name"] for r in rows})
+    mean = {n: statistics.mean(float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == n) for n in names}
+    n_disp = len([r for r in rows if r["Counter_Name"] == names[0]]) if names else 0
+    print("# rocprofv3 --pmc SQ_* (%s), mean per sweep2d dispatch (%d dispatches)" % (d, n_disp))
+    for n in names:
+        print("%-24s %.4g" % (n, mean[n]))
+    cells = 8192 * 8192
+    if "SQ_INSTS_VALU" in mean:
+        print("VALU instructions per grid cell (wave instructions x 64 lanes / 4 cells per lane ... per cell): %.1f"
+              % (mean["SQ_INSTS_VALU"] * 64 / cells))
+    if "SQ_INSTS_LDS" in mean:
+        print("LDS (ds_bpermute) instructions per grid cell: %.1f" % (mean["SQ_INSTS_LDS"] * 64 / cells))
+    if "SQ_WAIT_INST_ANY" in mean and "SQ_WAVE_CYCLES" in mean:
+        print("issue-stall share of wave cycles (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES): %.3f"
+              % (mean["SQ_WAIT_INST_ANY"] / mean["SQ_WAVE_CYCLES"]))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) >= 3 and sys.argv[1] == "stats":
+    if len(sys.argv) >= 3 and sys.argv[1] == "sq":
+        sq(sys.argv[2])
+    elif len(sys.argv) >= 3 and sys.argv[1] == "stats":
         stats(sys.argv[2])
     elif len(sys.argv) >= 4 and sys.argv[1] == "pmc":
         pmc(sys.argv[2], sys.argv[3])
