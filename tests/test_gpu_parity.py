@@ -701,3 +701,39 @@ def test_device_streamline_batch_equals_host_walk(goldens, name):
         ok += 1
     assert ok > 50   # the batch really walked a good number of paths
     gpu_fini(h)
+
+
+# ---- seeded random shapes: ragged strips, one-row and one-column interiors, many goals, dense obstacles ---------------
+def test_random_shapes_both_schemes_equal_the_checker():
+    """40 random 2-D grids (3..150 rows, 3..900 columns: 1-4 strips, partial last strip, partial last 8-row mask group),
+    random obstacle density and goal count, random sweep counts and tilings; Jacobi and red-black against the checker."""
+    rng = np.random.default_rng(20240603)
+    lib = O.oracle()
+    for case in range(40):
+        rows, cols = int(rng.integers(3, 151)), int(rng.integers(3, 901))
+        m = [rows, cols]
+        u0, locked = synthetic_grid(m, int(rng.integers(1, 1 << 30)), float(rng.uniform(0.0, 0.3)))
+        free = np.flatnonzero(locked == 0)
+        if free.size:
+            for idx in rng.choice(free, size=min(free.size, int(rng.integers(0, 6))), replace=False):
+                u0[idx] = 0.0
+                locked[idx] = 1
+        k = int(rng.integers(1, 60))
+        rpt = int(rng.choice([0, 1, 2, 3, 5, 8, 16, 64]))
+        scheme = case % 2
+        h = make(m, u0, locked)
+        gpu_init(h)
+        assert E.epic_hip_set_scheme(h, scheme) == 0
+        if rpt:
+            assert E.epic_hip_set_rows_per_task(h, rpt) == 0
+        assert E.epic_hip_update_n_gpu(h, k, 1) in (0, 1)
+        assert E.harmonic_get_potential_values_gpu(h) == 0
+        gpu_fini(h)
+        p = O.Problem(m, u0, locked)
+        if scheme == 0:
+            assert lib.oracle_jacobi_run(ct.byref(p.h), k) == 0
+        else:
+            for i in range(k):
+                (lib.oracle_update_and_check if i == k - 1 else lib.oracle_update)(ct.byref(p.h))
+        assert np.array_equal(h.u_array().ravel(), p.u), f"case {case}: {m}, {k} iterations, scheme {scheme}, rpt {rpt}"
+        assert float(h.delta) == float(p.h.delta), f"case {case}: delta"

@@ -48,6 +48,7 @@ def main():
     if args.rows_per_task:
         E.epic_hip_set_rows_per_task(h, args.rows_per_task)
     ms = ct.c_float(0)
+    assert E.epic_hip_set_activity_tracking(h, 0) == 0   # timed sweeps recompute every cell; the relaxation below uses the default
     assert E.epic_hip_timed_sweeps_gpu(h, args.warmup, 0, ct.byref(ms)) == 0
     assert E.epic_hip_timed_sweeps_gpu(h, args.sweeps, 100, ct.byref(ms)) == 0
     us = ms.value * 1e3 / args.sweeps
@@ -56,6 +57,7 @@ def main():
                Mcell_updates_per_s=round(free / us, 1), algorithmic_GBps=round(8.0 * cells / us / 1e3, 1),
                frac_of_8TBps=round(8.0 * cells / us / 1e3 / 8000.0, 4), free_cells=free, cells=cells,
                generate_s=round(gen_s, 2), h2d_s=round(up_s, 3))
+    assert E.epic_hip_set_activity_tracking(h, 2) == 0
     if args.relax:
         assert E.harmonic_uninitialize_gpu(h) == 0
         h.u_array().ravel()[:] = u0
