@@ -279,6 +279,55 @@ def test_full_size_8192_window_property():
     assert abs(h.delta - p.h.delta) <= 1e-5 * max(1.0, p.h.delta)
 
 
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_full_size_8192_tracking_and_tiling_leave_no_trace(scheme, tracking_mode):
+    """BASELINE config 3 at full size, properties that need no reference run: the field after 700 iterations, a live-map
+    edit far from the front and 300 more iterations is the same array, bit for bit, (a) with work-list tracking and
+    with every tile recomputed every time, (b) with 8 and with 24 rows per task; the maximum principle holds (u <= 0,
+    goals stay 0, obstacles stay at the seed); and what the front has not reached has not moved."""
+    if tracking_mode == "tracking_on":
+        pytest.skip("the test sets the tracking mode itself")
+    n = 8192
+    u0, locked = synthetic_grid([n, n])
+    v = np.array([700, 900, 7000, 7100], dtype=np.uint32)            # (x, y) pairs: a new goal and a new obstacle
+    types = np.array([eh.EPIC_CELL_TYPE_GOAL, eh.EPIC_CELL_TYPE_OBSTACLE], dtype=np.uint32)
+    fields = []
+    for track, rpt in ((1, 0), (0, 0), (1, 24)):
+        h = make([n, n], u0, locked)
+        gpu_init(h)
+        assert E.epic_hip_set_scheme(h, scheme) == 0 and E.epic_hip_set_activity_tracking(h, track) == 0
+        if rpt:
+            assert E.epic_hip_set_rows_per_task(h, rpt) == 0
+        assert E.epic_hip_update_n_gpu(h, 700, 1) in (0, 1)
+        d1 = float(h.delta)
+        if track:
+            a, t = ct.c_ulonglong(0), ct.c_ulonglong(0)
+            assert E.epic_hip_activity_stats(h, ct.byref(a), ct.byref(t)) == 0
+            assert 0 < a.value < t.value // 4, (a.value, t.value)     # the front is ~700 cells out: most tiles sleep
+        assert E.harmonic_utilities_set_cells_2d_gpu(h, NT, 2, v.ctypes.data_as(eh._UP), types.ctypes.data_as(eh._UP)) == 0
+        assert E.epic_hip_update_n_gpu(h, 300, 1) in (0, 1)
+        assert E.harmonic_get_potential_values_gpu(h) == 0
+        fields.append((h.u_array().copy(), d1, float(h.delta)))
+        gpu_fini(h)
+    for other in fields[1:]:
+        assert np.array_equal(fields[0][0], other[0]) and fields[0][1:] == other[1:]
+    got = fields[0][0]
+    lk = locked.reshape(n, n).copy()
+    lk[900, 700] = lk[7100, 7000] = 1
+    assert got.max() == 0.0 and got[900, 700] == 0.0 and got[7100, 7000] == np.float32(-1e6)
+    goals = (u0.reshape(n, n) == 0.0)
+    assert np.all(got[goals] == 0.0)
+    obstacles = (locked.reshape(n, n) != 0) & ~goals
+    assert np.all(got[obstacles] == np.float32(-1e6))
+    c = n // 2
+    far = np.ones((n, n), dtype=bool)
+    far[c - 1001:c + 1002, c - 1001:c + 1002] = False               # the first goal's reach after 1000 iterations
+    far[900 - 301:900 + 302, 700 - 301:700 + 302] = False           # the new goal's reach after 300
+    assert np.all(got[far & (lk == 0)] == np.float32(-1e6))
+    moved = (got != np.float32(-1e6)) & (lk == 0)
+    assert moved[c - 900:c + 900, c].any() and moved[900 - 200:900 + 200, 700].any()
+
+
 def test_raw_operator_row_ranges_match_whole_sweep():
     """include/epic_hip.h: epic_hip_sweep_2d over [0, r) and [r, rows) == one launch over [0, rows) (slab mode)."""
     import torch
