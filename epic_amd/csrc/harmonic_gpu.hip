@@ -1115,4 +1115,19 @@ int epic_hip_sweep_2d(const float *d_in, float *d_out, const uint32_t *d_maskw, 
                : EPIC_ERROR_KERNEL_EXECUTION;
 }
 
+int epic_hip_sweep_rb_2d(float *d_u, const uint32_t *d_maskw, unsigned int rows, unsigned int pitch, unsigned int row_begin,
+                         unsigned int row_end, unsigned int rows_per_task, int math_mode, int parity,
+                         uint32_t *d_delta_bits, void *stream)
+{
+    if (!d_u || !d_maskw || rows < 3 || pitch % 256 != 0 || pitch == 0 || row_end > rows || row_begin > row_end ||
+        (parity != 0 && parity != 1))
+        return EPIC_ERROR_INVALID_DATA;
+    if (rows_per_task == 0) rows_per_task = 32;
+    if (math_mode < 0 || math_mode > 3) return EPIC_ERROR_INVALID_DATA;
+    return epic_hip::launch_sweep_2d(d_u, d_u, d_maskw, (int)rows, (int)pitch, (int)row_begin, (int)row_end,
+                                     (int)rows_per_task, math_mode, parity, d_delta_bits, (hipStream_t)stream) == hipSuccess
+               ? EPIC_SUCCESS
+               : EPIC_ERROR_KERNEL_EXECUTION;
+}
+
 }  // extern "C"

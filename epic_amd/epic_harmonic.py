@@ -137,6 +137,8 @@ _SIGNATURES = {
                               ct.c_void_p),
     "epic_hip_sweep_2d": (ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_uint,
                           ct.c_uint, ct.c_int, ct.c_void_p, ct.c_void_p),
+    "epic_hip_sweep_rb_2d": (ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_int,
+                             ct.c_int, ct.c_void_p, ct.c_void_p),
 }
 
 for _name, _args in _SIGNATURES.items():

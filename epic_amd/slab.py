@@ -98,6 +98,17 @@ class HipBackend:
         if rc != 0:
             raise RuntimeError("epic_hip_sweep_2d failed: %d" % rc)
 
+    def sweep_rb(self, u, maskw, rows, pitch, row_begin, row_end, parity, delta_bits):
+        """One in-place red-black half-sweep of local rows [row_begin, row_end): cells with (row + col + parity) odd."""
+        if row_end <= row_begin:
+            return
+        rc = self.E.epic_hip_sweep_rb_2d(u.data_ptr(), maskw.data_ptr(), rows, pitch, row_begin, row_end,
+                                         self.rows_per_task, self.math, int(parity) & 1,
+                                         delta_bits.data_ptr() if delta_bits is not None else None,
+                                         torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("epic_hip_sweep_rb_2d failed: %d" % rc)
+
 
 class SlabSolver:
     """One rank's share of a row-slab-decomposed 2-D relaxation.
@@ -110,11 +121,19 @@ class SlabSolver:
     rows are swept with their true masks, so every owned cell sees exactly the values a single-domain sweep would."""
 
     def __init__(self, grid, rank, world, device, stagger=100, epsilon=1e-6, rows_per_task=0, math="precise",
-                 backend=None, group=None, halo=8):
+                 backend=None, group=None, halo=8, scheme="jacobi"):
         self.grid = (int(grid[0]), int(grid[1]))
         self.rank, self.world, self.device = rank, world, torch.device(device)
         self.stagger, self.epsilon = int(stagger), float(epsilon)
         self.group = group
+        if scheme not in ("jacobi", "redblack"):
+            raise ValueError("scheme must be 'jacobi' or 'redblack'")
+        # "redblack" = the reference's own iteration (harmonic_cpu.cpp:46-51): one iteration updates, in place, the cells
+        # with (global row + column + iteration) odd; with the precise math the distributed result -- field, iteration
+        # count, delta -- is harmonic_complete_cpu's, bit for bit.  Ghost rows age exactly as in the Jacobi scheme
+        # (a row's update reads the rows next to it as they were one iteration ago), so the same G rows are traded
+        # every G iterations.
+        self.redblack = scheme == "redblack"
         self.backend = backend if backend is not None else HipBackend(rows_per_task, math)
         parts = partition_rows(self.grid[0], world)
         self.lo, self.hi = parts[rank]
@@ -253,15 +272,20 @@ class SlabSolver:
         return dist.batch_isend_irecv(ops) if ops else []
 
     def sweep(self, check=False):
-        """One Jacobi sweep of the whole (distributed) grid.  With check=True the local max |du| of the OWNED rows lands
+        """One iteration of the whole (distributed) grid: a Jacobi sweep, or a red-black half-sweep.  With check=True the local max |du| of the OWNED rows lands
         in self.delta_bits (float bits); combine across ranks with reduce_delta()."""
-        src, dst = self.buf[self.cur], self.buf[self.cur ^ 1]
+        src = self.buf[self.cur]
+        dst = src if self.redblack else self.buf[self.cur ^ 1]
         be, d = self.backend, (self.delta_bits if check else None)
         if check:
             self.delta_bits.zero_()
+        parity = (self.iteration + self.lo - self.g_top) & 1   # local row 0 is global row lo - g_top
 
         def rows(lo, hi, delta=None):
-            be.sweep(src, dst, self.maskw, self.rows, self.pitch, lo, hi, delta)
+            if self.redblack:
+                be.sweep_rb(src, self.maskw, self.rows, self.pitch, lo, hi, parity, delta)
+            else:
+                be.sweep(src, dst, self.maskw, self.rows, self.pitch, lo, hi, delta)
 
         if self.world == 1 or self.since + 1 < self.halo:
             # no exchange due: ghost rows (still exact deep enough) are swept like any other row
@@ -300,7 +324,8 @@ class SlabSolver:
                 for w in works:
                     w.wait()
             self.since = 0
-        self.cur ^= 1
+        if not self.redblack:
+            self.cur ^= 1
         self.iteration += 1
 
     def reduce_delta(self):

@@ -110,6 +110,12 @@ int epic_hip_pack_mask_2d(const uint32_t *d_locked, unsigned int rows, unsigned 
 int epic_hip_sweep_2d(const float *d_in, float *d_out, const uint32_t *d_maskw, unsigned int rows,
                       unsigned int pitch, unsigned int row_begin, unsigned int row_end, unsigned int rows_per_task,
                       int math_mode, uint32_t *d_delta_bits, void *stream);
+/* The same for the reference's red-black scheme: one in-place half-sweep of rows [row_begin, row_end) of d_u, updating
+ * the unlocked cells with (local row + column + parity) odd (libepic/src/harmonic/harmonic_cpu.cpp:46-51 with
+ * parity = currentIteration; a slab whose local row 0 is global row `top` passes (currentIteration + top) & 1). */
+int epic_hip_sweep_rb_2d(float *d_u, const uint32_t *d_maskw, unsigned int rows, unsigned int pitch, unsigned int row_begin,
+                         unsigned int row_end, unsigned int rows_per_task, int math_mode, int parity,
+                         uint32_t *d_delta_bits, void *stream);
 
 #ifdef __cplusplus
 }

@@ -338,3 +338,23 @@ float oracle_jacobi_rows_2d(const float *in, float *out, const unsigned int *loc
     }
     return d;
 }
+
+/* The red-black form of the same: one in-place half-sweep of rows [row_begin, row_end) of a rows x pitch array, updating
+ * the unlocked interior cells with (r + c + parity) odd -- harmonic_cpu.cpp:46-51 with parity standing for
+ * currentIteration (a slab whose local row 0 is global row `top` passes currentIteration + top).  Returns max |du|. */
+float oracle_redblack_rows_2d(float *u, const unsigned int *locked, unsigned int rows, unsigned int cols,
+                              unsigned int pitch, unsigned int row_begin, unsigned int row_end, unsigned int parity)
+{
+    float d = 0.0f;
+    for (unsigned int r = row_begin; r < row_end && r < rows; r++) {
+        if (r == 0 || r == rows - 1) continue;
+        for (unsigned int c = 1; c + 1 < cols; c++) {
+            if (((r + c + parity) & 1u) == 0u || locked[(size_t)r * cols + c]) continue;
+            size_t i = (size_t)r * pitch + c;
+            float v = cell_update_2d(u[i - pitch], u[i + pitch], u[i - 1], u[i + 1]);
+            d = fmax2(d, (float)fabs(u[i] - v));
+            u[i] = v;
+        }
+    }
+    return d;
+}

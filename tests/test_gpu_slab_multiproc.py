@@ -31,6 +31,29 @@ def _edits(grid):
     return np.array(v, dtype=np.uint32), np.array(t, dtype=np.uint32)
 
 
+def _map_worker(rank, world, port, name, out_dir):
+    """Red-black solve of a reference map on `world` ranks sharing cuda:0."""
+    import torch
+    import torch.distributed as dist
+
+    from epic_amd.slab import SlabSolver
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m, u0, locked = O.load_png_reference_rule(os.path.join(O.ROOT, "tests", "golden", "maps", name + ".png"))
+        s = SlabSolver(m, rank, world, device=torch.device("cuda:0"), stagger=100, epsilon=1e-6, scheme="redblack",
+                       rows_per_task=1)
+        top, bot = s.lo - s.g_top, s.hi + s.g_bot
+        s.load_rows(u0.reshape(m)[top:bot], locked.reshape(m)[top:bot])
+        iterations = s.solve()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), u=s.owned(), delta=s.delta, iterations=iterations)
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, grid, seed, sweeps, out_dir, edit=False):
     import torch
     import torch.distributed as dist
@@ -85,3 +108,16 @@ def test_set_cells_on_slabs_equals_single_domain(tmp_path):
     assert lib.oracle_jacobi_run(ct.byref(p.h), sweeps) == 0
     assert np.array_equal(field.ravel(), p.u)
     assert all(float(q["delta"]) == float(p.h.delta) for q in parts)
+
+
+def test_redblack_slab_solve_of_a_reference_map_is_the_reference_result(goldens, tmp_path):
+    """BASELINE config 1's little brother (basic.png, 256 x 256) solved on two ranks with the reference's own scheme:
+    the same 23 801 half-sweeps, the same final delta and the same field as harmonic_complete_cpu produced
+    (tests/golden/maps_converged.npz), bit for bit."""
+    name, world = "basic", 2
+    mp.spawn(_map_worker, args=(world, _free_port(), name, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    run = goldens["manifest"]["maps"][name]["runs"]["1e-06"]
+    assert all(int(q["iterations"]) == run["iterations"] and float(q["delta"]) == run["delta"] for q in parts)
+    field = np.concatenate([p["u"] for p in parts], axis=0)
+    assert np.array_equal(field.ravel(), goldens["maps"][name + "/converged_1e-06"])

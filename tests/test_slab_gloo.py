@@ -27,6 +27,9 @@ class OracleBackend:
         self.lib.oracle_jacobi_rows_2d.restype = ct.c_float
         self.lib.oracle_jacobi_rows_2d.argtypes = (ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_uint,
                                                    ct.c_uint, ct.c_uint, ct.c_uint)
+        self.lib.oracle_redblack_rows_2d.restype = ct.c_float
+        self.lib.oracle_redblack_rows_2d.argtypes = (ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_uint, ct.c_uint,
+                                                     ct.c_uint, ct.c_uint, ct.c_uint)
         self.cols = None
 
     def pitch_for(self, cols):
@@ -55,6 +58,15 @@ class OracleBackend:
             cur = delta_bits.view(torch.float32)
             cur[0] = max(float(cur[0]), d)
 
+    def sweep_rb(self, u, maskw, rows, pitch, row_begin, row_end, parity, delta_bits):
+        if row_end <= row_begin:
+            return
+        d = self.lib.oracle_redblack_rows_2d(u.data_ptr(), maskw.data_ptr(), rows, self.cols, pitch, row_begin, row_end,
+                                             parity)
+        if delta_bits is not None:
+            cur = delta_bits.view(torch.float32)
+            cur[0] = max(float(cur[0]), d)
+
 
 def _free_port():
     s = socket.socket()
@@ -64,13 +76,19 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, grid, seed, sweeps, mode, out_dir, halo=8):
+def _worker(rank, world, port, grid, seed, sweeps, mode, out_dir, halo=8, scheme="jacobi", problem=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        s = SlabSolver(grid, rank, world, device="cpu", stagger=10, epsilon=1e-6, backend=OracleBackend(), halo=halo)
-        free = s.load_synthetic(seed=seed, density=0.08)
+        stagger, eps = (10, 1e-6) if problem is None else (problem["stagger"], problem["epsilon"])
+        s = SlabSolver(grid, rank, world, device="cpu", stagger=stagger, epsilon=eps, backend=OracleBackend(), halo=halo,
+                       scheme=scheme)
+        if problem is None:
+            free = s.load_synthetic(seed=seed, density=0.08)
+        else:
+            top, bot = s.lo - s.g_top, s.hi + s.g_bot
+            free = s.load_rows(problem["u0"].reshape(grid)[top:bot], problem["locked"].reshape(grid)[top:bot])
         if mode == "fixed":
             for i in range(sweeps):
                 s.sweep(check=(i == sweeps - 1))
@@ -111,8 +129,9 @@ def _edits(grid, seed):
     return np.array(v, dtype=np.uint32), np.array(t, dtype=np.uint32)
 
 
-def _run(world, grid, seed, sweeps, mode, tmp_path, halo=8):
-    mp.spawn(_worker, args=(world, _free_port(), grid, seed, sweeps, mode, str(tmp_path), halo), nprocs=world, join=True)
+def _run(world, grid, seed, sweeps, mode, tmp_path, halo=8, scheme="jacobi", problem=None):
+    mp.spawn(_worker, args=(world, _free_port(), grid, seed, sweeps, mode, str(tmp_path), halo, scheme, problem),
+             nprocs=world, join=True)
     parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
     field = np.concatenate([p["u"] for p in parts], axis=0)
     return field, parts
@@ -170,3 +189,33 @@ def test_set_cells_between_sweeps_equals_single_domain(world, halo, sweeps, tmp_
     assert all(float(q["delta"]) == float(p.h.delta) for q in parts)
     in_range = (v[:, 0] < grid[1]) & (v[:, 1] < grid[0]) & ok
     assert sum(int(q["free"]) for q in parts) == int(in_range.sum())
+
+
+@pytest.mark.parametrize("world,halo", [(2, 1), (2, 8), (3, 3), (3, 5)])
+def test_redblack_half_sweeps_equal_single_domain(world, halo, tmp_path):
+    """The reference's own scheme on slabs: 25 in-place half-sweeps (a count that ends between two exchanges) equal the
+    checker's red-black half-sweeps on the whole grid, whatever the slab's first row parity (37 rows over 2 and 3 ranks
+    give even and odd starts)."""
+    grid, seed, sweeps = [37, 50], 5, 25
+    field, parts = _run(world, grid, seed, sweeps, "fixed", tmp_path, halo, "redblack")
+    u0, locked = synthetic_grid(grid, seed, 0.08)
+    p = O.Problem(grid, u0, locked)
+    lib = O.oracle()
+    for i in range(sweeps):
+        (lib.oracle_update_and_check if i == sweeps - 1 else lib.oracle_update)(ct.byref(p.h))
+    assert np.array_equal(field.ravel(), p.u)
+    assert all(float(q["delta"]) == float(p.h.delta) for q in parts)
+
+
+@pytest.mark.parametrize("name,world", [("g2d_64", 2), ("g2d_23x37", 3), ("g2d_70x66_dense", 2)])
+def test_redblack_slab_solve_is_the_reference_result(goldens, name, world, tmp_path):
+    """Distributed solve with the reference's scheme against vectors the REFERENCE produced (tests/golden/small_grids.npz):
+    same number of half-sweeps, same final delta, same field, bit for bit."""
+    g, info = goldens["small"], goldens["manifest"]["small"][name]
+    grid = [int(v) for v in g[name + "/m"]]
+    problem = dict(u0=np.asarray(g[name + "/u0"], dtype=np.float32), locked=np.asarray(g[name + "/locked"], dtype=np.uint32),
+                   stagger=int(info["stagger"]), epsilon=float(info["epsilon"]))
+    field, parts = _run(world, grid, 0, 0, "solve", tmp_path, 4, "redblack", problem)
+    assert all(int(q["iteration"]) == info["iterations"] for q in parts)
+    assert all(float(q["delta"]) == info["delta"] for q in parts)
+    assert np.array_equal(field.ravel(), g[name + "/converged"])
