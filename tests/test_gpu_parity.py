@@ -148,6 +148,31 @@ SMALL = ["g2d_16", "g2d_32", "g2d_64", "g2d_23x37", "g2d_5x7", "g2d_3x3", "g2d_8
 
 
 @pytest.mark.parametrize("name", SMALL)
+def test_jacobi_sweeps_contain_the_reference_half_sweeps(goldens, name):
+    """Link between the default Jacobi path and REFERENCE-generated vectors.  The grid is bipartite, so a Jacobi run is two
+    interleaved red-black chains; the chain that updates, at sweep k, the colour the reference updates at iteration k
+    (harmonic_cpu.cpp:46-51 / :88-93) starts from the same values and sees the same neighbours, so after k sweeps the
+    cells of the colour last updated hold exactly what the reference's k-th half-sweep wrote: bit for bit, 2-D and 3-D."""
+    g = goldens["small"]
+    m = [int(v) for v in g[name + "/m"]]
+    u0, locked = g[name + "/u0"], g[name + "/locked"]
+    idx = np.indices(m).sum(axis=0)
+    interior = np.ones(m, dtype=bool)
+    for ax in range(len(m)):
+        sl = [slice(None)] * len(m)
+        sl[ax] = [0, m[ax] - 1]
+        interior[tuple(sl)] = False
+    free = interior & (np.asarray(locked).reshape(m) == 0)
+    for k in (1, 2, 3, 10):
+        got, _ = gpu_sweeps(m, u0, locked, k)
+        # iteration k - 1 was the last one: 2-D updates (x0 + x1 + iteration) odd, 3-D (x0 + x1 + x2 + iteration) even
+        last = ((idx + (k - 1)) % 2 == 1) if len(m) == 2 else ((idx + (k - 1)) % 2 == 0)
+        ref = np.asarray(g[f"{name}/rb{k}"]).reshape(m)
+        sel = free & last
+        assert np.array_equal(np.asarray(got).reshape(m)[sel], ref[sel]), f"{name}: colour of half-sweep {k}"
+
+
+@pytest.mark.parametrize("name", SMALL)
 def test_complete_gpu_vs_reference_golden(goldens, name):
     """harmonic_complete_gpu (the plugin's one-shot call) converged at eps = 1e-6 vs the reference's field."""
     g, info = goldens["small"], goldens["manifest"]["small"][name]
@@ -172,6 +197,14 @@ def test_maps_converged_vs_reference_golden(goldens, name, record_property):
     record_property("max_rel_err", worst)
     record_property("max_abs_err", absmax)
     print(f"{name}: sweeps {h.currentIteration}, delta {h.delta:.3e}, max rel {worst:.3e}, max abs {absmax:.3e}")
+    # The Jacobi run contains the reference's red-black chain (see test_jacobi_sweeps_contain_the_reference_half_sweeps):
+    # it stops after the same number of iterations, and the cells of the colour updated last are the reference's, exactly.
+    run = goldens["manifest"]["maps"][name]["runs"]["1e-06"]
+    assert h.currentIteration == run["iterations"]
+    rows, cols = h.shape
+    rr, cc = np.indices((rows, cols), sparse=True)
+    last = ((rr + cc + (h.currentIteration - 1)) % 2 == 1) & (h.locked_array() == 0)
+    assert np.array_equal(h.u_array()[last], want.reshape(rows, cols)[last])
 
 
 def test_execute_gpu_validation_and_lifecycle(capfd):

@@ -106,3 +106,27 @@ def test_jacobi_and_red_black_reach_the_same_field():
     assert np.array_equal(a.u <= -9e5, b.u <= -9e5)
     rel = np.abs(a.u[reach] - b.u[reach]) / np.maximum(1.0, np.abs(a.u[reach]))
     assert rel.max() < 2e-6
+
+
+@pytest.mark.parametrize("name", ["g2d_16", "g2d_23x37", "g2d_8x300", "g2d_70x66_dense", "g3d_8", "g3d_7x9x11", "g3d_20x12x34"])
+def test_jacobi_checker_contains_the_reference_half_sweeps(goldens, name):
+    """Pins the JACOBI form of the checker (what the default GPU path is compared with) to reference-generated vectors:
+    the grid is bipartite, so a Jacobi run is two interleaved red-black chains, and the chain in phase with the reference
+    (harmonic_cpu.cpp:46-51, :88-93) reproduces its half-sweeps -- after k sweeps the cells of the colour updated last
+    equal the reference's field after k iterations, bit for bit."""
+    g = goldens["small"]
+    m = [int(v) for v in g[name + "/m"]]
+    u0, locked = g[name + "/u0"], g[name + "/locked"]
+    idx = np.indices(m).sum(axis=0)
+    interior = np.ones(m, dtype=bool)
+    for ax in range(len(m)):
+        sl = [slice(None)] * len(m)
+        sl[ax] = [0, m[ax] - 1]
+        interior[tuple(sl)] = False
+    free = interior & (np.asarray(locked).reshape(m) == 0)
+    for k in (1, 2, 3, 10):
+        p = O.Problem(m, u0, locked)
+        assert O.oracle().oracle_jacobi_run(ct.byref(p.h), k) == 0
+        last = ((idx + (k - 1)) % 2 == 1) if len(m) == 2 else ((idx + (k - 1)) % 2 == 0)
+        sel = free & last
+        assert sel.any() and np.array_equal(p.u.reshape(m)[sel], np.asarray(g[f"{name}/rb{k}"]).reshape(m)[sel])
