@@ -188,9 +188,9 @@ int auto_rows_per_task(const Ctx *c)
     const long long nstrips = (c->pitch + 255) / 256;
     // The kernel is VALU-bound (precise math): a full sweep of 8192^2 takes the same time with 8 to 32 rows per task
     // (2 extra halo rows per task are cheap).  With activity tracking the tile is also the unit of skipping, and a sweep
-    // with few active tiles costs what its slowest SIMD costs: shorter tasks spread better (8192^2 at 10 % activity:
-    // 61 us with 16 rows, 46 us with 8 or 4; whole relaxation 4.76 -> 4.60 s), while below 4 rows the waves that only
-    // test their flags start to cost (profiles/r01_experiments.txt).  Aim at >= 32768 wave-tasks.
+    // with few listed tiles costs the march of its longest task (one wave alone: ~1.3 us per row), so shorter tasks help
+    // the tail of a relaxation, while very short ones pay the per-task prologue too often (profiles/r01_experiments.txt).
+    // Aim at >= 32768 wave-tasks (8 rows per task at 8192^2).
     // Small grids (the ROS maps are 0.1-1 Mcell) cannot fill the chip at all: there one row per wave is best
     // (310 x 940: 4.3 us per sweep at 1 row per task vs 11.4 us at 8, both measured).
     long long r = (long long)c->rows * nstrips / 32768;
@@ -299,7 +299,7 @@ int fused_rows_per_task(const Ctx *c)
 hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
 {
     static const bool no_fuse = getenv("EPIC_HIP_NO_FUSE") != nullptr;
-    // (the fused pass has its own 248-column tiling and no activity flags: it is used when tracking is off)
+    // (the fused pass has its own 248-column tiling and no work lists: it is used when tracking is off)
     const bool fuse = c->redblack && c->n == 2 && !no_fuse && !c->track && (long long)c->rows * c->pitch >= (1ll << 22);
     unsigned i = 0;
     while (fuse && count - i >= 2) {
@@ -320,7 +320,7 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
 {
     const bool small = (long long)c->rows * c->pitch <= (1ll << 22);
     static const bool no_graph = getenv("EPIC_HIP_NO_GRAPH") != nullptr;
-    // a captured sequence bakes in the flag buffers and force = 0: run eagerly until the forced iterations are over
+    // a captured sequence bakes in the work-list buffers and list mode: run eagerly until the forced iterations are over
     if (!small || count < 8 || no_graph || (c->track && c->n == 2 && (c->force > 0 || c->act_tiles == 0)))
         return enqueue_plain_run(c, count, first);
     const auto key = std::make_tuple(count, c->cur + 2 * (c->track ? 1 + c->phase : 0), (int)(first & 1u), c->math,
@@ -365,7 +365,7 @@ int read_delta(Harmonic *h, Ctx *c, const char *fn)
 
 int upload_u(Harmonic *h, Ctx *c, const char *fn)
 {
-    c->force = 2;  // new values: no tile may be skipped on the old flags
+    c->force = 2;  // new values: no tile may be left out on the strength of the old work lists
     // padding columns hold the obstacle seed; both buffers, so that whichever is read first is complete
     if (c->pitch != c->cols) {
         for (int b = 0; b < 2; b++)
@@ -814,7 +814,7 @@ int harmonic_utilities_set_cells_2d_gpu(Harmonic *harmonic, unsigned int numThre
     }
     unsigned *d_v = nullptr, *d_types = nullptr;
     int rc = EPIC_SUCCESS;
-    c->force = 2;  // cells and mask bits change under the activity flags
+    c->force = 2;  // cells and mask bits change under the work lists
     if (hipMalloc((void **)&d_v, 2 * (size_t)k * sizeof(unsigned)) != hipSuccess ||
         hipMalloc((void **)&d_types, (size_t)k * sizeof(unsigned)) != hipSuccess) {
         (void)hipGetLastError();

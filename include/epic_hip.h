@@ -87,8 +87,8 @@ int epic_hip_compute_path_2d_gpu(EpicHarmonicT *harmonic, float x, float y, floa
 /* Diagnostic: the number of tiles the next iteration will recompute and the number of tiles (both 0 when tracking is
  * off or the grid is 3-D).  Synchronises the stream and copies the list counters to the host. */
 int epic_hip_activity_stats(EpicHarmonicT *harmonic, unsigned long long *active_tiles, unsigned long long *tiles);
-/* The same with both outputs of the earlier flag-based scheme (active_tiles and due_tiles now report the same number:
- * the tiles listed for the next iteration); due_tiles may be NULL. */
+/* The same with a separate output for the tiles due in the next iteration (with work lists both outputs report that
+ * number: the tiles a launch changed are the tiles it lists, apart from woken neighbours); due_tiles may be NULL. */
 int epic_hip_activity_stats2(EpicHarmonicT *harmonic, unsigned long long *active_tiles, unsigned long long *due_tiles,
                              unsigned long long *tiles);
 

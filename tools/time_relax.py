@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time harmonic_execute_gpu on the synthetic N x N grid: tools/time_relax.py [--size 8192] [--scheme jacobi|redblack]
 [--track 0|1] [--rows-per-task R] [--math precise|df32].  Prints one JSON line (seconds, iterations, final active-tile
-share).  Tiling experiments: EPIC_HIP_BAND (chunk-rows per XCD band) is read from the environment by the library."""
+share).  Tuning experiments: EPIC_HIP_LIST_WAVES is read from the environment by the library."""
 import argparse
 import ctypes as ct
 import json
@@ -51,6 +51,6 @@ for _ in range(a.repeat):
     act, tiles = ct.c_ulonglong(0), ct.c_ulonglong(0)
     E.epic_hip_activity_stats(h, ct.byref(act), ct.byref(tiles))
     print(json.dumps({"scheme": a.scheme, "track": a.track, "rows_per_task": a.rows_per_task, "math": a.math,
-                      "band": os.environ.get("EPIC_HIP_BAND"), "seconds": round(dt, 3),
+                      "list_waves": os.environ.get("EPIC_HIP_LIST_WAVES"), "seconds": round(dt, 3),
                       "iterations": int(h.currentIteration), "delta": float(h.delta),
                       "active_tiles_at_end": act.value, "tiles": tiles.value}), flush=True)
