@@ -123,3 +123,33 @@ def test_all_30_reference_symbols_exported():
         r = subprocess.run(["nm", "-D", "--defined-only", ref_so], capture_output=True, text=True, check=True).stdout
         ref_names = sorted(l.split()[-1] for l in r.splitlines() if " T harmonic_" in l)
         assert names == ref_names
+
+
+def test_legacy_python_classes(paths):
+    """HarmonicLegacy / HarmonicLegacyMap (reference python package, harmonic_legacy.py:34-95, harmonic_legacy_map.py:38-123)
+    over the exported legacy functions: the SOR run and a streamline equal the reference-generated vectors."""
+    from epic_amd.harmonic_legacy import HarmonicLegacy, HarmonicLegacyMap
+
+    w, h = (int(v) for v in paths["legacy/w_h"])
+    solver = HarmonicLegacy()
+    solver.set_grid(paths["legacy/u0"].astype(np.float64).reshape(h, w), paths["legacy/locked"].reshape(h, w))
+    wall, cpu = solver.solve(omega=1.5, epsilon=1e-3)      # the parameters of the golden run
+    assert wall >= 0 and cpu >= 0 and solver.currentIteration == int(paths["legacy/double_iter"])
+    assert np.array_equal(solver.u_array().ravel(), paths["legacy/double_u"])
+    assert "omega" in str(solver)
+    # the map flavour: load, relax, walk; the streamline ends on a goal pixel (255)
+    m = HarmonicLegacyMap().load(os.path.join(G, "maps", "basic.png"))
+    assert (m.w, m.h) == (256, 256) and m.locked_array()[0, 0] == 1
+    assert set(np.unique(m.u_array())) <= {0.0, 1.0}
+    m.solve(omega=1.5, epsilon=1e-10)
+    free = np.argwhere((m.image != 0) & (m.image != 255))
+    ends_on_goal = 0
+    for y, x in free[:: max(1, len(free) // 12)][:12]:
+        try:
+            path = m._compute_streamline(float(x), float(y))
+        except RuntimeError:
+            continue
+        ex, ey = path[-1]
+        if np.isfinite(ex) and np.isfinite(ey) and m.image[int(ey + 0.5), int(ex + 0.5)] == 255:
+            ends_on_goal += 1
+    assert ends_on_goal >= 1
