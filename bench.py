@@ -17,7 +17,8 @@ Prints ONE JSON line on rank 0.  Extra objects:
   cpu_baseline  the reference's own harmonic_cpu.cpp compiled by oracle/Makefile (oracle/_ref/libepic_ref.so, kind
                 "reference") or, when that did not travel with the repo, its C restatement (oracle/liboracle.so, kind
                 "port"); 1 thread -- the reference is single-threaded -- timed on this host for a bounded number of
-                red-black half-sweeps of the same grid.  Rank 0, N = 1 only.
+                red-black half-sweeps of the same grid.  Rank 0, N = 1 only.  Its `all_cores` entry is the build's own
+                OpenMP form of the same half-sweep on every host core (not the reference, which has no threading).
   relax*        (N = 1) the complete relaxation to epsilon = 1e-6 through harmonic_execute_gpu: iterations, seconds --
                 Jacobi and red-black with the library defaults (activity tracking on), Jacobi also with tracking off.
 The timed region itself runs with activity tracking OFF: every sweep recomputes every unlocked cell.
@@ -84,10 +85,27 @@ def cpu_baseline(m, u0, locked, half_sweeps, free_by_colour):
     dt = time.perf_counter() - t0
     # iteration i recomputes the unlocked cells with (row + col + i) odd (harmonic_cpu.cpp:46-51)
     updates = sum(free_by_colour[i % 2] for i in range(half_sweeps))
-    return dict(value=round(updates / dt / 1e6, 3), unit="Mcell-updates/s", cores=1, host_cores=os.cpu_count(),
-                kind=kind, seconds=round(dt, 2),
-                sample="%d red-black half-sweeps (harmonic_update_cpu, one of them with the convergence check) of the "
-                       "same %dx%d grid (full relaxation needs ~5e4, ~15 h on one core)" % (half_sweeps, m[0], m[1]))
+    out = dict(value=round(updates / dt / 1e6, 3), unit="Mcell-updates/s", cores=1, host_cores=os.cpu_count(),
+               kind=kind, seconds=round(dt, 2),
+               sample="%d red-black half-sweeps (harmonic_update_cpu, one of them with the convergence check) of the "
+                      "same %dx%d grid (full relaxation needs ~5e4, ~15 h on one core)" % (half_sweeps, m[0], m[1]))
+    # Not the reference (which has no threading): the same half-sweep with its rows dealt to every host core by OpenMP
+    # (oracle_update_parallel_2d, bit-identical to the sequential one) -- the best this host can do with that algorithm.
+    lib = O.oracle()
+    if hasattr(lib, "oracle_update_parallel_2d"):
+        lib.oracle_update_parallel_2d.argtypes = (ct.c_void_p, ct.c_int)
+        lib.oracle_update_parallel_2d.restype = ct.c_int
+        threads = os.cpu_count() or 1
+        lib.oracle_update_parallel_2d(ct.byref(p.h), threads)          # thread pool start-up, page placement
+        first = int(p.h.currentIteration)
+        t0 = time.perf_counter()
+        for _ in range(half_sweeps):
+            lib.oracle_update_parallel_2d(ct.byref(p.h), threads)
+        dt = time.perf_counter() - t0
+        upd = sum(free_by_colour[(first + i) % 2] for i in range(half_sweeps))
+        out["all_cores"] = dict(value=round(upd / dt / 1e6, 1), unit="Mcell-updates/s", cores=threads, kind="port+openmp",
+                                seconds=round(dt, 2))
+    return out
 
 
 def measured_traffic(n, math, scheme):

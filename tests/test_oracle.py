@@ -130,3 +130,22 @@ def test_jacobi_checker_contains_the_reference_half_sweeps(goldens, name):
         last = ((idx + (k - 1)) % 2 == 1) if len(m) == 2 else ((idx + (k - 1)) % 2 == 0)
         sel = free & last
         assert sel.any() and np.array_equal(p.u.reshape(m)[sel], np.asarray(g[f"{name}/rb{k}"]).reshape(m)[sel])
+
+
+def test_parallel_half_sweeps_equal_the_sequential_ones():
+    """oracle_update_parallel_2d (the all-cores CPU figure of bench.py): rows of a red-black half-sweep are independent,
+    so 1, 3 and 8 threads give the sequential result bit for bit."""
+    from epic_amd.synthetic import synthetic_grid
+
+    lib = O.oracle()
+    lib.oracle_update_parallel_2d.argtypes = (ct.c_void_p, ct.c_int)
+    m = [97, 203]
+    u0, locked = synthetic_grid(m, 3, 0.07)
+    seq = O.Problem(m, u0, locked)
+    for _ in range(31):
+        lib.oracle_update(ct.byref(seq.h))
+    for threads in (1, 3, 8):
+        par = O.Problem(m, u0, locked)
+        for _ in range(31):
+            assert lib.oracle_update_parallel_2d(ct.byref(par.h), threads) == 0
+        assert par.h.currentIteration == 31 and np.array_equal(par.u, seq.u)
