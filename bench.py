@@ -95,16 +95,24 @@ def cpu_baseline(m, u0, locked, half_sweeps, free_by_colour):
     if hasattr(lib, "oracle_update_parallel_2d"):
         lib.oracle_update_parallel_2d.argtypes = (ct.c_void_p, ct.c_int)
         lib.oracle_update_parallel_2d.restype = ct.c_int
-        threads = os.cpu_count() or 1
-        lib.oracle_update_parallel_2d(ct.byref(p.h), threads)          # thread pool start-up, page placement
-        first = int(p.h.currentIteration)
-        t0 = time.perf_counter()
-        for _ in range(half_sweeps):
-            lib.oracle_update_parallel_2d(ct.byref(p.h), threads)
-        dt = time.perf_counter() - t0
-        upd = sum(free_by_colour[(first + i) % 2] for i in range(half_sweeps))
-        out["all_cores"] = dict(value=round(upd / dt / 1e6, 1), unit="Mcell-updates/s", cores=threads, kind="port+openmp",
-                                seconds=round(dt, 2))
+        allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        best = None
+        for threads in sorted({allowed, 128, 64, 32, 16, 8} & set(range(1, allowed + 1)), reverse=True):
+            lib.oracle_update_parallel_2d(ct.byref(p.h), threads)      # thread start-up, page placement
+            first = int(p.h.currentIteration)
+            n = max(4, half_sweeps // 4)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                lib.oracle_update_parallel_2d(ct.byref(p.h), threads)
+            dt = time.perf_counter() - t0
+            rate = sum(free_by_colour[(first + i) % 2] for i in range(n)) / dt / 1e6
+            if best is None or rate > best["value"]:
+                best = dict(value=round(rate, 1), unit="Mcell-updates/s", cores=threads, kind="port+openmp",
+                            seconds=round(dt, 2), half_sweeps=n)
+        if best:
+            best["allowed_cores"] = allowed
+            best["note"] = "best of a few thread counts; the host may cap CPU time below its core count"
+            out["all_cores"] = best
     return out
 
 
