@@ -98,7 +98,9 @@ def cpu_baseline(m, u0, locked, half_sweeps, free_by_colour):
         allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         best = None
         for threads in sorted({allowed, 128, 64, 32, 16, 8} & set(range(1, allowed + 1)), reverse=True):
-            lib.oracle_update_parallel_2d(ct.byref(p.h), threads)      # thread start-up, page placement
+            t_warm = time.perf_counter()                                # thread start-up, sleeping cores, page placement
+            while time.perf_counter() - t_warm < 0.3:
+                lib.oracle_update_parallel_2d(ct.byref(p.h), threads)
             first = int(p.h.currentIteration)
             n = max(4, half_sweeps // 4)
             t0 = time.perf_counter()
