@@ -50,7 +50,7 @@ struct Ctx {
     // Launch-bound grids replay the plain sweeps between two checks from a captured hipGraph; key = (count, starting
     // buffer, starting parity, math, scheme, rows_per_task) -- everything a captured launch sequence depends on.
     std::map<std::tuple<unsigned, int, int, int, int, int>, hipGraphExec_t> graphs;
-    // Activity tracking (2-D): every iteration lists the tiles its successor has to recompute; tiles whose inputs did
+    // Activity tracking: every iteration lists the tiles its successor has to recompute; tiles whose inputs did
     // not change are never touched (bit-identical results, see kernels_2d.hip).  One device block `wake` holds 3 counter
     // sets (L words each, L = kWakeListCount), the queued marks of both directions (act_tiles words each) and both
     // directions' L lists (ceil(act_tiles / L) words each); `phase` (mod 6) says which direction (phase & 1) and which
@@ -179,7 +179,7 @@ void drop_ctx_if_empty(Harmonic *h)
 // are launch-bound either way (3.2-4 us per sweep without, 5-6.7 us with lists, measured), so "automatic" leaves them alone.
 void resolve_tracking(Ctx *c)
 {
-    c->track = c->n == 2 && (c->track_mode == 1 || (c->track_mode == 2 && (long long)c->rows * c->pitch > (1ll << 22)));
+    c->track = c->track_mode == 1 || (c->track_mode == 2 && (long long)c->rows * c->pitch > (1ll << 22));
 }
 
 int auto_rows_per_task(const Ctx *c)
@@ -219,9 +219,10 @@ hipError_t enqueue_sweep(Ctx *c, bool check, unsigned iteration)
     float *out = c->buf[c->cur ^ 1];
     // wake lists of this iteration (2-D only); (re)allocated when the tiling changes
     epic_hip::Activity act = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (c->n == 2 && c->track) {
-        const int rpt = auto_rows_per_task(c);
-        const size_t tiles = epic_hip::sweep_2d_tiles(c->rows, c->pitch, rpt);
+    if (c->track) {
+        const int rpt = c->n == 2 ? auto_rows_per_task(c) : 32;   // the 3-D kernel has a fixed task shape
+        const size_t tiles = c->n == 2 ? epic_hip::sweep_2d_tiles(c->rows, c->pitch, rpt)
+                                       : epic_hip::sweep_3d_tiles(c->m[0], c->m[1], c->pitch);
         if (tiles != c->act_tiles || rpt != c->act_rpt) {
             drop_graphs(c);  // captured sequences hold the old lists (never reached during a capture: force > 0)
             if (c->wake) (void)hipFree(c->wake);
@@ -263,15 +264,15 @@ hipError_t enqueue_sweep(Ctx *c, bool check, unsigned iteration)
             return advance(epic_hip::launch_sweep_2d(inout, inout, c->maskw, c->rows, c->pitch, 0, c->rows,
                                                      auto_rows_per_task(c), c->math, (int)(iteration & 1u),
                                                      check ? c->d_delta : nullptr, c->stream, &act));
-        return epic_hip::launch_sweep_3d(inout, inout, c->maskw, c->m[0], c->m[1], c->pitch, 0, c->m[0], c->math,
-                                         (int)(iteration & 1u), check ? c->d_delta : nullptr, c->stream);
+        return advance(epic_hip::launch_sweep_3d(inout, inout, c->maskw, c->m[0], c->m[1], c->pitch, 0, c->m[0], c->math,
+                                                 (int)(iteration & 1u), check ? c->d_delta : nullptr, c->stream, &act));
     }
     if (c->n == 2)
         e = advance(epic_hip::launch_sweep_2d(in, out, c->maskw, c->rows, c->pitch, 0, c->rows, auto_rows_per_task(c),
                                               c->math, -1, check ? c->d_delta : nullptr, c->stream, &act));
     else
-        e = epic_hip::launch_sweep_3d(in, out, c->maskw, c->m[0], c->m[1], c->pitch, 0, c->m[0], c->math, -1,
-                                      check ? c->d_delta : nullptr, c->stream);
+        e = advance(epic_hip::launch_sweep_3d(in, out, c->maskw, c->m[0], c->m[1], c->pitch, 0, c->m[0], c->math, -1,
+                                              check ? c->d_delta : nullptr, c->stream, &act));
     if (e == hipSuccess) c->cur ^= 1;
     return e;
 }
@@ -321,7 +322,7 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
     const bool small = (long long)c->rows * c->pitch <= (1ll << 22);
     static const bool no_graph = getenv("EPIC_HIP_NO_GRAPH") != nullptr;
     // a captured sequence bakes in the work-list buffers and list mode: run eagerly until the forced iterations are over
-    if (!small || count < 8 || no_graph || (c->track && c->n == 2 && (c->force > 0 || c->act_tiles == 0)))
+    if (!small || count < 8 || no_graph || (c->track && (c->force > 0 || c->act_tiles == 0)))
         return enqueue_plain_run(c, count, first);
     const auto key = std::make_tuple(count, c->cur + 2 * (c->track ? 1 + c->phase : 0), (int)(first & 1u), c->math,
                                      (int)c->redblack, auto_rows_per_task(c));
@@ -345,7 +346,7 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
     }
     hipError_t e = hipGraphLaunch(it->second, c->stream);
     if (e == hipSuccess && !c->redblack && (count & 1u)) c->cur ^= 1;
-    if (e == hipSuccess && c->track && c->n == 2) c->phase = (int)((c->phase + count) % 6);
+    if (e == hipSuccess && c->track) c->phase = (int)((c->phase + count) % 6);
     return e;
 }
 
@@ -1055,7 +1056,7 @@ int epic_hip_activity_stats2(Harmonic *harmonic, unsigned long long *active_tile
     if (!c || !active_tiles || !tiles) return EPIC_ERROR_INVALID_DATA;
     *active_tiles = *tiles = 0;
     if (due_tiles) *due_tiles = 0;
-    if (!c->track || c->n != 2 || c->act_tiles == 0) return EPIC_SUCCESS;
+    if (!c->track || c->act_tiles == 0) return EPIC_SUCCESS;
     // the counter set the next launch will consume was filled by the latest one: the tiles it woke
     std::vector<uint32_t> counts(Ctx::kL * Ctx::kCS);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return EPIC_ERROR_DEVICE_SYNCHRONIZE;

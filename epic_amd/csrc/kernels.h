@@ -68,7 +68,12 @@ inline size_t mask_words_2d(int rows, int pitch) { return (size_t)((rows + 7) / 
 // ---- 3-D (kernels_3d.hip) -------------------------------------------------------------------
 hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, int m0, int m1, int pitch,
                            int plane_begin, int plane_end, int math, int parity, unsigned *delta_bits,
-                           hipStream_t stream);
+                           hipStream_t stream, const Activity *act = nullptr);
+// tiles of the 3-D sweep: one per (x0-plane, 32-row x1-chunk, 256-column x2-strip)
+inline size_t sweep_3d_tiles(int m0, int m1, int pitch)
+{
+    return (size_t)m0 * (size_t)((m1 + 31) / 32) * (size_t)((pitch + 255) / 256);
+}
 hipError_t launch_pack_mask_3d(const uint32_t *locked, int m0, int m1, int m2, int pitch, uint32_t *maskw,
                                hipStream_t stream);
 inline size_t mask_words_3d(int m0, int m1, int pitch) { return (size_t)m0 * (size_t)m1 * (size_t)(pitch / 32); }

@@ -30,6 +30,7 @@
 
 #include "cell_update.h"
 #include "kernels.h"
+#include "wake.h"
 
 namespace epic_hip {
 
@@ -40,8 +41,7 @@ constexpr int kColsPerLane = 4;
 constexpr int kStripCols = kWave * kColsPerLane;  // 256
 constexpr int kWavesPerBlock = 4;
 constexpr int kNumXcd = 8;
-constexpr int kWakeLists = kWave * kWavesPerBlock;  // 256 work lists per tracked launch (see Sweep2dArgs)
-constexpr int kCounterStride = kWakeCounterStride;  // words between two list counters: one 128-byte line each
+static_assert(kWakeLists == kWave * kWavesPerBlock, "one thread per work list resets the counters");
 
 struct Sweep2dArgs {
     const float *in;
@@ -56,33 +56,10 @@ struct Sweep2dArgs {
     int ntasks;             // nstrips * nchunks
     int parity;             // red-black scheme only: currentIteration & 1 (which colour this half-sweep updates)
     int flags;              // tuning, never results: bit 0 = odd row-chunks march upwards, bit 1 = non-temporal stores
-    // Activity tracking (full-grid launches only; TRACK kernels).  A tile (= task: rows_per_task x 256 cells) has to be
-    // recomputed in iteration k + 1 only if iteration k changed one of the values it reads: one of its own cells, the
-    // last column of its left neighbour, the first column of its right neighbour, the last row of its upper neighbour
-    // or the first row of its lower neighbour (5-point stencil).  Otherwise its update would reproduce, bit for bit,
-    // the values already in place (Jacobi: in BOTH ping-pong buffers, because the tile itself did not change either).
-    // So every task that changed something WAKES the tiles that read it -- itself, and the neighbours across the edges
-    // it changed -- by appending them to the work lists of the next iteration (`queued` marks keep a tile from being
-    // listed twice).  Iteration k + 1 is then a fixed-size launch of persistent waves that walk those lists: no wave is
-    // spent on a tile that has nothing to do, and the listed tiles spread evenly over the chip however they cluster in
-    // space.  A single list with a single counter serialises on that counter (7 ns per atomicAdd: 460 us per 8192^2
-    // sweep, measured), so there are kWakeLists = 256 of them, each counter in a cache line of its own: tile t is always
-    // listed in list t / list_cap (list_cap = ceil(tiles / 256) consecutive tiles, a band of a few chunk-rows), so a list
-    // can never overflow and its tiles are neighbours in memory.  The consumer side sees the 256 lists as one sequence
-    // (entries of list 0, then list 1, ...): wave w takes elements w, w + W, w + 2 W ... of it (W = waves in the
-    // launch) after a prefix sum over the 256 counters -- perfectly even, whatever the lists hold, and waves that run
-    // side by side work on the same band, sharing its halo rows in L2.
-    // list_in == nullptr: every tile runs (the first two iterations after any edit of u, mask or mode) and the launch
-    // covers the grid like an untracked one, still waking tiles for its successor.  Three counter sets rotate: a launch
-    // reads count_in, fills count_out and resets count_zero, which the launch after next will fill.
-    const uint32_t *list_in;    // kWakeLists x list_cap tile ids; list i holds count_in[i] of them
-    const uint32_t *count_in;
-    uint32_t *list_out;         // tiles woken for the next launch
-    uint32_t *count_out;
-    uint32_t *count_zero;
-    uint32_t *queued_in;        // marks of the tiles listed for this launch: cleared as they are taken
-    uint32_t *queued_out;       // 1 = already in list_out
-    int list_cap;
+    // Activity tracking (full-grid launches only; TRACK kernels): wake.h.  A tile is one task (rows_per_task x 256
+    // cells); it reads its own cells, the last column of its left neighbour, the first column of its right neighbour,
+    // the last row of the tile above and the first row of the tile below (5-point stencil).
+    WakeArgs wake;
     int nchunks;
 };
 
@@ -112,29 +89,11 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
     const int lane = threadIdx.x & (kWave - 1);
     // wave-uniform quantities are forced into SGPRs: the row loop, its addresses and branches are scalar
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (TRACK && blockIdx.x == 0) a.count_zero[threadIdx.x * kCounterStride] = 0;  // kWakeLists == block size
-    // list-driven launch: the 256 lists form one sequence, cut into eight equal segments, one per XCD (blocks are dealt
-    // round-robin over the XCDs, blockIdx % 8 labels them; the launcher makes gridDim a multiple of 8): the waves of an
-    // XCD take the elements of its segment in turn, so tiles of one band meet in one L2
-    const bool listed = TRACK && a.list_in != nullptr;
-    const int xcd = blockIdx.x % kNumXcd;
-    const int nwaves = (gridDim.x / kNumXcd) * kWavesPerBlock;          // per XCD
-    int g = (blockIdx.x / kNumXcd) * kWavesPerBlock + wave;             // index into the sequence, set below
-    int total = 0;                                                       // end of this XCD's segment
-    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, incl = 0;  // lane l: counters 4 l .. 4 l + 3 and their inclusive prefix sum
-    if (listed) {
-        const uint32_t *mine = a.count_in + (size_t)(4 * lane) * kCounterStride;
-        c0 = mine[0]; c1 = mine[kCounterStride]; c2 = mine[2 * kCounterStride]; c3 = mine[3 * kCounterStride];
-        incl = c0 + c1 + c2 + c3;
-        for (int d = 1; d < kWave; d <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, d, kWave);
-            if (lane >= d) incl += up;
-        }
-        const long long all = __builtin_amdgcn_readlane((int)incl, kWave - 1);
-        g += (int)(all * xcd / kNumXcd);
-        total = (int)(all * (xcd + 1) / kNumXcd);
-        if (g >= total) return;
-    }
+    if (TRACK) wake_reset_next(a.wake);
+    // list-driven launch (wake.h): persistent waves walking the tiles listed by the previous iteration
+    const bool listed = TRACK && a.wake.list_in != nullptr;
+    WakeCursor cursor = {};
+    if (listed && !wake_begin(a.wake, lane, wave, kWavesPerBlock, cursor)) return;
     MathTab lds = {};  // libm tables, one entry per lane (precise math only)
     if (MATH == kMathPrecise) lds = math_tables_load();
     float dmax = 0.0f;
@@ -146,20 +105,10 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
 
     for (;;) {  // one pass per task: exactly one unless the launch is list-driven
     int task;
-    if (listed) {
-        // element g of the sequence: the first lane whose inclusive prefix exceeds g holds its list among its four
-        const int L = __popcll(__ballot(incl <= (uint32_t)g));
-        const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)c0, L), l1 = (uint32_t)__builtin_amdgcn_readlane((int)c1, L);
-        const uint32_t l2 = (uint32_t)__builtin_amdgcn_readlane((int)c2, L), l3 = (uint32_t)__builtin_amdgcn_readlane((int)c3, L);
-        uint32_t r = (uint32_t)g - ((uint32_t)__builtin_amdgcn_readlane((int)incl, L) - (l0 + l1 + l2 + l3));
-        int list = 4 * L;
-        if (r >= l0) { r -= l0; list++; if (r >= l1) { r -= l1; list++; if (r >= l2) { r -= l2; list++; } } }
-        task = __builtin_amdgcn_readfirstlane((int)a.list_in[(size_t)list * a.list_cap + r]);
-    } else {
-        task = xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
-    }
+    if (listed) task = wake_tile(a.wake, cursor);
+    else task = xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
     if (task >= a.ntasks) break;
-    if (TRACK && lane == 0) a.queued_in[task] = 0;
+    if (TRACK && lane == 0) a.wake.queued_in[task] = 0;
     const int strip = task % a.nstrips;
     const int chunk = task / a.nstrips;
     const int r0 = a.row_begin + chunk * a.rows_per_task;
@@ -306,15 +255,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
         if (lane == 2) { t = task + 1; want = strip + 1 < a.nstrips && last_col; }           // its right neighbour
         if (lane == 3) { t = task - a.nstrips; want = chunk > 0 && first_row; }              // the tile above
         if (lane == 4) { t = task + a.nstrips; want = chunk + 1 < a.nchunks && last_row; }   // the tile below
-        want = want && lane < 5;
-        if (want && atomicExch(&a.queued_out[t], 1u) == 0u) {  // first to wake tile t: append it to its list
-            const unsigned li = (unsigned)t / (unsigned)a.list_cap;
-            a.list_out[(size_t)li * a.list_cap + atomicAdd(&a.count_out[(size_t)li * kCounterStride], 1u)] = (uint32_t)t;
-        }
+        wake_push(a.wake, t, want && lane < 5);
     }
-    if (!listed) break;
-    g += nwaves;
-    if (g >= total) break;
+    if (!listed || !wake_next(cursor)) break;
     }  // task loop
 
     if (CHECK) {
@@ -549,7 +492,7 @@ void launch_sweep_2d_math(int math, int nblocks, hipStream_t stream, const Sweep
 template <bool CHECK, bool RB>
 void launch_sweep_2d_track(int math, int nblocks, hipStream_t stream, const Sweep2dArgs &a)
 {
-    if (a.list_out) launch_sweep_2d_math<CHECK, RB, true>(math, nblocks, stream, a);
+    if (a.wake.list_out) launch_sweep_2d_math<CHECK, RB, true>(math, nblocks, stream, a);
     else launch_sweep_2d_math<CHECK, RB, false>(math, nblocks, stream, a);
 }
 }  // namespace
@@ -578,25 +521,11 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, i
     a.ntasks = a.nstrips * nchunks;
     a.parity = parity < 0 ? 0 : (parity & 1);
     a.flags = sweep_flags();
-    a.list_in = nullptr;
-    a.count_in = nullptr;
-    a.list_out = nullptr;
-    a.count_out = a.count_zero = nullptr;
-    a.queued_in = a.queued_out = nullptr;
-    a.list_cap = 0;
     a.nchunks = nchunks;
+    const bool whole = row_begin == 0 && row_end == rows;
+    a.wake = wake_args(whole ? act : nullptr, (size_t)a.ntasks);
     int nblocks = (a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (act && act->list_out && row_begin == 0 && row_end == rows) {
-        a.list_in = act->list_in;
-        a.count_in = act->count_in;
-        a.list_out = act->list_out;
-        a.count_out = act->count_out;
-        a.count_zero = act->count_zero;
-        a.queued_in = act->queued_in;
-        a.queued_out = act->queued_out;
-        a.list_cap = (a.ntasks + kWakeLists - 1) / kWakeLists;
-        if (a.list_in) nblocks = sweep_2d_list_blocks((size_t)a.ntasks);  // persistent waves walking the lists
-    }
+    if (a.wake.list_in) nblocks = sweep_2d_list_blocks((size_t)a.ntasks);  // persistent waves walking the lists
     if (parity < 0) {
         if (delta_bits) launch_sweep_2d_track<true, false>(math, nblocks, stream, a);
         else launch_sweep_2d_track<false, false>(math, nblocks, stream, a);
@@ -626,13 +555,8 @@ hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw
     a.ntasks = a.nstrips * ((rows + rows_per_task - 1) / rows_per_task);
     a.parity = parity & 1;
     a.flags = sweep_flags();
-    a.list_in = nullptr;
-    a.count_in = nullptr;
-    a.list_out = nullptr;
-    a.count_out = a.count_zero = nullptr;
-    a.queued_in = a.queued_out = nullptr;
-    a.list_cap = 0;
     a.nchunks = 0;
+    a.wake = wake_args(nullptr, 0);
     const dim3 grid((a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
     if (math == kMathFast) hipLaunchKernelGGL((rb_fused2d_kernel<kMathFast>), grid, block, 0, stream, a);
     else if (math == kMathTraffic) hipLaunchKernelGGL((rb_fused2d_kernel<kMathTraffic>), grid, block, 0, stream, a);

@@ -4,17 +4,20 @@
 // :334-336, :367-369); the arithmetic follows its CPU sweep (libepic/src/harmonic/harmonic_cpu.cpp:81-133):
 // neighbours in the order x0-1, x0+1, x1-1, x1+1, x2-1, x2+1, constant log(6.0).
 //
-// Layout: u[x0][x1][x2] with x2 contiguous and padded to `pitch` (multiple of 64 floats).  A wave owns 256 x2-columns
+// Layout: u[x0][x1][x2] with x2 contiguous and padded to `pitch` (multiple of 256 floats).  A wave owns 256 x2-columns
 // (4 per lane, one dwordx4) of one x0-plane and marches along x1, keeping rows x1-1 / x1 / x1+1 of its plane in
 // registers; x2 neighbours are full-wave DPP shifts; the rows of planes x0-1 and x0+1 are loaded per step.  The four
 // waves of a workgroup sweep four consecutive planes of the same (x1-chunk, strip), so those extra rows are the
 // sibling waves' centre rows and are served by the CU's L1 / the XCD's L2 rather than HBM.
 // Mask: 1 bit per cell, 32 consecutive x2 cells per word.
+// Optional activity tracking (wake.h): a tile is one task -- 32 x1-rows x 256 x2-columns of one x0-plane; it reads its
+// own cells, the adjacent column / row of its four in-plane neighbours and the whole tile of the planes x0 - 1 and x0 + 1.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "cell_update.h"
 #include "kernels.h"
+#include "wake.h"
 
 namespace epic_hip {
 
@@ -34,24 +37,42 @@ struct Sweep3dArgs {
     int plane_begin, plane_end;
     int nstrips, nchunks, nplane_groups;
     int parity;  // red-black scheme only: currentIteration & 1
+    WakeArgs wake;  // TRACK kernels, whole-grid launches only
 };
 
 // RB = true: the reference's 3-D red-black half-sweep in place (in == out): cells with (x0 + x1 + x2 + currentIteration)
 // even are recomputed (harmonic_cpu.cpp:89-102), all six neighbours have the other colour.
-template <bool CHECK, int MATH, bool RB>
+template <bool CHECK, int MATH, bool RB, bool TRACK>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3dArgs a)
 {
-    MathTab lds = {};  // libm tables, one entry per lane (precise math only)
-    if (MATH == kMathPrecise) lds = math_tables_load();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int b = blockIdx.x;
-    const int strip = b % a.nstrips;
-    b /= a.nstrips;
-    const int chunk = b % a.nchunks;
-    const int pg = b / a.nchunks;
-    const int x0 = a.plane_begin + pg * kWavesPerBlock + wave;
-    if (x0 >= a.plane_end) return;  // wave-uniform
+    if (TRACK) wake_reset_next(a.wake);
+    const bool listed = TRACK && a.wake.list_in != nullptr;
+    WakeCursor cursor = {};
+    if (listed && !wake_begin(a.wake, lane, wave, kWavesPerBlock, cursor)) return;
+    MathTab lds = {};  // libm tables, one entry per lane (precise math only)
+    if (MATH == kMathPrecise) lds = math_tables_load();
+    float dmax = 0.0f;
+
+    for (;;) {  // one pass per task: exactly one unless the launch is list-driven
+    int strip, chunk, x0;
+    if (listed) {
+        int t = wake_tile(a.wake, cursor);  // tile id = (x0 * nchunks + chunk) * nstrips + strip
+        strip = t % a.nstrips;
+        t /= a.nstrips;
+        chunk = t % a.nchunks;
+        x0 = t / a.nchunks;
+    } else {
+        int b = blockIdx.x;
+        strip = b % a.nstrips;
+        b /= a.nstrips;
+        chunk = b % a.nchunks;
+        x0 = a.plane_begin + (b / a.nchunks) * kWavesPerBlock + wave;
+    }
+    if (x0 >= a.plane_end) break;  // wave-uniform
+    const int tile = (x0 * a.nchunks + chunk) * a.nstrips + strip;
+    if (TRACK && lane == 0) a.wake.queued_in[tile] = 0;
     const int r0 = chunk * kRowsPerTask;
     const int r1 = min(r0 + kRowsPerTask, a.m1);
 
@@ -88,7 +109,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3d
     float4 a1 = ld(pa, r0), b1 = ld(pb, r0);
     float hc = ldh(r0), h1 = ldh(r0 + 1);
     uint32_t mw = ldm(r0);
-    float dmax = 0.0f;
+    bool chg_any = false, chg_x = false, chg_w = false, chg_top = false, chg_bot = false;  // as in the 2-D kernel
 
     for (int r = r0; r < r1; ++r) {
         const float4 d2 = ld(pc, r + 2);
@@ -130,6 +151,15 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3d
             dmax = max2(dmax, fabsf(c.z - o.z));
             dmax = max2(dmax, fabsf(c.w - o.w));
         }
+        if (TRACK) {
+            const bool cx = f2u(o.x) != f2u(c.x), cw = f2u(o.w) != f2u(c.w);
+            const bool rc = cx | cw | (f2u(o.y) != f2u(c.y)) | (f2u(o.z) != f2u(c.z));
+            chg_any |= rc;
+            chg_x |= cx;
+            chg_w |= cw;
+            if (r == r0) chg_top = rc;
+            if (r == r1 - 1) chg_bot = rc;
+        }
         *reinterpret_cast<float4 *>(a.out + (size_t)x0 * plane + (size_t)r * pitch + col) = o;
 
         up = c; c = d1; d1 = d2;
@@ -137,6 +167,26 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3d
         hc = h1; h1 = h2;
         mw = mw2;
     }
+
+    if (TRACK) {
+        // wake the tiles that read what this task changed: itself, the in-plane neighbours across the edges that
+        // changed, and the same tile of the two neighbouring planes (every cell has an x0 - 1 and an x0 + 1 neighbour)
+        const bool any = __ballot(chg_any) != 0;
+        const bool first_col = (__ballot(chg_x) & 1ull) != 0, last_col = (__ballot(chg_w) >> 63) != 0;
+        const bool first_row = __ballot(chg_top) != 0, last_row = __ballot(chg_bot) != 0;
+        const int per_plane = a.nchunks * a.nstrips;
+        int t = tile;
+        bool want = any;
+        if (lane == 1) { t = tile - 1; want = strip > 0 && first_col; }
+        if (lane == 2) { t = tile + 1; want = strip + 1 < a.nstrips && last_col; }
+        if (lane == 3) { t = tile - a.nstrips; want = chunk > 0 && first_row; }
+        if (lane == 4) { t = tile + a.nstrips; want = chunk + 1 < a.nchunks && last_row; }
+        if (lane == 5) { t = tile - per_plane; want = x0 > 0 && any; }
+        if (lane == 6) { t = tile + per_plane; want = x0 + 1 < a.m0 && any; }
+        wake_push(a.wake, t, want && lane < 7);
+    }
+    if (!listed || !wake_next(cursor)) break;
+    }  // task loop
 
     if (CHECK) {
         dmax = wave_max(dmax);
@@ -173,18 +223,24 @@ __global__ void pack_mask_3d_kernel(const uint32_t *locked, int m0, int m1, int 
 }  // namespace
 
 namespace {
+template <bool CHECK, bool RB, bool TRACK>
+void launch_sweep_3d_track(int math, dim3 grid, dim3 block, hipStream_t stream, const Sweep3dArgs &a)
+{
+    if (math == kMathFast) hipLaunchKernelGGL((sweep3d_kernel<CHECK, kMathFast, RB, TRACK>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((sweep3d_kernel<CHECK, kMathPrecise, RB, TRACK>), grid, block, 0, stream, a);
+}
 template <bool CHECK, bool RB>
 void launch_sweep_3d_math(int math, dim3 grid, dim3 block, hipStream_t stream, const Sweep3dArgs &a)
 {
-    if (math == kMathFast) hipLaunchKernelGGL((sweep3d_kernel<CHECK, kMathFast, RB>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((sweep3d_kernel<CHECK, kMathPrecise, RB>), grid, block, 0, stream, a);
+    if (a.wake.list_out) launch_sweep_3d_track<CHECK, RB, true>(math, grid, block, stream, a);
+    else launch_sweep_3d_track<CHECK, RB, false>(math, grid, block, stream, a);
 }
 }  // namespace
 
 // parity < 0: Jacobi (in != out); parity 0 / 1: red-black half-sweep in place (in == out).
 hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, int m0, int m1, int pitch,
                            int plane_begin, int plane_end, int math, int parity, unsigned *delta_bits,
-                           hipStream_t stream)
+                           hipStream_t stream, const Activity *act)
 {
     if (plane_end <= plane_begin) return hipSuccess;
     if (pitch <= 0 || (pitch % 256) != 0 || m0 <= 0 || m1 <= 0 || plane_begin < 0 || plane_end > m0)
@@ -206,7 +262,10 @@ hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, i
     const long long nblocks = (long long)a.nstrips * a.nchunks * a.nplane_groups;
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
     a.parity = parity < 0 ? 0 : (parity & 1);
-    const dim3 grid((unsigned)nblocks), block(kWave * kWavesPerBlock);
+    const bool whole = plane_begin == 0 && plane_end == m0;
+    const size_t tiles = sweep_3d_tiles(m0, m1, pitch);
+    a.wake = wake_args(whole ? act : nullptr, tiles);
+    const dim3 grid(a.wake.list_in ? (unsigned)sweep_2d_list_blocks(tiles) : (unsigned)nblocks), block(kWave * kWavesPerBlock);
     if (parity < 0) {
         if (delta_bits) launch_sweep_3d_math<true, false>(math, grid, block, stream, a);
         else launch_sweep_3d_math<false, false>(math, grid, block, stream, a);

@@ -60,8 +60,9 @@ int epic_hip_set_math_mode(EpicHarmonicT *harmonic, int mode);
  * harmonic_complete_cpu.  Also EPIC_HIP_SCHEME=jacobi|redblack in the environment at initialisation. */
 int epic_hip_set_scheme(EpicHarmonicT *harmonic, int scheme);
 
-/* Activity tracking of the 2-D solver: 0 off, 1 on, 2 automatic (default: on for grids above 4 Mcell; also
- * EPIC_HIP_TRACK=0|1 in the environment at initialisation).  A tile of rows_per_task x 256 cells is recomputed in an
+/* Activity tracking: 0 off, 1 on, 2 automatic (default: on for grids above 4 Mcell; also
+ * EPIC_HIP_TRACK=0|1 in the environment at initialisation).  A tile (2-D: rows_per_task x 256 cells; 3-D: 32 x 256 cells
+ * of one plane) is recomputed in an
  * iteration only if the previous iteration changed a value it reads (one of its own cells or the adjacent row / column of
  * an edge neighbour); otherwise the update would reproduce the values already held, so fields, delta and iteration counts
  * are bit-identical with tracking on or off.  Every iteration builds the work lists of its successor, which then runs as
@@ -85,7 +86,7 @@ int epic_hip_compute_path_2d_gpu(EpicHarmonicT *harmonic, float x, float y, floa
                                  unsigned int maxLength, unsigned int *k, float **path);
 
 /* Diagnostic: the number of tiles the next iteration will recompute and the number of tiles (both 0 when tracking is
- * off or the grid is 3-D).  Synchronises the stream and copies the list counters to the host. */
+ * off).  Synchronises the stream and copies the list counters to the host. */
 int epic_hip_activity_stats(EpicHarmonicT *harmonic, unsigned long long *active_tiles, unsigned long long *tiles);
 /* The same with a separate output for the tiles due in the next iteration (with work lists both outputs report that
  * number: the tiles a launch changed are the tiles it lists, apart from woken neighbours); due_tiles may be NULL. */

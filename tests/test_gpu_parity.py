@@ -819,3 +819,39 @@ def test_random_shapes_both_schemes_equal_the_checker():
                 (lib.oracle_update_and_check if i == k - 1 else lib.oracle_update)(ct.byref(p.h))
         assert np.array_equal(h.u_array().ravel(), p.u), f"case {case}: {m}, {k} iterations, scheme {scheme}, rpt {rpt}"
         assert float(h.delta) == float(p.h.delta), f"case {case}: delta"
+
+
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_activity_tracking_3d_is_invisible_and_skips(scheme):
+    """3-D work lists: tiles are (plane, 32-row chunk, 256-column strip), woken across the six faces.  Same bits with
+    tracking on and off, against the checker, across a re-upload; and the lists really are short while the front is near
+    the goal."""
+    m = [36, 70, 300]
+    u0, locked = synthetic_grid(m, 41, 0.05)
+    lib = O.oracle()
+    fields = {}
+    for track in (1, 0):
+        h = make(m, u0, locked)
+        gpu_init(h)
+        assert E.epic_hip_set_scheme(h, scheme) == 0 and E.epic_hip_set_activity_tracking(h, track) == 0
+        assert E.epic_hip_update_n_gpu(h, 9, 1) in (0, 1)
+        if track:
+            act, tiles = _activity(h)
+            assert tiles == 36 * 3 * 2 and 0 < act < tiles, (act, tiles)
+        assert E.epic_hip_update_n_gpu(h, 60, 1) in (0, 1)
+        first = float(h.delta)
+        h.u_array().ravel()[:] = u0           # start over from the host copy: the lists must not survive it
+        h.currentIteration = 0
+        assert E.harmonic_update_model_gpu(h) == 0
+        assert E.epic_hip_update_n_gpu(h, 45, 1) in (0, 1)
+        assert E.harmonic_get_potential_values_gpu(h) == 0
+        fields[track] = (h.u_array().ravel().copy(), first, float(h.delta))
+        gpu_fini(h)
+    assert np.array_equal(fields[1][0], fields[0][0]) and fields[1][1:] == fields[0][1:]
+    p = O.Problem(m, u0, locked)
+    if scheme == 0:
+        assert lib.oracle_jacobi_run(ct.byref(p.h), 45) == 0
+    else:
+        for i in range(45):
+            (lib.oracle_update_and_check if i == 44 else lib.oracle_update)(ct.byref(p.h))
+    assert np.array_equal(fields[1][0], p.u) and fields[1][2] == float(p.h.delta)
