@@ -81,9 +81,10 @@ __constant__ const double kLogTab[32] = {
 // The tables live in registers, one entry per lane, and are fetched with ds_bpermute_b32 (the LDS crossbar, no LDS
 // memory, no staging pass or barrier at kernel start): lane L holds exp entry L & 31 (2 dwords) and log entry L (4
 // dwords).  The log table is expanded over the binade index k = 0..3 (arguments in [0.7, 11.2) cover the sums of 4 or 6
-// terms <= 1 with one term == 1): entry 16 k + i = {invc_i, logc_i + k ln2}, so the kernel needs neither k nor a
-// multiply.  ds_bpermute reads the SOURCE lane's register, so every lane of the wave must be active where it is used:
-// the kernels keep all 64 lanes live (pitch is a multiple of 256 floats).
+// terms <= 1 with one term == 1): entry 16 k + i = {invc_i 2^-k, logc_i + k ln2}, so the kernel needs neither k, nor a
+// multiply, nor the normalised argument z = s 2^-k (s invc_i 2^-k is the same real number as z invc_i, so the fma that
+// forms r rounds alike).  ds_bpermute reads the SOURCE lane's register, so every lane of the wave must be active where
+// it is used: the kernels keep all 64 lanes live (pitch is a multiple of 256 floats).
 struct MathTab {
     int e_lo, e_hi;          // 2^((L & 31)/32)
     int i_lo, i_hi;          // invc of log entry L
@@ -95,7 +96,7 @@ __device__ __forceinline__ MathTab math_tables_load()
     const int lane = threadIdx.x & 63;
     const uint64_t e = kExpTab[lane & 31] + ((uint64_t)(lane & 31) << 47);
     const int k = lane >> 4, i = lane & 15;
-    const uint64_t inv = __builtin_bit_cast(uint64_t, kLogTab[2 * i]);
+    const uint64_t inv = __builtin_bit_cast(uint64_t, __builtin_ldexp(kLogTab[2 * i], -k));  // exact: a power of two
     const uint64_t y0 = __builtin_bit_cast(uint64_t, kLogTab[2 * i + 1] + (double)k * 0x1.62e42fefa39efp-1);
     MathTab t;
     t.e_lo = (int)(uint32_t)e; t.e_hi = (int)(uint32_t)(e >> 32);
@@ -138,13 +139,12 @@ __device__ __forceinline__ float precise_exp(float x, const MathTab &tab)
 // r = z invc - 1, ln s = log1p(r) + logc + k ln2 with a cubic for log1p, all in double.
 __device__ __forceinline__ float precise_ln(float sf, const MathTab &tab)
 {
-    const uint32_t ix = __builtin_bit_cast(uint32_t, sf);
-    const uint32_t tmp = ix - 0x3f330000u;
-    const int addr = (int)((tmp >> 17) & 0xfcu);     // 4 * (16 k + i): lane of the table entry
-    const uint32_t iz = ix - (tmp & 0xff800000u);    // z = s / 2^k
+    const uint32_t tmp = __builtin_bit_cast(uint32_t, sf) - 0x3f330000u;
+    // lane of the table entry = 16 k + i = bits 24..19 of tmp; the permute takes the lane from address bits 7..2 and
+    // ignores the rest, so the shifted word is the address as it stands (no mask)
+    const int addr = (int)(tmp >> 17);
     const double invc = bperm_f64(addr, tab.i_lo, tab.i_hi), y0 = bperm_f64(addr, tab.y_lo, tab.y_hi);
-    const double z = (double)__builtin_bit_cast(float, iz);
-    const double r = __builtin_fma(z, invc, -1.0);
+    const double r = __builtin_fma((double)sf, invc, -1.0);  // = z invc_i - 1 with z = s 2^-k, see MathTab
     const double r2 = r * r;
     double y = __builtin_fma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);
     y = __builtin_fma(-0x1.00ea348b88334p-2, r2, y);
@@ -229,6 +229,33 @@ __device__ __forceinline__ v2f df_pair_update_2d(v2f up, v2f dn, v2f lf, v2f rt,
     return v2f{(float)((double)t.x - kLn4), (float)((double)t.y - kLn4)};
 }
 
+// ---- selects on lane masks held in SGPR pairs ----------------------------------------------------------------------
+// Measured on gfx950 (tools/ubench_alu2.hip, profiles/r01_ubench_alu2.txt): v_cndmask_b32 in its VOP2 form (mask in
+// VCC) issues in ~22 cycles unless it directly follows the compare that wrote VCC; the VOP3 form with the mask in an
+// ordinary SGPR pair issues in 4.3 like any other VALU instruction.  The selects of the update are therefore written
+// out in the VOP3 form, on masks that come from v_cmp (ballot of a comparison) and are combined with scalar s_or.
+typedef uint64_t lmask;
+__device__ __forceinline__ lmask lanes_eq(float a, float b) { return __builtin_amdgcn_ballot_w64(a == b); }
+__device__ __forceinline__ lmask lanes_bit(uint32_t w, uint32_t bit) { return __builtin_amdgcn_ballot_w64((w & bit) != 0u); }
+__device__ __forceinline__ float sel(lmask m, float if_set, float if_clear)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+    return r;
+}
+__device__ __forceinline__ float sel_one_or(lmask m, float if_clear)  // m ? 1.0f : if_clear
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, 1.0, %2" : "=v"(r) : "v"(if_clear), "s"(m));
+    return r;
+}
+__device__ __forceinline__ float sel_or_one(lmask m, float if_set)  // m ? if_set : 1.0f
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, 1.0, %1, %2" : "=v"(r) : "v"(if_set), "s"(m));
+    return r;
+}
+
 template <int MATH>
 __device__ __forceinline__ float m_exp(float x, const MathTab &lds)
 {
@@ -248,21 +275,25 @@ __device__ __forceinline__ float cell_update_2d(float up, float down, float left
     if (MATH == kMathPrecise) {
         // One of the four terms is expf(0) = 1 exactly -- the neighbour that IS the maximum (the first one, if several
         // tie: the others go through the exp and come out as 1 as well).  Evaluating only the other three saves one of
-        // the four f64 exps (10 of the 51 four-cycle instructions per cell) for ten selects and compares.  With
-        // P_k = "the maximum is among the first k + 1 neighbours", the three arguments in order are
-        //   w0 = P0 ? down : up,  w1 = P1 ? left : down,  w2 = P2 ? right : left
-        // and the reference's sum ((e_up + e_down) + e_left) + e_right has its 1 at position p:
-        //   p = 0, 1: (1 + E0) + E1 + E2   (the first add commutes, so the two cases coincide)
-        //   p = 2   : (E0 + E1) + 1 + E2        p = 3: (E0 + E1) + E2 + 1
-        // i.e. E0 + (P1 ? 1 : E1), then + (P1 ? E1 : P2 ? 1 : E2), then + (P2 ? E2 : 1) -- the same f32 additions of
-        // the same values in the same order as the four-exp form, hence the same bits.
-        const bool p0 = up == mx, p1 = p0 | (down == mx), p2 = p1 | (left == mx);
-        const float e0 = precise_exp((p0 ? down : up) - mx, lds);
-        const float e1 = precise_exp((p1 ? left : down) - mx, lds);
-        const float e2 = precise_exp((p2 ? right : left) - mx, lds);
-        float s = e0 + (p1 ? 1.0f : e1);
-        s = s + (p1 ? e1 : (p2 ? 1.0f : e2));
-        s = s + (p2 ? e2 : 1.0f);
+        // the four f64 exps (10 of the 51 four-cycle instructions per cell) for a handful of selects and compares.
+        // The reference's sum is ((e_up + e_down) + e_left) + e_right; its first addition commutes, so the vertical
+        // pair may be taken as hv = max(up, down), lv = min(up, down): e_lv is always evaluated, and with
+        //   P = "hv is the maximum",  Q = "left is the maximum" (else right is)
+        // the other two arguments are  b = P ? left : hv,  c = P | Q ? right : left,  and the sum reads
+        //   P      : ((1 + E_lv) + E_b) + E_c        (b = left, c = right)
+        //   !P,  Q : ((E_b + E_lv) + 1) + E_c        (b = hv,   c = right)
+        //   !P, !Q : ((E_b + E_lv) + E_c) + 1        (b = hv,   c = left)
+        // i.e. E_lv + (P ? 1 : E_b), then + (P ? E_b : Q ? 1 : E_c), then + (P | Q ? E_c : 1) -- the same f32 additions
+        // of the same values in the same order as the four-exp form, hence the same bits.
+        const float hv = max2(up, down), lv = __builtin_fminf(up, down);
+        mx = max2(max2(hv, left), right);
+        const lmask P = lanes_eq(hv, mx), Q = lanes_eq(left, mx), PQ = P | Q;
+        const float ea = precise_exp(lv - mx, lds);
+        const float eb = precise_exp(sel(P, left, hv) - mx, lds);
+        const float ec = precise_exp(sel(PQ, right, left) - mx, lds);
+        float s = ea + sel_one_or(P, eb);
+        s = s + sel(P, eb, sel_one_or(Q, ec));
+        s = s + sel_or_one(PQ, ec);
         const float t = mx + precise_ln(s, lds);
         return (float)((double)t - kLn4);
     }

@@ -114,27 +114,39 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
     const int r0 = a.row_begin + chunk * a.rows_per_task;
     const int r1 = min(r0 + a.rows_per_task, a.row_end);
 
-    const int col0 = strip * kStripCols;
+    const int col0 = strip * kStripCols;  // pitch % 256 == 0: every lane of every strip is in bounds (DPP / bpermute want all lanes live)
     const int col = col0 + lane * kColsPerLane;
-    const int lcol = col;  // pitch % 256 == 0: every lane of every strip is in bounds (DPP / bpermute want all lanes live)
-    const int hcol = (lane == 0) ? max(col0 - 1, 0) : min(col0 + kStripCols, a.pitch - 1);
-    const bool edge_lane = (lane == 0) | (lane == kWave - 1);
+
+    // Addressing costs no VALU instruction: rows are reached through buffer descriptors (base = a few rows above the
+    // task, so that byte offsets stay far below 4 GiB on any grid) with the lane part of the address in a VGPR that
+    // never changes (lane * 16 bytes) and the row / strip part in an SGPR (buffer_load ... offen with soffset).
+    const int rlo = max(r0 - 8, 0);  // the march touches rows r0 - 6 .. r1 + 5 at most (prefetch past either end)
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + (size_t)rlo * pitch), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (size_t)rlo * pitch), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc((void *)(a.maskw + (size_t)(rlo >> 3) * qpitch), 0, 0x7fffffff, 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u, lane4 = (unsigned)lane * 4u;
+    typedef unsigned vu4 __attribute__((ext_vector_type(4)));
+    auto row_off = [&](int r) -> unsigned { return (unsigned)((r - rlo) * a.pitch + col0) * 4u; };  // r already clamped
 
     auto ld = [&](int r) -> float4 {
         r = min(max(r, 0), rlast);
-        const float *row = a.in + (size_t)r * pitch;
-        return *reinterpret_cast<const float4 *>(row + lcol);
+        const vu4 q = __builtin_amdgcn_raw_buffer_load_b128(rin, lane16, row_off(r), 0);
+        return make_float4(u2f(q.x), u2f(q.y), u2f(q.z), u2f(q.w));
     };
-    auto ldh = [&](int r) -> float {  // lane 0: u[r][col0-1]; lane 63: u[r][col0+256]
-        float h = 0.0f;
+    // The two strip-edge values u[r][col0 - 1] and u[r][col0 + 256] are wave-uniform addresses: scalar loads (the
+    // sweep never writes what it reads through them -- Jacobi reads u_in only; red-black reads cells of the other
+    // colour -- and every kernel launch starts with an invalidated scalar cache).
+    typedef const __attribute__((address_space(4))) float cfloat;
+    const int hcol_l = max(col0 - 1, 0), hcol_r = min(col0 + kStripCols, a.pitch - 1);
+    struct Halo { float l, r; };
+    auto ldh = [&](int r) -> Halo {
         r = min(max(r, 0), rlast);
-        const float *row = a.in + (size_t)r * pitch;
-        if (edge_lane) h = row[hcol];
-        return h;
+        cfloat *row = (cfloat *)(a.in + (size_t)r * pitch);
+        return Halo{row[hcol_l], row[hcol_r]};
     };
     auto ldm = [&](int g) -> uint32_t {
-        const uint32_t *row = a.maskw + (size_t)min(g, glast) * qpitch;
-        return row[lcol >> 2];
+        g = min(g, glast);
+        return __builtin_amdgcn_raw_buffer_load_b32(rmask, lane4, (unsigned)((g - (rlo >> 3)) * qpitch + (col0 >> 2)) * 4u, 0);
     };
 
     // March direction.  Vertically adjacent tasks share two halo rows; if every task marched downwards, task k would
@@ -152,9 +164,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
     uint32_t mw = ldm(gcur), mw_next = ldm(max(gcur + dir, 0));
 
     // One row: up / c / dn are rows r-1, r, r+1 of u_in, h the two strip-edge values of row r.
-    auto row_step = [&](int r, const float4 &up, const float4 &c, const float4 &dn, float h) {
-        const float lf = wave_from_left(c.w, h);   // u[r][col-1]
-        const float rt = wave_from_right(c.x, h);  // u[r][col+4]
+    auto row_step = [&](int r, const float4 &up, const float4 &c, const float4 &dn, const Halo &h) {
+        const float lf = wave_from_left(c.w, h.l);   // u[r][col-1]
+        const float rt = wave_from_right(c.x, h.r);  // u[r][col+4]
         if ((r >> 3) != gcur) {  // scalar branch: crossed into the next 8-row mask group
             gcur = r >> 3;
             mw = mw_next;
@@ -173,8 +185,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
                     ny = cell_update_2d<MATH>(up.y, dn.y, c.x, c.z, lds);
                     nw = cell_update_2d<MATH>(up.w, dn.w, c.z, rt, lds);
                 }
-                o.y = (nib & 2u) ? c.y : ny;
-                o.w = (nib & 8u) ? c.w : nw;
+                o.y = sel(lanes_bit(nib, 2u), c.y, ny);
+                o.w = sel(lanes_bit(nib, 8u), c.w, nw);
             } else {                           // even columns (.x, .z)
                 float nx, nz;
                 if (MATH == kMathDf32) {
@@ -184,8 +196,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
                     nx = cell_update_2d<MATH>(up.x, dn.x, lf, c.y, lds);
                     nz = cell_update_2d<MATH>(up.z, dn.z, c.y, c.w, lds);
                 }
-                o.x = (nib & 1u) ? c.x : nx;
-                o.z = (nib & 4u) ? c.z : nz;
+                o.x = sel(lanes_bit(nib, 1u), c.x, nx);
+                o.z = sel(lanes_bit(nib, 4u), c.z, nz);
             }
         } else if (MATH == kMathDf32) {  // two cells per packed instruction
             const v2f a = df_pair_update_2d(v2f{up.x, up.y}, v2f{dn.x, dn.y}, v2f{lf, c.x}, v2f{c.y, c.z}, ldsf);
@@ -198,10 +210,10 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
             o.w = cell_update_2d<MATH>(up.w, dn.w, c.z, rt, lds);
         }
         if (!RB) {
-            o.x = (nib & 1u) ? c.x : o.x;
-            o.y = (nib & 2u) ? c.y : o.y;
-            o.z = (nib & 4u) ? c.z : o.z;
-            o.w = (nib & 8u) ? c.w : o.w;
+            o.x = sel(lanes_bit(nib, 1u), c.x, o.x);
+            o.y = sel(lanes_bit(nib, 2u), c.y, o.y);
+            o.z = sel(lanes_bit(nib, 4u), c.z, o.z);
+            o.w = sel(lanes_bit(nib, 8u), c.w, o.w);
         }
         if (CHECK) {
             dmax = max2(dmax, fabsf(c.x - o.x));
@@ -218,29 +230,34 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
             if (r == r0) chg_top = rc;      // scalar conditions
             if (r == r1 - 1) chg_bot = rc;
         }
-        float *orow = a.out + (size_t)r * pitch;
-        if (a.flags & 2) __builtin_nontemporal_store(vf4{o.x, o.y, o.z, o.w}, reinterpret_cast<vf4 *>(orow + col));
-        else *reinterpret_cast<float4 *>(orow + col) = o;
+        // non-temporal: the row is not read again before the next sweep (traffic-only build 115.6 -> 96.6 us with it)
+        __builtin_amdgcn_raw_buffer_store_b128(vu4{f2u(o.x), f2u(o.y), f2u(o.z), f2u(o.w)}, rout, lane16, row_off(r), 2 /*nt*/);
     };
 
     // Software pipeline, rotated by hand over a 4-row register ring so that no register moves (and hence no
     // vmcnt(0)) sit between a load and its use two rows later: while row r is computed, rows r+1 and r+2
-    // are already in flight.
+    // are already in flight.  Whole groups of four rows run without an exit test in between (a loop with three breaks
+    // costs four v_readfirstlane per row for the exit values alone); the ragged rest -- and the one-row tasks of the
+    // small grids -- go through a plain loop.
     auto row_at = [&](int i) { return rfirst + dir * i; };  // i-th row of the march
-    float4 q0 = ld(row_at(-1)), q1 = ld(row_at(0)), q2 = ld(row_at(1)), q3;
-    float h1 = ldh(row_at(0)), h2 = ldh(row_at(1)), h3, h0;
-    for (int i = 0; i < nrows; i += 4) {
-        q3 = ld(row_at(i + 2)); h3 = ldh(row_at(i + 2));
-        row_step(row_at(i), q0, q1, q2, h1);
-        if (i + 1 >= nrows) break;
-        q0 = ld(row_at(i + 3)); h0 = ldh(row_at(i + 3));
-        row_step(row_at(i + 1), q1, q2, q3, h2);
-        if (i + 2 >= nrows) break;
-        q1 = ld(row_at(i + 4)); h1 = ldh(row_at(i + 4));
-        row_step(row_at(i + 2), q2, q3, q0, h3);
-        if (i + 3 >= nrows) break;
-        q2 = ld(row_at(i + 5)); h2 = ldh(row_at(i + 5));
-        row_step(row_at(i + 3), q3, q0, q1, h0);
+    const int nfull = nrows & ~3;
+    if (nfull > 0) {
+        float4 q0 = ld(row_at(-1)), q1 = ld(row_at(0)), q2 = ld(row_at(1)), q3;
+        Halo h1 = ldh(row_at(0)), h2 = ldh(row_at(1)), h3, h0;
+        for (int i = 0; i < nfull; i += 4) {
+            q3 = ld(row_at(i + 2)); h3 = ldh(row_at(i + 2));
+            row_step(row_at(i), q0, q1, q2, h1);
+            q0 = ld(row_at(i + 3)); h0 = ldh(row_at(i + 3));
+            row_step(row_at(i + 1), q1, q2, q3, h2);
+            q1 = ld(row_at(i + 4)); h1 = ldh(row_at(i + 4));
+            row_step(row_at(i + 2), q2, q3, q0, h3);
+            q2 = ld(row_at(i + 5)); h2 = ldh(row_at(i + 5));
+            row_step(row_at(i + 3), q3, q0, q1, h0);
+        }
+    }
+    for (int i = nfull; i < nrows; ++i) {
+        const int r = row_at(i);
+        row_step(r, ld(r - dir), ld(r), ld(r + dir), ldh(r));
     }
 
     if (TRACK) {
@@ -341,8 +358,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
                 ny = cell_update_2d<MATH>(up.y, dn.y, c.x, c.z, lds);
                 nw = cell_update_2d<MATH>(up.w, dn.w, c.z, rt, lds);
             }
-            o.y = (nib & 2u) ? c.y : ny;
-            o.w = (nib & 8u) ? c.w : nw;
+            o.y = sel(lanes_bit(nib, 2u), c.y, ny);
+            o.w = sel(lanes_bit(nib, 8u), c.w, nw);
         } else {
             const float lf = wave_from_left(c.w, 0.0f);
             float nx, nz;
@@ -353,8 +370,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
                 nx = cell_update_2d<MATH>(up.x, dn.x, lf, c.y, lds);
                 nz = cell_update_2d<MATH>(up.z, dn.z, c.y, c.w, lds);
             }
-            o.x = (nib & 1u) ? c.x : nx;
-            o.z = (nib & 4u) ? c.z : nz;
+            o.x = sel(lanes_bit(nib, 1u), c.x, nx);
+            o.z = sel(lanes_bit(nib, 4u), c.z, nz);
         }
         return o;
     };
