@@ -78,30 +78,34 @@ __constant__ const double kLogTab[32] = {
     0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2,  0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2,
 };
 
-// The tables live in registers, one entry per lane, and are fetched with ds_bpermute_b32 (the LDS crossbar, no LDS
-// memory, no staging pass or barrier at kernel start): lane L holds exp entry L & 31 (2 dwords) and log entry L (4
-// dwords).  The log table is expanded over the binade index k = 0..3 (arguments in [0.7, 11.2) cover the sums of 4 or 6
-// terms <= 1 with one term == 1): entry 16 k + i = {invc_i 2^-k, logc_i + k ln2}, so the kernel needs neither k, nor a
+// Where the tables live.  exp: in registers, one entry per lane (lane L holds 2^((L & 31)/32) as two dwords), fetched
+// with ds_bpermute_b32 through the LDS crossbar: no LDS memory, and the byte address is just k << 2.  ds_bpermute reads
+// the SOURCE lane's register, so every lane of the wave must be active where it is used: the kernels keep all 64 lanes
+// live (pitch is a multiple of 256 floats).  log: in LDS, 64 entries of 16 bytes read with one ds_read_b128.  A
+// ds_bpermute costs 24 cycles per wave per SIMD on gfx950, a ds_read_b128 16 (tools/ubench_alu2.hip), and the four
+// permutes a register-resident log entry needs made the crossbar the co-limiter of the kernel next to the VALU.
+// The log table is expanded over the binade index k = 0..3 (arguments in [0.7, 11.2) cover the sums of 4 or 6 terms
+// <= 1 with one term == 1): entry 16 k + i = {invc_i 2^-k, logc_i + k ln2}, so the kernel needs neither k, nor a
 // multiply, nor the normalised argument z = s 2^-k (s invc_i 2^-k is the same real number as z invc_i, so the fma that
-// forms r rounds alike).  ds_bpermute reads the SOURCE lane's register, so every lane of the wave must be active where
-// it is used: the kernels keep all 64 lanes live (pitch is a multiple of 256 floats).
+// forms r rounds alike).
 struct MathTab {
-    int e_lo, e_hi;          // 2^((L & 31)/32)
-    int i_lo, i_hi;          // invc of log entry L
-    int y_lo, y_hi;          // logc + k ln2 of log entry L
+    int e_lo, e_hi;      // 2^((L & 31)/32)
+    const double2 *ln;   // LDS: {invc, logc + k ln2} x 64
 };
+constexpr int kLnTabEntries = 64;
 
-__device__ __forceinline__ MathTab math_tables_load()
+// Call from every thread of the workgroup (it holds a barrier); `ln_lds` = kLnTabEntries double2 of LDS.
+__device__ __forceinline__ MathTab math_tables_load(double2 *ln_lds)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t e = kExpTab[lane & 31] + ((uint64_t)(lane & 31) << 47);
     const int k = lane >> 4, i = lane & 15;
-    const uint64_t inv = __builtin_bit_cast(uint64_t, __builtin_ldexp(kLogTab[2 * i], -k));  // exact: a power of two
-    const uint64_t y0 = __builtin_bit_cast(uint64_t, kLogTab[2 * i + 1] + (double)k * 0x1.62e42fefa39efp-1);
+    if (threadIdx.x < kLnTabEntries)
+        ln_lds[lane] = double2{__builtin_ldexp(kLogTab[2 * i], -k) /* exact */, kLogTab[2 * i + 1] + (double)k * 0x1.62e42fefa39efp-1};
+    __syncthreads();
     MathTab t;
     t.e_lo = (int)(uint32_t)e; t.e_hi = (int)(uint32_t)(e >> 32);
-    t.i_lo = (int)(uint32_t)inv; t.i_hi = (int)(uint32_t)(inv >> 32);
-    t.y_lo = (int)(uint32_t)y0; t.y_hi = (int)(uint32_t)(y0 >> 32);
+    t.ln = ln_lds;
     return t;
 }
 
@@ -140,10 +144,9 @@ __device__ __forceinline__ float precise_exp(float x, const MathTab &tab)
 __device__ __forceinline__ float precise_ln(float sf, const MathTab &tab)
 {
     const uint32_t tmp = __builtin_bit_cast(uint32_t, sf) - 0x3f330000u;
-    // lane of the table entry = 16 k + i = bits 24..19 of tmp; the permute takes the lane from address bits 7..2 and
-    // ignores the rest, so the shifted word is the address as it stands (no mask)
-    const int addr = (int)(tmp >> 17);
-    const double invc = bperm_f64(addr, tab.i_lo, tab.i_hi), y0 = bperm_f64(addr, tab.y_lo, tab.y_hi);
+    // table entry 16 k + i = bits 24..19 of tmp; its byte offset is that times 16
+    const double2 ent = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(tab.ln) + ((tmp >> 15) & 0x3f0u));
+    const double invc = ent.x, y0 = ent.y;
     const double r = __builtin_fma((double)sf, invc, -1.0);  // = z invc_i - 1 with z = s 2^-k, see MathTab
     const double r2 = r * r;
     double y = __builtin_fma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);

@@ -63,7 +63,17 @@ hipError_t launch_follow_paths_2d(const float *u, const uint32_t *maskw, int row
 
 // rows are padded to whole wave-strips (256 floats = 1 KiB): every lane of every wave is in bounds, always
 inline int pitch_for_cols(int cols) { return (cols + 255) / 256 * 256; }
-inline size_t mask_words_2d(int rows, int pitch) { return (size_t)((rows + 7) / 8) * (size_t)(pitch / 4); }
+// 2-D mask layout (device-private): LANE MASKS.  For every row and every 256-column strip four 64-bit words, word j
+// holding in bit L the lock of cell (row, 256 strip + 4 L + j) -- i.e. exactly the SGPR-pair operand v_cndmask wants
+// for the j-th of the four cells lane L of the sweep owns.  A wave fetches the 32 bytes of its row with ONE scalar
+// load; no VALU instruction is spent on the mask except the select itself.  1 bit per cell, 32 B per (row, strip).
+inline size_t mask_words_2d(int rows, int pitch) { return (size_t)rows * (size_t)(pitch / 256) * 8u; }
+// 32-bit word and bit of cell (r, c) in that layout (little-endian halves of the 64-bit lane masks)
+__host__ __device__ inline size_t mask_word_2d(unsigned r, unsigned c, unsigned pitch)
+{
+    return (((size_t)r * (pitch >> 8) + (c >> 8)) * 4u + (c & 3u)) * 2u + ((c >> 7) & 1u);
+}
+__host__ __device__ inline unsigned mask_bit_2d(unsigned c) { return (c >> 2) & 31u; }
 
 // ---- 3-D (kernels_3d.hip) -------------------------------------------------------------------
 hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, int m0, int m1, int pitch,

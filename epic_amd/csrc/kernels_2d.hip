@@ -10,9 +10,13 @@
 //    4 consecutive columns as one dwordx4, so a wave-row is one fully coalesced 1 KiB load and 1 KiB store.
 //    The three live rows (up / centre / down) stay in registers while marching, so vertical neighbours cost
 //    no extra traffic; horizontal neighbours inside the strip move with one full-wave DPP shift each
-//    (v_mov_b32_dpp wave_shr:1 / wave_shl:1); the two strip-edge columns are one 2-lane halo load per row.
-//  * The obstacle/goal mask is bit-packed and tiled (8 rows x 4 columns per dword) so a lane fetches its
-//    mask once per 8 rows: +0.125 B/cell instead of the reference's +4 B/cell.
+//    (v_mov_b32_dpp wave_shr:1 / wave_shl:1); the two strip-edge columns are wave-uniform: two scalar loads per row.
+//  * The obstacle/goal mask is bit-packed as LANE MASKS (kernels.h): per row and strip four 64-bit words that are
+//    the SGPR-pair operands of the four v_cndmask of a row, fetched with one s_load_dwordx8: +0.125 B/cell instead
+//    of the reference's +4 B/cell, and no VALU instruction besides the select itself.
+//  * Rows are addressed through buffer descriptors with the row / strip part of the address in an SGPR: loads and
+//    stores cost no VALU instruction either.  The kernel is bound by VALU issue, so every instruction that is not
+//    arithmetic of the update was moved to the scalar unit (68 VALU instructions per cell, 41 of them f64).
 //  * max |u_new - u_old| is reduced in registers, across the wave with shuffles, and leaves the wave as a
 //    single atomicMax on the float's bit pattern (valid order for non-negative floats).  No second kernel.
 //  * blockIdx is remapped so that each XCD sweeps a contiguous band of rows: vertically adjacent tasks share
@@ -23,7 +27,8 @@
 //
 // Roofline: the memory side is HBM-bound (8 B per cell, 97 us per 8192^2 sweep with trivial arithmetic).  With the
 // fast math (v_exp_f32 / v_log_f32) the kernel stays there; with the default precise math (expf / logf bit-identical to
-// glibc, evaluated in f64) it is bound by VALU issue: 41 four-cycle instructions per cell.
+// glibc, evaluated in f64) it is bound by VALU issue: 41 f64 / conversion instructions per cell plus 27 others at ~4
+// cycles per wave each.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -46,7 +51,7 @@ static_assert(kWakeLists == kWave * kWavesPerBlock, "one thread per work list re
 struct Sweep2dArgs {
     const float *in;
     float *out;
-    const uint32_t *maskw;  // tiled bits: word (r>>3, c>>2), bit 4*(r&7) + (c&3); 1 = locked
+    const uint32_t *maskw;  // lane masks (kernels.h): per row and strip four 64-bit words, bit L of word j = cell 4 L + j; 1 = locked
     unsigned *delta_bits;   // max |du| as float bits (atomicMax), used when CHECK
     int rows;               // rows of the (local) grid, including ghost rows in slab mode
     int pitch;              // floats per row, multiple of 256
@@ -55,7 +60,7 @@ struct Sweep2dArgs {
     int nstrips;            // ceil(pitch / 256)
     int ntasks;             // nstrips * nchunks
     int parity;             // red-black scheme only: currentIteration & 1 (which colour this half-sweep updates)
-    int flags;              // tuning, never results: bit 0 = odd row-chunks march upwards, bit 1 = non-temporal stores
+    int flags;              // tuning, never results: bit 0 = odd row-chunks march upwards, bit 1 = non-temporal stores (fused kernel)
     // Activity tracking (full-grid launches only; TRACK kernels): wake.h.  A tile is one task (rows_per_task x 256
     // cells); it reads its own cells, the last column of its left neighbour, the first column of its right neighbour,
     // the last row of the tile above and the first row of the tile below (5-point stencil).
@@ -76,16 +81,24 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nblk)
 // cells with (row + col + currentIteration) odd are recomputed (harmonic_cpu.cpp:46-51), from neighbours that all have
 // the other colour and therefore do not change during this launch -- no ordering between waves is needed, and with
 // the precise math the result is the reference CPU solver's, bit for bit, half-sweep for half-sweep.
-// (68 VGPRs = 7 waves per SIMD with the precise math, untracked.  Forcing more waves per SIMD with amdgpu_waves_per_eu
-// spills and is slower, profiles/r01_experiments.txt.)
+// (68 VGPRs = 7 waves per SIMD with the precise math, untracked; 6, 7 or 8 waves per SIMD time the same,
+// profiles/r01_experiments.txt.)
+#ifdef EPIC_SWEEP_WAVES  // experiment knob (make EXTRA=-DEPIC_SWEEP_WAVES=8): pin the waves per SIMD of the sweep
+#define EPIC_SWEEP_OCC __attribute__((amdgpu_waves_per_eu(EPIC_SWEEP_WAVES, EPIC_SWEEP_WAVES)))
+#else
+#define EPIC_SWEEP_OCC
+#endif
 template <bool CHECK, int MATH, bool RB, bool TRACK>
-__global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2dArgs a)
+__global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d_kernel(Sweep2dArgs a)
 {
     __shared__ __attribute__((aligned(16))) float ldsf[kDfLdsFloats];  // df32 tables (df32 math only)
     if (MATH == kMathDf32) {
         df_tables_to_lds(ldsf);
         __syncthreads();
     }
+    __shared__ double2 ln_lds[kLnTabEntries];  // glibc's logf table (precise math only)
+    MathTab lds = {};  // libm tables (precise math only): exp entries in registers, log entries in LDS
+    if (MATH == kMathPrecise) lds = math_tables_load(ln_lds);
     const int lane = threadIdx.x & (kWave - 1);
     // wave-uniform quantities are forced into SGPRs: the row loop, its addresses and branches are scalar
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -94,14 +107,10 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
     const bool listed = TRACK && a.wake.list_in != nullptr;
     WakeCursor cursor = {};
     if (listed && !wake_begin(a.wake, lane, wave, kWavesPerBlock, cursor)) return;
-    MathTab lds = {};  // libm tables, one entry per lane (precise math only)
-    if (MATH == kMathPrecise) lds = math_tables_load();
     float dmax = 0.0f;
     typedef float vf4 __attribute__((ext_vector_type(4)));
     const int rlast = a.rows - 1;
     const size_t pitch = (size_t)a.pitch;
-    const int qpitch = a.pitch >> 2;  // mask words per 8-row group
-    const int glast = rlast >> 3;
 
     for (;;) {  // one pass per task: exactly one unless the launch is list-driven
     int task;
@@ -123,8 +132,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
     const int rlo = max(r0 - 8, 0);  // the march touches rows r0 - 6 .. r1 + 5 at most (prefetch past either end)
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + (size_t)rlo * pitch), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (size_t)rlo * pitch), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc((void *)(a.maskw + (size_t)(rlo >> 3) * qpitch), 0, 0x7fffffff, 0x00020000);
-    const unsigned lane16 = (unsigned)lane * 16u, lane4 = (unsigned)lane * 4u;
+    const unsigned lane16 = (unsigned)lane * 16u;
     typedef unsigned vu4 __attribute__((ext_vector_type(4)));
     auto row_off = [&](int r) -> unsigned { return (unsigned)((r - rlo) * a.pitch + col0) * 4u; };  // r already clamped
 
@@ -133,20 +141,19 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
         const vu4 q = __builtin_amdgcn_raw_buffer_load_b128(rin, lane16, row_off(r), 0);
         return make_float4(u2f(q.x), u2f(q.y), u2f(q.z), u2f(q.w));
     };
-    // The two strip-edge values u[r][col0 - 1] and u[r][col0 + 256] are wave-uniform addresses: scalar loads (the
-    // sweep never writes what it reads through them -- Jacobi reads u_in only; red-black reads cells of the other
-    // colour -- and every kernel launch starts with an invalidated scalar cache).
+    // What a row needs besides its three rows of u is wave-uniform and arrives through SCALAR loads: the two strip-edge
+    // values u[r][col0 - 1] and u[r][col0 + 256], and the four lane masks of the row (32 bytes, one s_load_dwordx8).
+    // (The sweep never writes what it reads through them -- Jacobi reads u_in only, red-black reads cells of the other
+    // colour, nothing writes the mask -- and every kernel launch starts with an invalidated scalar cache.)
     typedef const __attribute__((address_space(4))) float cfloat;
+    typedef const __attribute__((address_space(4))) uint64_t cu64;
     const int hcol_l = max(col0 - 1, 0), hcol_r = min(col0 + kStripCols, a.pitch - 1);
-    struct Halo { float l, r; };
-    auto ldh = [&](int r) -> Halo {
+    struct RowSide { float l, r; lmask m0, m1, m2, m3; };
+    auto lds_ = [&](int r) -> RowSide {
         r = min(max(r, 0), rlast);
         cfloat *row = (cfloat *)(a.in + (size_t)r * pitch);
-        return Halo{row[hcol_l], row[hcol_r]};
-    };
-    auto ldm = [&](int g) -> uint32_t {
-        g = min(g, glast);
-        return __builtin_amdgcn_raw_buffer_load_b32(rmask, lane4, (unsigned)((g - (rlo >> 3)) * qpitch + (col0 >> 2)) * 4u, 0);
+        cu64 *mk = (cu64 *)a.maskw + ((size_t)r * a.nstrips + strip) * 4;
+        return RowSide{row[hcol_l], row[hcol_r], mk[0], mk[1], mk[2], mk[3]};
     };
 
     // March direction.  Vertically adjacent tasks share two halo rows; if every task marched downwards, task k would
@@ -160,19 +167,10 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
     // activity tracking: cells of this lane rewritten with different bits -- anywhere, in its first / last column
     // (meaningful in lane 0 / lane 63), in the task's first / last row
     bool chg_any = false, chg_x = false, chg_w = false, chg_top = false, chg_bot = false;
-    int gcur = rfirst >> 3;
-    uint32_t mw = ldm(gcur), mw_next = ldm(max(gcur + dir, 0));
-
     // One row: up / c / dn are rows r-1, r, r+1 of u_in, h the two strip-edge values of row r.
-    auto row_step = [&](int r, const float4 &up, const float4 &c, const float4 &dn, const Halo &h) {
+    auto row_step = [&](int r, const float4 &up, const float4 &c, const float4 &dn, const RowSide &h) {
         const float lf = wave_from_left(c.w, h.l);   // u[r][col-1]
         const float rt = wave_from_right(c.x, h.r);  // u[r][col+4]
-        if ((r >> 3) != gcur) {  // scalar branch: crossed into the next 8-row mask group
-            gcur = r >> 3;
-            mw = mw_next;
-            mw_next = ldm(max(gcur + dir, 0));
-        }
-        const uint32_t nib = mw >> ((r & 7) * 4);
         float4 o;
         if (RB) {
             o = c;
@@ -185,8 +183,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
                     ny = cell_update_2d<MATH>(up.y, dn.y, c.x, c.z, lds);
                     nw = cell_update_2d<MATH>(up.w, dn.w, c.z, rt, lds);
                 }
-                o.y = sel(lanes_bit(nib, 2u), c.y, ny);
-                o.w = sel(lanes_bit(nib, 8u), c.w, nw);
+                o.y = sel(h.m1, c.y, ny);
+                o.w = sel(h.m3, c.w, nw);
             } else {                           // even columns (.x, .z)
                 float nx, nz;
                 if (MATH == kMathDf32) {
@@ -196,8 +194,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
                     nx = cell_update_2d<MATH>(up.x, dn.x, lf, c.y, lds);
                     nz = cell_update_2d<MATH>(up.z, dn.z, c.y, c.w, lds);
                 }
-                o.x = sel(lanes_bit(nib, 1u), c.x, nx);
-                o.z = sel(lanes_bit(nib, 4u), c.z, nz);
+                o.x = sel(h.m0, c.x, nx);
+                o.z = sel(h.m2, c.z, nz);
             }
         } else if (MATH == kMathDf32) {  // two cells per packed instruction
             const v2f a = df_pair_update_2d(v2f{up.x, up.y}, v2f{dn.x, dn.y}, v2f{lf, c.x}, v2f{c.y, c.z}, ldsf);
@@ -210,10 +208,10 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
             o.w = cell_update_2d<MATH>(up.w, dn.w, c.z, rt, lds);
         }
         if (!RB) {
-            o.x = sel(lanes_bit(nib, 1u), c.x, o.x);
-            o.y = sel(lanes_bit(nib, 2u), c.y, o.y);
-            o.z = sel(lanes_bit(nib, 4u), c.z, o.z);
-            o.w = sel(lanes_bit(nib, 8u), c.w, o.w);
+            o.x = sel(h.m0, c.x, o.x);
+            o.y = sel(h.m1, c.y, o.y);
+            o.z = sel(h.m2, c.z, o.z);
+            o.w = sel(h.m3, c.w, o.w);
         }
         if (CHECK) {
             dmax = max2(dmax, fabsf(c.x - o.x));
@@ -243,21 +241,21 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep2d_kernel(Sweep2d
     const int nfull = nrows & ~3;
     if (nfull > 0) {
         float4 q0 = ld(row_at(-1)), q1 = ld(row_at(0)), q2 = ld(row_at(1)), q3;
-        Halo h1 = ldh(row_at(0)), h2 = ldh(row_at(1)), h3, h0;
+        RowSide sa = lds_(row_at(0)), sb;  // row sides run one row ahead, alternating between two sets of SGPRs
         for (int i = 0; i < nfull; i += 4) {
-            q3 = ld(row_at(i + 2)); h3 = ldh(row_at(i + 2));
-            row_step(row_at(i), q0, q1, q2, h1);
-            q0 = ld(row_at(i + 3)); h0 = ldh(row_at(i + 3));
-            row_step(row_at(i + 1), q1, q2, q3, h2);
-            q1 = ld(row_at(i + 4)); h1 = ldh(row_at(i + 4));
-            row_step(row_at(i + 2), q2, q3, q0, h3);
-            q2 = ld(row_at(i + 5)); h2 = ldh(row_at(i + 5));
-            row_step(row_at(i + 3), q3, q0, q1, h0);
+            q3 = ld(row_at(i + 2)); sb = lds_(row_at(i + 1));
+            row_step(row_at(i), q0, q1, q2, sa);
+            q0 = ld(row_at(i + 3)); sa = lds_(row_at(i + 2));
+            row_step(row_at(i + 1), q1, q2, q3, sb);
+            q1 = ld(row_at(i + 4)); sb = lds_(row_at(i + 3));
+            row_step(row_at(i + 2), q2, q3, q0, sa);
+            q2 = ld(row_at(i + 5)); sa = lds_(row_at(i + 4));
+            row_step(row_at(i + 3), q3, q0, q1, sb);
         }
     }
     for (int i = nfull; i < nrows; ++i) {
         const int r = row_at(i);
-        row_step(r, ld(r - dir), ld(r), ld(r + dir), ldh(r));
+        row_step(r, ld(r - dir), ld(r), ld(r + dir), lds_(r));
     }
 
     if (TRACK) {
@@ -305,8 +303,9 @@ template <int MATH>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Sweep2dArgs a)
 {
     __shared__ __attribute__((aligned(16))) float ldsf[kDfLdsFloats];
+    __shared__ double2 ln_lds[kLnTabEntries];
     MathTab lds = {};
-    if (MATH == kMathPrecise) lds = math_tables_load();
+    if (MATH == kMathPrecise) lds = math_tables_load(ln_lds);
     if (MATH == kMathDf32) {
         df_tables_to_lds(ldsf);
         __syncthreads();
@@ -324,8 +323,6 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
     const bool owner = lane >= 1 && lane <= kWave - 2 && col < a.pitch;
     const int rlast = a.rows - 1;
     const size_t pitch = (size_t)a.pitch;
-    const int qpitch = a.pitch >> 2;
-    const int glast = rlast >> 3;
     const int it = a.parity;  // colour A = cells with (row + col + it) odd; col is even for .x
     typedef float vf4 __attribute__((ext_vector_type(4)));
 
@@ -333,19 +330,27 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
         r = min(max(r, 0), rlast);
         return *reinterpret_cast<const float4 *>(a.in + (size_t)r * pitch + lcol);
     };
-    // mask nibble of row r; one cached word per stage (each stage walks the rows in order)
-    int gA = -1, gB = -1;
-    uint32_t wA = 0, wB = 0;
-    auto nibble = [&](int r, int &g, uint32_t &w) -> uint32_t {
-        const int rr = min(max(r, 0), rlast);
-        if ((rr >> 3) != g) {  // scalar branch
-            g = rr >> 3;
-            w = a.maskw[(size_t)min(g, glast) * qpitch + (lcol >> 2)];
-        }
-        return w >> ((rr & 7) * 4);
+    // Lane masks of row r for THIS kernel's lane -> column mapping (lane L holds quad strip * 62 - 1 + L of the row,
+    // the stored masks are cut at multiples of 64 quads): a funnel shift of two neighbouring words, all scalar.
+    // Lanes outside the row (lane 0 of strip 0, lanes past the last column) get arbitrary bits: nothing they compute
+    // is stored or reaches an unlocked cell.
+    typedef const __attribute__((address_space(4))) uint64_t cu64;
+    struct RowMask { lmask m0, m1, m2, m3; };
+    const int nstd = a.pitch >> 8;
+    const int g0 = strip * (kFusedOut / kColsPerLane) - 1;
+    const int sw = max(g0, 0) >> 6, sh = max(g0, 0) & 63, sw1 = min(sw + 1, nstd - 1);
+    auto row_mask = [&](int r) -> RowMask {
+        r = min(max(r, 0), rlast);
+        cu64 *lo = (cu64 *)a.maskw + ((size_t)r * nstd + sw) * 4, *hi = (cu64 *)a.maskw + ((size_t)r * nstd + sw1) * 4;
+        auto cut = [&](int j) -> lmask {
+            lmask m = lo[j];
+            if (sh) m = (m >> sh) | (hi[j] << (64 - sh));
+            return g0 < 0 ? m << 1 : m;
+        };
+        return RowMask{cut(0), cut(1), cut(2), cut(3)};
     };
     // One colour of one row.  second = false: colour A (iteration it), true: colour B (iteration it + 1).
-    auto stage = [&](int r, bool second, const float4 &up, const float4 &c, const float4 &dn, uint32_t nib) -> float4 {
+    auto stage = [&](int r, bool second, const float4 &up, const float4 &c, const float4 &dn, const RowMask &k) -> float4 {
         float4 o = c;
         const bool odd_cols = ((((r + it) & 1) == 0) != second);  // scalar
         if (odd_cols) {
@@ -358,8 +363,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
                 ny = cell_update_2d<MATH>(up.y, dn.y, c.x, c.z, lds);
                 nw = cell_update_2d<MATH>(up.w, dn.w, c.z, rt, lds);
             }
-            o.y = sel(lanes_bit(nib, 2u), c.y, ny);
-            o.w = sel(lanes_bit(nib, 8u), c.w, nw);
+            o.y = sel(k.m1, c.y, ny);
+            o.w = sel(k.m3, c.w, nw);
         } else {
             const float lf = wave_from_left(c.w, 0.0f);
             float nx, nz;
@@ -370,8 +375,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
                 nx = cell_update_2d<MATH>(up.x, dn.x, lf, c.y, lds);
                 nz = cell_update_2d<MATH>(up.z, dn.z, c.y, c.w, lds);
             }
-            o.x = sel(lanes_bit(nib, 1u), c.x, nx);
-            o.z = sel(lanes_bit(nib, 4u), c.z, nz);
+            o.x = sel(k.m0, c.x, nx);
+            o.z = sel(k.m2, c.z, nz);
         }
         return o;
     };
@@ -379,14 +384,17 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
     // prologue: colour A of rows r0-1 and r0 (old neighbours only: the other colour has not moved yet)
     const float4 om2 = ld(r0 - 2), om1 = ld(r0 - 1), o0 = ld(r0);
     float4 onext = ld(r0 + 1), onext2 = ld(r0 + 2);
-    float4 mprev = stage(r0 - 1, false, om2, om1, o0, nibble(r0 - 1, gA, wA));
-    float4 mcur = stage(r0, false, om1, o0, onext, nibble(r0, gA, wA));
+    RowMask kcur = row_mask(r0);
+    float4 mprev = stage(r0 - 1, false, om2, om1, o0, row_mask(r0 - 1));
+    float4 mcur = stage(r0, false, om1, o0, onext, kcur);
     for (int r = r0; r < r1; ++r) {
         const float4 opre = ld(r + 3);
+        const RowMask knext = row_mask(r + 1);
         // colour A of row r+1: up = row r (its B cells are still old in mcur), centre / down old
-        const float4 mnext = stage(r + 1, false, mcur, onext, onext2, nibble(r + 1, gA, wA));
+        const float4 mnext = stage(r + 1, false, mcur, onext, onext2, knext);
         // colour B of row r from the fresh A cells around it
-        const float4 x = stage(r, true, mprev, mcur, mnext, nibble(r, gB, wB));
+        const float4 x = stage(r, true, mprev, mcur, mnext, kcur);
+        kcur = knext;
         if (owner) {
             float *orow = a.out + (size_t)r * pitch;
             if (a.flags & 2) __builtin_nontemporal_store(vf4{x.x, x.y, x.z, x.w}, reinterpret_cast<vf4 *>(orow + col));
@@ -399,28 +407,29 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
     }
 }
 
-// uint32-per-cell mask (the ABI's format, rows x cols, unpitched) -> tiled bits.  Border cells and the
-// padding beyond `cols` / `rows` are forced locked (harmonic.h:35-37 "assumes border values are locked").
-__global__ void pack_mask_2d_kernel(const uint32_t *locked, int rows, int cols, int pitch, int ghost_top,
-                                    int ghost_bottom, uint32_t *maskw, int ngroups)
+// uint32-per-cell mask (the ABI's format, rows x cols, unpitched) -> lane masks (kernels.h).  One wave per (row,
+// strip): lane L looks at its four cells, four ballots are the four words.  Border cells and the padding beyond
+// `cols` are forced locked (harmonic.h:35-37 "assumes border values are locked").
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void pack_mask_2d_kernel(const uint32_t *locked, int rows, int cols,
+                                                                              int pitch, int ghost_top, int ghost_bottom,
+                                                                              uint32_t *maskw)
 {
-    const int qpitch = pitch >> 2;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    const int g = blockIdx.y;
-    if (q >= qpitch || g >= ngroups) return;
-    uint32_t w = 0;
-    for (int rr = 0; rr < 8; ++rr) {
-        const int r = g * 8 + rr;
-        for (int cc = 0; cc < 4; ++cc) {
-            const int cidx = q * 4 + cc;
-            bool lk = true;
-            const bool ghost = (ghost_top && r == 0) || (ghost_bottom && r == rows - 1);
-            const bool border = (!ghost_top && r == 0) || (!ghost_bottom && r == rows - 1) || cidx == 0 || cidx == cols - 1;
-            if (r < rows && cidx < cols && !border && !ghost) lk = locked[(size_t)r * cols + cidx] != 0;
-            w |= (lk ? 1u : 0u) << (rr * 4 + cc);
-        }
+    const int lane = threadIdx.x & (kWave - 1);
+    const int nstrips = pitch >> 8;
+    const int strip = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
+    const int r = blockIdx.x;  // rows ride on grid.x: grid.y stops at 65535
+    if (strip >= nstrips || r >= rows) return;  // wave-uniform
+    const bool ghost = (ghost_top && r == 0) || (ghost_bottom && r == rows - 1);
+    const bool border_row = (!ghost_top && r == 0) || (!ghost_bottom && r == rows - 1);
+    unsigned long long *out = reinterpret_cast<unsigned long long *>(maskw) + ((size_t)r * nstrips + strip) * 4;
+#pragma unroll
+    for (int j = 0; j < kColsPerLane; ++j) {
+        const int c = strip * kStripCols + lane * kColsPerLane + j;
+        bool lk = true;
+        if (c < cols && !border_row && !ghost && c != 0 && c != cols - 1) lk = locked[(size_t)r * cols + c] != 0;
+        const unsigned long long m = __ballot(lk);
+        if (lane == j) out[j] = m;
     }
-    maskw[(size_t)g * qpitch + q] = w;
 }
 
 __global__ void fill_kernel(float *p, size_t n, float v)
@@ -431,7 +440,7 @@ __global__ void fill_kernel(float *p, size_t n, float v)
 }
 
 // Sparse edits (harmonic_utilities_gpu.cu:38-63): one thread per edit, into the CURRENT buffer and the
-// tiled mask.  Border cells stay locked in the mask whatever the edit says (the sweep never updates them).
+// lane masks.  Border cells stay locked in the mask whatever the edit says (the sweep never updates them).
 __global__ void set_cells_2d_kernel(float *u, uint32_t *maskw, int rows, int cols, int pitch, unsigned k,
                                     const unsigned *v, const unsigned *types)
 {
@@ -444,8 +453,8 @@ __global__ void set_cells_2d_kernel(float *u, uint32_t *maskw, int rows, int col
     const float val = (t == 0u) ? 0.0f : -1e6f;
     const bool lock = (t != 2u) || x == 0 || y == 0 || x == (unsigned)cols - 1 || y == (unsigned)rows - 1;
     u[(size_t)y * pitch + x] = val;
-    uint32_t *w = maskw + (size_t)(y >> 3) * (pitch >> 2) + (x >> 2);
-    const uint32_t bit = 1u << ((y & 7) * 4 + (x & 3));
+    uint32_t *w = maskw + mask_word_2d(y, x, (unsigned)pitch);
+    const uint32_t bit = 1u << mask_bit_2d(x);
     if (lock) atomicOr(w, bit);
     else atomicAnd(w, ~bit);
 }
@@ -454,7 +463,8 @@ __global__ void set_cells_2d_kernel(float *u, uint32_t *maskw, int rows, int col
 __global__ void eval_math_kernel(const float *in, float *out, size_t n, int which)
 {
     __shared__ __attribute__((aligned(16))) float ldsf[kDfLdsFloats];
-    const MathTab lds = math_tables_load();
+    __shared__ double2 ln_lds[kLnTabEntries];
+    const MathTab lds = math_tables_load(ln_lds);
     df_tables_to_lds(ldsf);
     __syncthreads();
     // the table fetch is a cross-lane permute: all 64 lanes must stay active, so the loop count is wave-uniform and
@@ -486,8 +496,9 @@ hipError_t launch_eval_math(const float *in, float *out, size_t n, int which, hi
 }
 
 namespace {
-// EPIC_HIP_FLAGS: bit 0 = alternate march direction, bit 1 = non-temporal stores (default 3 = both; measured on 8192^2:
-// traffic-only build 115.6 -> 96.6 us, red-black 104.2 -> 100.5 us, precise Jacobi 161.3 -> 155.8 us).
+// EPIC_HIP_FLAGS: bit 0 = alternate march direction, bit 1 = non-temporal stores of the fused red-black kernel (the
+// plain sweep always stores non-temporally); default 3 = both.  Measured on 8192^2 when both were switchable:
+// traffic-only build 115.6 -> 96.6 us, red-black 104.2 -> 100.5 us, precise Jacobi 161.3 -> 155.8 us.
 int sweep_flags()
 {
     static const int flags = [] {
@@ -585,11 +596,10 @@ hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw
 hipError_t launch_pack_mask_2d(const uint32_t *locked, int rows, int cols, int pitch, int ghost_top,
                                int ghost_bottom, uint32_t *maskw, hipStream_t stream)
 {
-    const int ngroups = (rows + 7) / 8;
-    const int qpitch = pitch / 4;
-    dim3 grid((qpitch + 255) / 256, ngroups);
-    hipLaunchKernelGGL(pack_mask_2d_kernel, grid, dim3(256), 0, stream, locked, rows, cols, pitch, ghost_top,
-                       ghost_bottom, maskw, ngroups);
+    const int nstrips = pitch / kStripCols;
+    dim3 grid(rows, (nstrips + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(pack_mask_2d_kernel, grid, dim3(kWave * kWavesPerBlock), 0, stream, locked, rows, cols, pitch,
+                       ghost_top, ghost_bottom, maskw);
     return hipGetLastError();
 }
 

@@ -9,7 +9,7 @@
 // registers; x2 neighbours are full-wave DPP shifts; the rows of planes x0-1 and x0+1 are loaded per step.  The four
 // waves of a workgroup sweep four consecutive planes of the same (x1-chunk, strip), so those extra rows are the
 // sibling waves' centre rows and are served by the CU's L1 / the XCD's L2 rather than HBM.
-// Mask: 1 bit per cell, 32 consecutive x2 cells per word.
+// Mask: 1 bit per cell as lane masks (kernels.h), fetched with one scalar load per row.
 // Optional activity tracking (wake.h): a tile is one task -- 32 x1-rows x 256 x2-columns of one x0-plane; it reads its
 // own cells, the adjacent column / row of its four in-plane neighbours and the whole tile of the planes x0 - 1 and x0 + 1.
 #include <hip/hip_runtime.h>
@@ -45,14 +45,15 @@ struct Sweep3dArgs {
 template <bool CHECK, int MATH, bool RB, bool TRACK>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3dArgs a)
 {
+    __shared__ double2 ln_lds[kLnTabEntries];  // glibc's logf table (precise math only)
+    MathTab lds = {};  // libm tables (precise math only): exp entries in registers, log entries in LDS
+    if (MATH == kMathPrecise) lds = math_tables_load(ln_lds);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (TRACK) wake_reset_next(a.wake);
     const bool listed = TRACK && a.wake.list_in != nullptr;
     WakeCursor cursor = {};
     if (listed && !wake_begin(a.wake, lane, wave, kWavesPerBlock, cursor)) return;
-    MathTab lds = {};  // libm tables, one entry per lane (precise math only)
-    if (MATH == kMathPrecise) lds = math_tables_load();
     float dmax = 0.0f;
 
     for (;;) {  // one pass per task: exactly one unless the launch is list-driven
@@ -76,74 +77,68 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3d
     const int r0 = chunk * kRowsPerTask;
     const int r1 = min(r0 + kRowsPerTask, a.m1);
 
-    const int col0 = strip * kStripCols;
-    const int col = col0 + lane * 4;
-    const int lcol = col;  // pitch % 256 == 0: every lane is in bounds
-    const int hcol = (lane == 0) ? max(col0 - 1, 0) : min(col0 + kStripCols, a.pitch - 1);
-    const bool edge_lane = (lane == 0) | (lane == 63);
+    const int col0 = strip * kStripCols;  // pitch % 256 == 0: every lane is in bounds
     const size_t pitch = (size_t)a.pitch;
     const size_t plane = (size_t)a.m1 * pitch;
-    const int wpitch = a.pitch >> 5;
-
-    const float *pc = a.in + (size_t)x0 * plane;
-    const float *pa = a.in + (size_t)max(x0 - 1, 0) * plane;
-    const float *pb = a.in + (size_t)min(x0 + 1, a.m0 - 1) * plane;
     const int rlast = a.m1 - 1;
 
-    auto ld = [&](const float *p, int r) -> float4 {
-        r = min(max(r, 0), rlast);
-        return *reinterpret_cast<const float4 *>(p + (size_t)r * pitch + lcol);
+    // As in the 2-D kernel, nothing but the arithmetic of the update is left to the VALU: rows are reached through
+    // buffer descriptors (one per plane x0 - 1 / x0 / x0 + 1 and one for the output, based a few rows above the task) with
+    // the lane part of the address in a VGPR that never changes and the row / strip part in an SGPR; the strip-edge
+    // values of the centre row and the four lane masks of the row (kernels.h) come through scalar loads.
+    const int rlo = max(r0 - 4, 0);
+    auto rsrc = [&](const float *p) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(p + (size_t)rlo * pitch), 0, 0x7fffffff, 0x00020000);
     };
-    auto ldh = [&](int r) -> float {
-        float h = 0.0f;
+    const float *pc = a.in + (size_t)x0 * plane;
+    const __amdgpu_buffer_rsrc_t rc = rsrc(pc), ra = rsrc(a.in + (size_t)max(x0 - 1, 0) * plane),
+                                 rb = rsrc(a.in + (size_t)min(x0 + 1, a.m0 - 1) * plane),
+                                 rout = rsrc(a.out + (size_t)x0 * plane);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    typedef unsigned vu4 __attribute__((ext_vector_type(4)));
+    auto row_off = [&](int r) -> unsigned { return (unsigned)((r - rlo) * a.pitch + col0) * 4u; };  // r already clamped
+    auto ld = [&](const __amdgpu_buffer_rsrc_t &p, int r) -> float4 {
         r = min(max(r, 0), rlast);
-        if (edge_lane) h = pc[(size_t)r * pitch + hcol];
-        return h;
+        const vu4 q = __builtin_amdgcn_raw_buffer_load_b128(p, lane16, row_off(r), 0);
+        return make_float4(u2f(q.x), u2f(q.y), u2f(q.z), u2f(q.w));
     };
-    auto ldm = [&](int r) -> uint32_t {
-        r = min(r, rlast);
-        return a.maskw[((size_t)x0 * a.m1 + r) * wpitch + (lcol >> 5)];
+    typedef const __attribute__((address_space(4))) float cfloat;
+    typedef const __attribute__((address_space(4))) uint64_t cu64;
+    const int hcol_l = max(col0 - 1, 0), hcol_r = min(col0 + kStripCols, a.pitch - 1);
+    struct RowSide { float l, r; lmask m0, m1, m2, m3; };
+    auto side = [&](int r) -> RowSide {
+        r = min(max(r, 0), rlast);
+        cfloat *row = (cfloat *)(pc + (size_t)r * pitch);
+        cu64 *mk = (cu64 *)a.maskw + (((size_t)x0 * a.m1 + r) * a.nstrips + strip) * 4;
+        return RowSide{row[hcol_l], row[hcol_r], mk[0], mk[1], mk[2], mk[3]};
     };
 
-    float4 up = ld(pc, r0 - 1), c = ld(pc, r0), d1 = ld(pc, r0 + 1);
-    float4 a1 = ld(pa, r0), b1 = ld(pb, r0);
-    float hc = ldh(r0), h1 = ldh(r0 + 1);
-    uint32_t mw = ldm(r0);
     bool chg_any = false, chg_x = false, chg_w = false, chg_top = false, chg_bot = false;  // as in the 2-D kernel
 
-    for (int r = r0; r < r1; ++r) {
-        const float4 d2 = ld(pc, r + 2);
-        const float4 a2 = ld(pa, r + 1), b2 = ld(pb, r + 1);
-        const float h2 = ldh(r + 2);
-        const uint32_t mw2 = ldm(r + 1);
-
-        const float lf = wave_from_left(c.w, hc);
-        const float rt = wave_from_right(c.x, hc);
-        const uint32_t nib = mw >> (lcol & 31);
-
+    // One row: up / c / dn = rows x1 - 1, x1, x1 + 1 of the plane, pa / pb = row x1 of the planes x0 - 1 and x0 + 1.
+    auto row_step = [&](int r, const float4 &up, const float4 &c, const float4 &dn, const float4 &pa, const float4 &pb,
+                        const RowSide &h) {
+        const float lf = wave_from_left(c.w, h.l);
+        const float rt = wave_from_right(c.x, h.r);
         float4 o;
         if (RB) {
             o = c;
             if (((x0 + r + a.parity) & 1) == 0) {  // scalar: even x2 columns (.x, .z) are this row's active cells
-                const float nx = cell_update_3d<MATH>(a1.x, b1.x, up.x, d1.x, lf, c.y, lds);
-                const float nz = cell_update_3d<MATH>(a1.z, b1.z, up.z, d1.z, c.y, c.w, lds);
-                o.x = (nib & 1u) ? c.x : nx;
-                o.z = (nib & 4u) ? c.z : nz;
+                const float nx = cell_update_3d<MATH>(pa.x, pb.x, up.x, dn.x, lf, c.y, lds);
+                const float nz = cell_update_3d<MATH>(pa.z, pb.z, up.z, dn.z, c.y, c.w, lds);
+                o.x = sel(h.m0, c.x, nx);
+                o.z = sel(h.m2, c.z, nz);
             } else {
-                const float ny = cell_update_3d<MATH>(a1.y, b1.y, up.y, d1.y, c.x, c.z, lds);
-                const float nw = cell_update_3d<MATH>(a1.w, b1.w, up.w, d1.w, c.z, rt, lds);
-                o.y = (nib & 2u) ? c.y : ny;
-                o.w = (nib & 8u) ? c.w : nw;
+                const float ny = cell_update_3d<MATH>(pa.y, pb.y, up.y, dn.y, c.x, c.z, lds);
+                const float nw = cell_update_3d<MATH>(pa.w, pb.w, up.w, dn.w, c.z, rt, lds);
+                o.y = sel(h.m1, c.y, ny);
+                o.w = sel(h.m3, c.w, nw);
             }
         } else {
-            o.x = cell_update_3d<MATH>(a1.x, b1.x, up.x, d1.x, lf, c.y, lds);
-            o.y = cell_update_3d<MATH>(a1.y, b1.y, up.y, d1.y, c.x, c.z, lds);
-            o.z = cell_update_3d<MATH>(a1.z, b1.z, up.z, d1.z, c.y, c.w, lds);
-            o.w = cell_update_3d<MATH>(a1.w, b1.w, up.w, d1.w, c.z, rt, lds);
-            o.x = (nib & 1u) ? c.x : o.x;
-            o.y = (nib & 2u) ? c.y : o.y;
-            o.z = (nib & 4u) ? c.z : o.z;
-            o.w = (nib & 8u) ? c.w : o.w;
+            o.x = sel(h.m0, c.x, cell_update_3d<MATH>(pa.x, pb.x, up.x, dn.x, lf, c.y, lds));
+            o.y = sel(h.m1, c.y, cell_update_3d<MATH>(pa.y, pb.y, up.y, dn.y, c.x, c.z, lds));
+            o.z = sel(h.m2, c.z, cell_update_3d<MATH>(pa.z, pb.z, up.z, dn.z, c.y, c.w, lds));
+            o.w = sel(h.m3, c.w, cell_update_3d<MATH>(pa.w, pb.w, up.w, dn.w, c.z, rt, lds));
         }
         if (CHECK) {
             dmax = max2(dmax, fabsf(c.x - o.x));
@@ -153,20 +148,37 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3d
         }
         if (TRACK) {
             const bool cx = f2u(o.x) != f2u(c.x), cw = f2u(o.w) != f2u(c.w);
-            const bool rc = cx | cw | (f2u(o.y) != f2u(c.y)) | (f2u(o.z) != f2u(c.z));
-            chg_any |= rc;
+            const bool rc2 = cx | cw | (f2u(o.y) != f2u(c.y)) | (f2u(o.z) != f2u(c.z));
+            chg_any |= rc2;
             chg_x |= cx;
             chg_w |= cw;
-            if (r == r0) chg_top = rc;
-            if (r == r1 - 1) chg_bot = rc;
+            if (r == r0) chg_top = rc2;
+            if (r == r1 - 1) chg_bot = rc2;
         }
-        *reinterpret_cast<float4 *>(a.out + (size_t)x0 * plane + (size_t)r * pitch + col) = o;
+        __builtin_amdgcn_raw_buffer_store_b128(vu4{f2u(o.x), f2u(o.y), f2u(o.z), f2u(o.w)}, rout, lane16, row_off(r), 0);
+    };
 
-        up = c; c = d1; d1 = d2;
-        a1 = a2; b1 = b2;
-        hc = h1; h1 = h2;
-        mw = mw2;
+    // Register rings rotated by hand (no moves between a load and its use): the plane's own rows run two rows ahead
+    // over four registers, the rows of the neighbouring planes and the scalar row sides one row ahead over two.
+    const int nrows = r1 - r0, nfull = nrows & ~3;
+    if (nfull > 0) {
+        float4 q0 = ld(rc, r0 - 1), q1 = ld(rc, r0), q2 = ld(rc, r0 + 1), q3;
+        float4 aa = ld(ra, r0), ba = ld(rb, r0), ab, bb;
+        RowSide sa = side(r0), sb;
+        for (int i = 0; i < nfull; i += 4) {
+            const int r = r0 + i;
+            q3 = ld(rc, r + 2); ab = ld(ra, r + 1); bb = ld(rb, r + 1); sb = side(r + 1);
+            row_step(r, q0, q1, q2, aa, ba, sa);
+            q0 = ld(rc, r + 3); aa = ld(ra, r + 2); ba = ld(rb, r + 2); sa = side(r + 2);
+            row_step(r + 1, q1, q2, q3, ab, bb, sb);
+            q1 = ld(rc, r + 4); ab = ld(ra, r + 3); bb = ld(rb, r + 3); sb = side(r + 3);
+            row_step(r + 2, q2, q3, q0, aa, ba, sa);
+            q2 = ld(rc, r + 5); aa = ld(ra, r + 4); ba = ld(rb, r + 4); sa = side(r + 4);
+            row_step(r + 3, q3, q0, q1, ab, bb, sb);
+        }
     }
+    for (int r = r0 + nfull; r < r1; ++r)  // ragged tail
+        row_step(r, ld(rc, r - 1), ld(rc, r), ld(rc, r + 1), ld(ra, r), ld(rb, r), side(r));
 
     if (TRACK) {
         // wake the tiles that read what this task changed: itself, the in-plane neighbours across the edges that
@@ -198,26 +210,27 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3d
     }
 }
 
-// uint32-per-cell mask (m0 x m1 x m2, unpitched) -> 1 bit per cell, 32 x2-cells per word; faces and padding locked.
-__global__ void pack_mask_3d_kernel(const uint32_t *locked, int m0, int m1, int m2, int pitch, uint32_t *maskw)
+// uint32-per-cell mask (m0 x m1 x m2, unpitched) -> lane masks (kernels.h: per x2-row and strip four 64-bit words);
+// faces and padding locked.  One wave per (row, strip), four ballots.
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void pack_mask_3d_kernel(const uint32_t *locked, int m0, int m1, int m2,
+                                                                              int pitch, uint32_t *maskw)
 {
-    const int wpitch = pitch >> 5;
-    const size_t nwords = (size_t)m0 * m1 * wpitch;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nwords) return;
-    const int w = (int)(i % wpitch);
-    const size_t row = i / wpitch;
-    const int x1 = (int)(row % m1);
-    const int x0 = (int)(row / m1);
+    const int lane = threadIdx.x & 63;
+    const int nstrips = pitch >> 8;
+    const int strip = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
+    const size_t row = blockIdx.x;  // x0 * m1 + x1 (rows ride on grid.x: grid.y stops at 65535)
+    if (strip >= nstrips) return;   // wave-uniform
+    const int x1 = (int)(row % m1), x0 = (int)(row / m1);
     const bool face01 = x0 == 0 || x0 == m0 - 1 || x1 == 0 || x1 == m1 - 1;
-    uint32_t bits = 0;
-    for (int k = 0; k < 32; ++k) {
-        const int x2 = w * 32 + k;
+    unsigned long long *out = reinterpret_cast<unsigned long long *>(maskw) + (row * nstrips + strip) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x2 = strip * kStripCols + lane * 4 + j;
         bool lk = true;
-        if (!face01 && x2 > 0 && x2 < m2 - 1) lk = locked[((size_t)x0 * m1 + x1) * m2 + x2] != 0;
-        bits |= (lk ? 1u : 0u) << k;
+        if (!face01 && x2 > 0 && x2 < m2 - 1) lk = locked[row * m2 + x2] != 0;
+        const unsigned long long m = __ballot(lk);
+        if (lane == j) out[j] = m;
     }
-    maskw[i] = bits;
 }
 
 }  // namespace
@@ -279,9 +292,11 @@ hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, i
 hipError_t launch_pack_mask_3d(const uint32_t *locked, int m0, int m1, int m2, int pitch, uint32_t *maskw,
                                hipStream_t stream)
 {
-    const size_t nwords = mask_words_3d(m0, m1, pitch);
-    hipLaunchKernelGGL(pack_mask_3d_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, stream, locked, m0, m1,
-                       m2, pitch, maskw);
+    const int nstrips = pitch / kStripCols;
+    const size_t nrows = (size_t)m0 * (size_t)m1;
+    if (nrows > 0x7fffffffu) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_mask_3d_kernel, dim3((unsigned)nrows, (unsigned)((nstrips + kWavesPerBlock - 1) / kWavesPerBlock)),
+                       dim3(kWave * kWavesPerBlock), 0, stream, locked, m0, m1, m2, pitch, maskw);
     return hipGetLastError();
 }
 

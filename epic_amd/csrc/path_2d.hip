@@ -43,8 +43,7 @@ __device__ __forceinline__ bool locked(const PathField &f, unsigned x, unsigned 
 {
     x = min(x, f.w - 1u);
     y = min(y, f.h - 1u);
-    const uint32_t word = f.maskw[(size_t)(y >> 3) * (f.pitch >> 2) + (x >> 2)];
-    return (word >> ((y & 7u) * 4u + (x & 3u))) & 1u;
+    return (f.maskw[mask_word_2d(y, x, f.pitch)] >> mask_bit_2d(x)) & 1u;
 }
 
 // harmonic_path_cpu.cpp:55-57: outside the grid, or a locked cell with u < 0 (an obstacle; goals are locked with u == 0)

@@ -9,7 +9,8 @@ import ctypes as ct
 import os
 
 _HERE = os.path.dirname(os.path.realpath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libepic.so")
+# EPIC_LIB: another build of the same library (A/B timing of kernel variants, tools/ab_bench.sh)
+LIB_PATH = os.environ.get("EPIC_LIB") or os.path.join(_HERE, "lib", "libepic.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
