@@ -382,3 +382,28 @@ float oracle_redblack_rows_2d(float *u, const unsigned int *locked, unsigned int
     }
     return d;
 }
+
+/* ---- the libm under the reference's arithmetic, array form ------------------------------------------------------
+ * harmonic_cpu.cpp:65-70 calls std::exp / std::log on floats, i.e. this host's libm expf / logf.  The device restates
+ * them (epic_amd/csrc/cell_update.h); this is the checker for that restatement over WHOLE input ranges: the inputs are
+ * the n consecutive float bit patterns first_bits, first_bits + 1, ...; got[i] is the device's result for the i-th.
+ * Returns the number of results whose bits differ from libm's; *first_bad = index of the first one (if any).
+ * which = 0: expf, 1: logf. */
+size_t oracle_libm_mismatches(int which, uint32_t first_bits, size_t n, const float *got, size_t *first_bad, int threads)
+{
+    size_t bad = 0, first = (size_t)-1;
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(static) reduction(+ : bad) reduction(min : first)
+    for (size_t i = 0; i < n; i++) {
+        union { uint32_t u; float f; } x, want, have;
+        x.u = first_bits + (uint32_t)i;
+        want.f = which ? logf(x.f) : expf(x.f);
+        have.f = got[i];
+        if (want.u != have.u) {
+            bad++;
+            if (i < first) first = i;
+        }
+    }
+    if (first_bad) *first_bad = first;
+    return bad;
+}
