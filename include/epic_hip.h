@@ -100,8 +100,8 @@ int epic_hip_eval_math(const float *d_in, float *d_out, size_t n, int which, voi
 int epic_hip_get_layout(EpicHarmonicT *harmonic, unsigned int *pitch, size_t *u_bytes, size_t *mask_bytes);
 
 /* ---- raw operators on caller-owned device memory (slab decomposition / multi-process drivers) ----------
- * 2-D grid of `rows` x `pitch` floats (pitch % 256 == 0, rows include any ghost rows); the mask is the tiled
- * bit layout produced by epic_hip_pack_mask_2d (epic_hip_mask_words_2d(rows, pitch) uint32 words).
+ * 2-D grid of `rows` x `pitch` floats (pitch % 256 == 0, rows include any ghost rows); the mask is the private
+ * bit layout produced by epic_hip_pack_mask_2d (epic_hip_mask_words_2d(rows, pitch) uint32 words, 1 bit per cell).
  * epic_hip_sweep_2d sweeps rows [row_begin, row_end) from d_in to d_out; if d_delta_bits != NULL the max |du|
  * of those rows is atomically max-ed into it as float bits (zero it first).  Asynchronous on `stream`. */
 size_t epic_hip_mask_words_2d(unsigned int rows, unsigned int pitch);
