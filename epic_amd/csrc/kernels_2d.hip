@@ -33,6 +33,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "cell_update.h"
 #include "kernels.h"
 #include "wake.h"
@@ -534,6 +536,10 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, i
     if (pitch <= 0 || (pitch % 256) != 0 || rows <= 0 || row_begin < 0 || row_end > rows || rows_per_task <= 0)
         return hipErrorInvalidValue;
     if ((parity >= 0) != (in == out)) return hipErrorInvalidValue;
+    // the kernel addresses a task's rows with 32-bit byte offsets from a base 8 rows above it (rows_per_task + 14 rows)
+    const long long max_rows = 0x7fffffffLL / ((long long)pitch * 4) - 16;
+    if (max_rows < 1) return hipErrorInvalidValue;
+    rows_per_task = (int)std::min<long long>(rows_per_task, max_rows);
     Sweep2dArgs a;
     a.in = in;
     a.out = out;

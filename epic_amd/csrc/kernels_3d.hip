@@ -259,6 +259,7 @@ hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, i
     if (pitch <= 0 || (pitch % 256) != 0 || m0 <= 0 || m1 <= 0 || plane_begin < 0 || plane_end > m0)
         return hipErrorInvalidValue;
     if ((parity >= 0) != (in == out)) return hipErrorInvalidValue;
+    if ((long long)pitch * 4 * (kRowsPerTask + 12) > 0x7fffffffLL) return hipErrorInvalidValue;  // 32-bit row offsets
     Sweep3dArgs a;
     a.in = in;
     a.out = out;
