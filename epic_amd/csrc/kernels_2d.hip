@@ -110,7 +110,6 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
     WakeCursor cursor = {};
     if (listed && !wake_begin(a.wake, lane, wave, kWavesPerBlock, cursor)) return;
     float dmax = 0.0f;
-    typedef float vf4 __attribute__((ext_vector_type(4)));
     const int rlast = a.rows - 1;
     const size_t pitch = (size_t)a.pitch;
 
@@ -126,7 +125,6 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
     const int r1 = min(r0 + a.rows_per_task, a.row_end);
 
     const int col0 = strip * kStripCols;  // pitch % 256 == 0: every lane of every strip is in bounds (DPP / bpermute want all lanes live)
-    const int col = col0 + lane * kColsPerLane;
 
     // Addressing costs no VALU instruction: rows are reached through buffer descriptors (base = a few rows above the
     // task, so that byte offsets stay far below 4 GiB on any grid) with the lane part of the address in a VGPR that
@@ -151,7 +149,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
     typedef const __attribute__((address_space(4))) uint64_t cu64;
     const int hcol_l = max(col0 - 1, 0), hcol_r = min(col0 + kStripCols, a.pitch - 1);
     struct RowSide { float l, r; lmask m0, m1, m2, m3; };
-    auto lds_ = [&](int r) -> RowSide {
+    auto side = [&](int r) -> RowSide {
         r = min(max(r, 0), rlast);
         cfloat *row = (cfloat *)(a.in + (size_t)r * pitch);
         cu64 *mk = (cu64 *)a.maskw + ((size_t)r * a.nstrips + strip) * 4;
@@ -243,21 +241,21 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
     const int nfull = nrows & ~3;
     if (nfull > 0) {
         float4 q0 = ld(row_at(-1)), q1 = ld(row_at(0)), q2 = ld(row_at(1)), q3;
-        RowSide sa = lds_(row_at(0)), sb;  // row sides run one row ahead, alternating between two sets of SGPRs
+        RowSide sa = side(row_at(0)), sb;  // row sides run one row ahead, alternating between two sets of SGPRs
         for (int i = 0; i < nfull; i += 4) {
-            q3 = ld(row_at(i + 2)); sb = lds_(row_at(i + 1));
+            q3 = ld(row_at(i + 2)); sb = side(row_at(i + 1));
             row_step(row_at(i), q0, q1, q2, sa);
-            q0 = ld(row_at(i + 3)); sa = lds_(row_at(i + 2));
+            q0 = ld(row_at(i + 3)); sa = side(row_at(i + 2));
             row_step(row_at(i + 1), q1, q2, q3, sb);
-            q1 = ld(row_at(i + 4)); sb = lds_(row_at(i + 3));
+            q1 = ld(row_at(i + 4)); sb = side(row_at(i + 3));
             row_step(row_at(i + 2), q2, q3, q0, sa);
-            q2 = ld(row_at(i + 5)); sa = lds_(row_at(i + 4));
+            q2 = ld(row_at(i + 5)); sa = side(row_at(i + 4));
             row_step(row_at(i + 3), q3, q0, q1, sb);
         }
     }
     for (int i = nfull; i < nrows; ++i) {
         const int r = row_at(i);
-        row_step(r, ld(r - dir), ld(r), ld(r + dir), lds_(r));
+        row_step(r, ld(r - dir), ld(r), ld(r + dir), side(r));
     }
 
     if (TRACK) {
