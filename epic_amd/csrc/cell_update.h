@@ -321,6 +321,19 @@ __device__ __forceinline__ float cell_update_3d(float a0, float a1, float b0, fl
     return (float)((double)t - kLn6);
 }
 
+// ---- raw buffer descriptors ------------------------------------------------------------------------------------
+// The sweeps address rows through V# descriptors (buffer_load / buffer_store ... offen with an SGPR soffset), which keeps
+// every address computation on the scalar unit.  Word 3 of a gfx9-family raw buffer descriptor: DATA_FORMAT = 32-bit
+// (bits 15..18 = 4), everything else 0 (no swizzle, no typed conversion); num_records is the byte range checked by the
+// hardware -- the kernels clamp their row indices themselves and keep offsets below 2 GiB, so it is simply the maximum.
+constexpr int kRawBufferWord3 = 0x00020000;
+constexpr int kRawBufferRange = 0x7fffffff;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t raw_buffer(const void *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, kRawBufferRange, kRawBufferWord3);
+}
+constexpr int kStoreNonTemporal = 2;  // cache-policy operand of the buffer store builtins: the "nt" bit
+
 // Full-wave (64-lane) shifts by one lane: one v_mov_b32_dpp each on gfx9-family ISAs.
 // lane i receives lane i-1's `v`; lane 0 keeps `edge`.
 __device__ __forceinline__ float wave_from_left(float v, float edge)

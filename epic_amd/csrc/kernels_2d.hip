@@ -130,8 +130,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
     // task, so that byte offsets stay far below 4 GiB on any grid) with the lane part of the address in a VGPR that
     // never changes (lane * 16 bytes) and the row / strip part in an SGPR (buffer_load ... offen with soffset).
     const int rlo = max(r0 - 8, 0);  // the march touches rows r0 - 6 .. r1 + 5 at most (prefetch past either end)
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + (size_t)rlo * pitch), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (size_t)rlo * pitch), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rin = raw_buffer(a.in + (size_t)rlo * pitch), rout = raw_buffer(a.out + (size_t)rlo * pitch);
     const unsigned lane16 = (unsigned)lane * 16u;
     typedef unsigned vu4 __attribute__((ext_vector_type(4)));
     auto row_off = [&](int r) -> unsigned { return (unsigned)((r - rlo) * a.pitch + col0) * 4u; };  // r already clamped
@@ -229,7 +228,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
             if (r == r1 - 1) chg_bot = rc;
         }
         // non-temporal: the row is not read again before the next sweep (traffic-only build 115.6 -> 96.6 us with it)
-        __builtin_amdgcn_raw_buffer_store_b128(vu4{f2u(o.x), f2u(o.y), f2u(o.z), f2u(o.w)}, rout, lane16, row_off(r), 2 /*nt*/);
+        __builtin_amdgcn_raw_buffer_store_b128(vu4{f2u(o.x), f2u(o.y), f2u(o.z), f2u(o.w)}, rout, lane16, row_off(r), kStoreNonTemporal);
     };
 
     // Software pipeline, rotated by hand over a 4-row register ring so that no register moves (and hence no

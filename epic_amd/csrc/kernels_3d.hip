@@ -87,9 +87,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3d
     // the lane part of the address in a VGPR that never changes and the row / strip part in an SGPR; the strip-edge
     // values of the centre row and the four lane masks of the row (kernels.h) come through scalar loads.
     const int rlo = max(r0 - 4, 0);
-    auto rsrc = [&](const float *p) {
-        return __builtin_amdgcn_make_buffer_rsrc((void *)(p + (size_t)rlo * pitch), 0, 0x7fffffff, 0x00020000);
-    };
+    auto rsrc = [&](const float *p) { return raw_buffer(p + (size_t)rlo * pitch); };
     const float *pc = a.in + (size_t)x0 * plane;
     const __amdgpu_buffer_rsrc_t rc = rsrc(pc), ra = rsrc(a.in + (size_t)max(x0 - 1, 0) * plane),
                                  rb = rsrc(a.in + (size_t)min(x0 + 1, a.m0 - 1) * plane),
