@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3d
             if (r == r0) chg_top = rc2;
             if (r == r1 - 1) chg_bot = rc2;
         }
-        __builtin_amdgcn_raw_buffer_store_b128(vu4{f2u(o.x), f2u(o.y), f2u(o.z), f2u(o.w)}, rout, lane16, row_off(r), 0);
+        __builtin_amdgcn_raw_buffer_store_b128(vu4{f2u(o.x), f2u(o.y), f2u(o.z), f2u(o.w)}, rout, lane16, row_off(r), kStoreNonTemporal);  // 389.7 -> 384.4 us per 512^3 sweep
     };
 
     // Register rings rotated by hand (no moves between a load and its use): the plane's own rows run two rows ahead
