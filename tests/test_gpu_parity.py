@@ -120,6 +120,22 @@ def test_fixed_sweeps_2d_vs_oracle_jacobi(m, seed, dens):
         assert gdelta == wdelta, (gdelta, wdelta)
 
 
+@pytest.mark.parametrize("m,rpt", [([66000, 300], 0), ([6, 80000], 0), ([1200, 9000], 64), ([40000, 520], 5)])
+def test_extreme_aspect_ratios(m, rpt):
+    """More rows than a grid dimension may hold in y (65535), hundreds of strips per row, the tallest tasks: the buffer
+    addressing (32-bit row offsets from a per-task base), the row-per-block mask packing and the scalar row sides must
+    hold on all of them.  Goals at both ends so that every part of the grid sees moving values."""
+    u0, locked = synthetic_grid(m, 17, 0.05)
+    free = np.flatnonzero(locked == 0)
+    for idx in (free[0], free[free.size // 2], free[-1]):
+        u0[idx] = 0.0
+        locked[idx] = 1
+    got, gdelta = gpu_sweeps(m, u0, locked, 6, rows_per_task=rpt)
+    want, wdelta = oracle_jacobi(m, u0, locked, 6)
+    assert_close(got, want, locked, FIXED_TOL, f"{m} after 6 sweeps")
+    assert gdelta == wdelta, (gdelta, wdelta)
+
+
 @pytest.mark.parametrize("rpt", [1, 3, 8, 13, 64, 1000])
 def test_rows_per_task_is_only_a_tiling_choice(rpt):
     m = [77, 300]
