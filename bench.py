@@ -52,6 +52,9 @@ def parse():
                     help="jacobi = ping-pong sweep of every cell (default); redblack = the reference's in-place half-sweeps")
     ap.add_argument("--halo", type=int, default=8, help="N > 1: ghost rows per side = sweeps between two halo exchanges")
     ap.add_argument("--slab", action="store_true", help="use the slab-decomposition driver even on one GPU")
+    ap.add_argument("--strong", action="store_true",
+                    help="N > 1: ONE size x size grid cut into N row slabs (BASELINE configs[3]: --size 32768 --gpus 4|8) "
+                         "instead of the default weak scaling (one size x size grid per GPU)")
     ap.add_argument("--develop", type=int, default=20000,
                     help="untimed sweeps before the timed region, so that it runs on a developed field: on the constant "
                          "initial field (u = -1e6 almost everywhere) the same VALU-bound kernel runs ~15 %% faster "
@@ -164,7 +167,7 @@ def main():
 
     E = eh._epic
     n = args.size
-    grid = [n * world, n]
+    grid = [n, n] if args.strong else [n * world, n]
 
     def barrier():
         if world > 1:
@@ -256,7 +259,8 @@ def main():
     # algorithmic bytes per launch: 8 B per cell the launch recomputes-or-copies.  A Jacobi sweep touches every cell of
     # the grid; a red-black half-sweep recomputes one colour, i.e. half the grid (its row-major in-place layout still
     # moves both colours -- that surplus shows up in `traffic`, not in `achieved`).
-    cells_per_launch = n * n if (args.scheme == "jacobi" or not use_abi) else n * n // 2
+    rows_per_rank = grid[0] // world   # the dominant kernel is one rank's sweep of its slab
+    cells_per_launch = rows_per_rank * n if (args.scheme == "jacobi" or not use_abi) else rows_per_rank * n // 2
     achieved = BYTES_PER_CELL_SWEEP * cells_per_launch / (launch_us * 1e-6) / 1e9
     out = {
         "metric": "cell_updates_per_s_log_harmonic_relax_8192sq",
@@ -267,13 +271,15 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(wall * 1e3 / args.steps, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if (args.strong and world > 1) else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "synthetic %dx%d occupancy grid per GPU, 5%% random obstacles + 1 goal (BASELINE configs[2]), "
-                        "log-space Jacobi relax towards eps=1e-6" % (n, n),
+            "workload": ("synthetic %dx%d occupancy grid cut into %d row slabs, 5%% random obstacles + 1 goal (BASELINE "
+                         "configs[3]), log-space Jacobi relax towards eps=1e-6" % (n, n, world)) if (args.strong and world > 1)
+                        else ("synthetic %dx%d occupancy grid per GPU, 5%% random obstacles + 1 goal (BASELINE configs[2]), "
+                              "log-space Jacobi relax towards eps=1e-6" % (n, n)),
             "grid": grid,
             "sweeps_per_step": args.stagger,
             "check_every": args.stagger,

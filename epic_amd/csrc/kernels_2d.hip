@@ -62,7 +62,7 @@ struct Sweep2dArgs {
     int nstrips;            // ceil(pitch / 256)
     int ntasks;             // nstrips * nchunks
     int parity;             // red-black scheme only: currentIteration & 1 (which colour this half-sweep updates)
-    int flags;              // tuning, never results: bit 0 = odd row-chunks march upwards, bit 1 = non-temporal stores (fused kernel)
+    int flags;              // tuning, never results: bit 0 = odd row-chunks march upwards
     // Activity tracking (full-grid launches only; TRACK kernels): wake.h.  A tile is one task (rows_per_task x 256
     // cells); it reads its own cells, the last column of its left neighbour, the first column of its right neighbour,
     // the last row of the tile above and the first row of the tile below (5-point stencil).
@@ -323,11 +323,17 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
     const int rlast = a.rows - 1;
     const size_t pitch = (size_t)a.pitch;
     const int it = a.parity;  // colour A = cells with (row + col + it) odd; col is even for .x
-    typedef float vf4 __attribute__((ext_vector_type(4)));
+    typedef unsigned vu4 __attribute__((ext_vector_type(4)));
 
+    // rows through buffer descriptors with scalar row offsets, as in the plain sweep (no VALU address arithmetic)
+    const int rlo = max(r0 - 2, 0);  // rows r0 - 2 .. r1 + 2 are touched
+    const __amdgpu_buffer_rsrc_t rin = raw_buffer(a.in + (size_t)rlo * pitch), rout = raw_buffer(a.out + (size_t)rlo * pitch);
+    const unsigned lane_off = (unsigned)lcol * 4u;
+    auto row_off = [&](int r) -> unsigned { return (unsigned)((r - rlo) * a.pitch) * 4u; };  // r already clamped
     auto ld = [&](int r) -> float4 {
         r = min(max(r, 0), rlast);
-        return *reinterpret_cast<const float4 *>(a.in + (size_t)r * pitch + lcol);
+        const vu4 q = __builtin_amdgcn_raw_buffer_load_b128(rin, lane_off, row_off(r), 0);
+        return make_float4(u2f(q.x), u2f(q.y), u2f(q.z), u2f(q.w));
     };
     // Lane masks of row r for THIS kernel's lane -> column mapping (lane L holds quad strip * 62 - 1 + L of the row,
     // the stored masks are cut at multiples of 64 quads): a funnel shift of two neighbouring words, all scalar.
@@ -382,27 +388,31 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
 
     // prologue: colour A of rows r0-1 and r0 (old neighbours only: the other colour has not moved yet)
     const float4 om2 = ld(r0 - 2), om1 = ld(r0 - 1), o0 = ld(r0);
-    float4 onext = ld(r0 + 1), onext2 = ld(r0 + 2);
+    float4 oa = ld(r0 + 1), ob = ld(r0 + 2), oc;  // old rows r+1, r+2, r+3
     RowMask kcur = row_mask(r0);
-    float4 mprev = stage(r0 - 1, false, om2, om1, o0, row_mask(r0 - 1));
-    float4 mcur = stage(r0, false, om1, o0, onext, kcur);
-    for (int r = r0; r < r1; ++r) {
-        const float4 opre = ld(r + 3);
+    float4 ma = stage(r0 - 1, false, om2, om1, o0, row_mask(r0 - 1)), mb = stage(r0, false, om1, o0, oa, kcur), mc;
+    // One row r: `mp`, `mq` = colour A of rows r-1, r; `o1`, `o2` = old rows r+1, r+2.  Leaves colour A of row r+1 in
+    // `mr` and old row r+3 in `o3`.  The three A rows and the three old rows rotate through fixed registers (the loop
+    // is unrolled by three), so nothing is moved.
+    auto step = [&](int r, const float4 &mp, const float4 &mq, float4 &mr, const float4 &o1, const float4 &o2, float4 &o3) {
+        o3 = ld(r + 3);
         const RowMask knext = row_mask(r + 1);
-        // colour A of row r+1: up = row r (its B cells are still old in mcur), centre / down old
-        const float4 mnext = stage(r + 1, false, mcur, onext, onext2, knext);
-        // colour B of row r from the fresh A cells around it
-        const float4 x = stage(r, true, mprev, mcur, mnext, kcur);
+        mr = stage(r + 1, false, mq, o1, o2, knext);           // colour A of row r+1: up = row r (its B cells still old)
+        const float4 x = stage(r, true, mp, mq, mr, kcur);    // colour B of row r from the fresh A cells around it
         kcur = knext;
-        if (owner) {
-            float *orow = a.out + (size_t)r * pitch;
-            if (a.flags & 2) __builtin_nontemporal_store(vf4{x.x, x.y, x.z, x.w}, reinterpret_cast<vf4 *>(orow + col));
-            else *reinterpret_cast<float4 *>(orow + col) = x;
-        }
-        mprev = mcur;
-        mcur = mnext;
-        onext = onext2;
-        onext2 = opre;
+        if (owner)  // non-temporal, as in the plain sweep
+            __builtin_amdgcn_raw_buffer_store_b128(vu4{f2u(x.x), f2u(x.y), f2u(x.z), f2u(x.w)}, rout, lane_off, row_off(r),
+                                                   kStoreNonTemporal);
+    };
+    int r = r0;
+    for (; r + 3 <= r1; r += 3) {
+        step(r, ma, mb, mc, oa, ob, oc);
+        step(r + 1, mb, mc, ma, ob, oc, oa);
+        step(r + 2, mc, ma, mb, oc, oa, ob);
+    }
+    for (; r < r1; ++r) {  // at most two rows
+        step(r, ma, mb, mc, oa, ob, oc);
+        ma = mb; mb = mc; oa = ob; ob = oc;
     }
 }
 
@@ -495,9 +505,9 @@ hipError_t launch_eval_math(const float *in, float *out, size_t n, int which, hi
 }
 
 namespace {
-// EPIC_HIP_FLAGS: bit 0 = alternate march direction, bit 1 = non-temporal stores of the fused red-black kernel (the
-// plain sweep always stores non-temporally); default 3 = both.  Measured on 8192^2 when both were switchable:
-// traffic-only build 115.6 -> 96.6 us, red-black 104.2 -> 100.5 us, precise Jacobi 161.3 -> 155.8 us.
+// EPIC_HIP_FLAGS: bit 0 = alternate march direction (default 1).  Stores are always non-temporal (bit 1 used to switch
+// that; measured on 8192^2 when both were switchable: traffic-only build 115.6 -> 96.6 us, red-black 104.2 -> 100.5 us,
+// precise Jacobi 161.3 -> 155.8 us).
 int sweep_flags()
 {
     static const int flags = [] {
