@@ -46,13 +46,15 @@ __device__ __forceinline__ bool locked(const PathField &f, unsigned x, unsigned 
     return (f.maskw[mask_word_2d(y, x, f.pitch)] >> mask_bit_2d(x)) & 1u;
 }
 
-// harmonic_path_cpu.cpp:55-57: outside the grid, or a locked cell with u < 0 (an obstacle; goals are locked with u == 0)
+// harmonic_path_cpu.cpp:55-57: outside the grid, or a locked cell with u < 0 (an obstacle; goals are locked with u == 0).
+// Both loads are issued unconditionally (indices are clamped, so they are always safe): a walk is one long chain of
+// dependent memory round trips, and every load that does not wait for a branch shortens it.
 __device__ __forceinline__ bool usable(const PathField &f, float x, float y)
 {
     const unsigned cx = to_index(x + 0.5f), cy = to_index(y + 0.5f);
-    if (cx >= f.w || cy >= f.h) return false;
-    if (!locked(f, cx, cy)) return true;
-    return !(at(f, cx, cy) < 0.0f);
+    const bool lk = locked(f, cx, cy);
+    const float v = at(f, cx, cy);
+    return (cx < f.w) & (cy < f.h) & (!lk | !(v < 0.0f));
 }
 
 // harmonic_path_cpu.cpp:63-80
@@ -70,9 +72,12 @@ __device__ __forceinline__ float bilinear(const PathField &f, float x, float y)
 __device__ __forceinline__ bool gradient(const PathField &f, float x, float y, float cd, float &gx, float &gy)
 {
     const float xl = x - cd, xr = x + cd, yu = y - cd, yd = y + cd;
-    // the sample points sit within cd of a usable point, but bilinear() reads up to one cell further: stay inside
-    if (!usable(f, xl, y) || !usable(f, xr, y) || !usable(f, x, yu) || !usable(f, x, yd)) return false;
+    // the sample points sit within cd of a usable point, but bilinear() reads up to one cell further: stay inside.
+    // (All 24 loads of a step -- four usability tests, four bilinear samples -- are independent of one another and of
+    // the test's outcome, so they travel together: one memory round trip per step instead of three.)
+    const bool ok = usable(f, xl, y) & usable(f, xr, y) & usable(f, x, yu) & usable(f, x, yd);
     const float v0 = bilinear(f, xl, y), v1 = bilinear(f, xr, y), v2 = bilinear(f, x, yu), v3 = bilinear(f, x, yd);
+    if (!ok) return false;
     gx = (v1 - v0) / (2.0f * cd);
     gy = (v3 - v2) / (2.0f * cd);
     const double dx = (double)gx, dy = (double)gy;
@@ -99,29 +104,36 @@ __global__ void follow_paths_kernel(PathField f, unsigned n_paths, const float *
     const float half = step / 2.0f;
     if (max_points > 0) { pts[0] = x; pts[1] = y; }
     n = 1;
-    unsigned cx = to_index(x + 0.5f), cy = to_index(y + 0.5f);
+    // the (up to) five points before the newest one, newest first, in registers: the stuck test must not wait for the
+    // way-points to come back from memory
+    float hx0 = 0.0f, hy0 = 0.0f, hx1 = 0.0f, hy1 = 0.0f, hx2 = 0.0f, hy2 = 0.0f, hx3 = 0.0f, hy3 = 0.0f, hx4 = 0.0f, hy4 = 0.0f;
+    auto near = [&](float qx, float qy) {
+        const double dx = (double)(x - qx), dy = (double)(y - qy);
+        return (float)sqrt(dx * dx + dy * dy) < half;
+    };
     // the host loop runs while size() < 2 * maxLength values, i.e. n < max_points points
-    while (n < max_points && cx < f.w && cy < f.h && !locked(f, cx, cy)) {
-        // stuck: the newest point is within step / 2 of one of the (up to) five before it (harmonic_path_cpu.cpp:121-151)
-        bool is_stuck = false;
-        const unsigned back = n - 1 < 5u ? n - 1 : 5u;
-        for (unsigned j = 1; j <= back; j++) {
-            const double dx = (double)(x - pts[2 * (n - 1 - j)]), dy = (double)(y - pts[2 * (n - 1 - j) + 1]);
-            if ((float)sqrt(dx * dx + dy * dy) < half) is_stuck = true;
-        }
-        if (is_stuck) break;
+    for (;;) {
+        const unsigned cx = to_index(x + 0.5f), cy = to_index(y + 0.5f);
+        // everything this step reads depends on (x, y) only: the lock of the current cell and the gradient samples
+        const bool lk = locked(f, cx, cy);
         float gx = 0.0f, gy = 0.0f;
-        if (!gradient(f, x, y, cd, gx, gy)) {
+        const bool grad_ok = gradient(f, x, y, cd, gx, gy);
+        if (!(n < max_points && cx < f.w && cy < f.h && !lk)) break;
+        // stuck: the newest point is within step / 2 of one of the (up to) five before it (harmonic_path_cpu.cpp:121-151)
+        const unsigned back = n - 1 < 5u ? n - 1 : 5u;
+        const bool is_stuck = (back >= 1 && near(hx0, hy0)) | (back >= 2 && near(hx1, hy1)) | (back >= 3 && near(hx2, hy2)) |
+                              (back >= 4 && near(hx3, hy3)) | (back >= 5 && near(hx4, hy4));
+        if (is_stuck) break;
+        if (!grad_ok) {
             rc_out[id] = 12;  // EPIC_ERROR_INVALID_GRADIENT
             return;
         }
+        hx4 = hx3; hy4 = hy3; hx3 = hx2; hy3 = hy2; hx2 = hx1; hy2 = hy1; hx1 = hx0; hy1 = hy0; hx0 = x; hy0 = y;
         x += gx * step;
         y += gy * step;
         pts[2 * n] = x;
         pts[2 * n + 1] = y;
         n++;
-        cx = to_index(x + 0.5f);
-        cy = to_index(y + 0.5f);
     }
     if (n <= 2) {
         rc_out[id] = 13;  // EPIC_ERROR_INVALID_PATH
