@@ -239,7 +239,6 @@ __device__ __forceinline__ v2f df_pair_update_2d(v2f up, v2f dn, v2f lf, v2f rt,
 // out in the VOP3 form, on masks that come from v_cmp (ballot of a comparison) and are combined with scalar s_or.
 typedef uint64_t lmask;
 __device__ __forceinline__ lmask lanes_eq(float a, float b) { return __builtin_amdgcn_ballot_w64(a == b); }
-__device__ __forceinline__ lmask lanes_bit(uint32_t w, uint32_t bit) { return __builtin_amdgcn_ballot_w64((w & bit) != 0u); }
 __device__ __forceinline__ float sel(lmask m, float if_set, float if_clear)
 {
     float r;
