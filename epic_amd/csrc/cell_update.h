@@ -14,9 +14,9 @@
 //      third-party dependency that is not under /root/reference: GNU libc 2.35 (Ubuntu 22.04 image), whose
 //      expf/logf are Szabolcs Nagy's table+polynomial routines evaluated in double precision
 //      (glibc sysdeps/ieee754/flt-32/e_expf.c, e_logf.c; tables e_exp2f_data.c, e_logf_data.c; published in
-//      ARM optimized-routines).  They are restated here with the hardware's f64 units, tables staged in LDS.
-//      Result: <= 0.502 ulp and, measured on the device over every float in [1, 6] (log) and a dense sweep of
-//      [-104, 0] (exp), bit-identical to the host libm (tests/test_gpu_parity.py::test_device_libm_replica).
+//      ARM optimized-routines).  They are restated here with the hardware's f64 units (exp table in registers, log
+//      table in LDS).  Result: <= 0.502 ulp and bit-identical to the host libm over the whole input ranges -- every
+//      float in [-104, -0] for exp, every float in [1, 6] for log (tests/test_gpu_libm.py, 1.14e9 inputs).
 //      Why it is the default: the relaxation amplifies any SYSTEMATIC error of the update by ~R^2 (R = domain
 //      radius in cells, 1e4..1e6); v_log_f32 is biased by -0.1..-0.4 ulp and v_exp_f32 by -0.1 ulp near 1
 //      (tools/probe_transcendentals.hip, profiles/r01_probe_transcendentals.txt), which moved the converged field
@@ -117,8 +117,9 @@ __device__ __forceinline__ double bperm_f64(int byte_addr, int lo, int hi)
 }
 
 // e^x for x <= 0.  glibc e_expf.c: z = x N/ln2, k = round(z), r = z - k, s = 2^(k/N) from the table, cubic in r,
-// all in double, one rounding to float at the end.  Differences to the C source that cannot change the float result
-// (the double result carries ~2^-30 of slack, checked exhaustively by test_device_libm_replica): k is taken from the
+// all in double, one rounding to float at the end.  Differences to the C source that do not change the float result
+// for any input the sweeps can produce (the double result carries ~2^-30 of slack; tests/test_gpu_libm.py compares
+// every float in [-104, -0] with the host libm): k is taken from the
 // low word of fma(x, N/ln2, 1.5 * 2^52) (glibc's own non-intrinsic path does the same with an add), r comes from a
 // second fma instead of a rounded product, the cubic is in Horner form.
 __device__ __forceinline__ float precise_exp(float x, const MathTab &tab)
