@@ -60,3 +60,9 @@ def test_device_libm_replica_exhaustive():
     assert E.epic_hip_eval_math(d_in.data_ptr(), d_out.data_ptr(), x.size, 0, s) == 0
     torch.cuda.synchronize()
     assert not d_out.cpu().numpy().any()
+    # +0.0 is what a tie produces (w - mx with w == mx); the range above starts at -0.0
+    z = torch.zeros(64, dtype=torch.float32, device=dev)
+    o = torch.empty_like(z)
+    assert E.epic_hip_eval_math(z.data_ptr(), o.data_ptr(), 64, 0, s) == 0
+    torch.cuda.synchronize()
+    assert o.cpu().numpy().tolist() == [1.0] * 64
