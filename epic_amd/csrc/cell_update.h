@@ -14,8 +14,7 @@
 //      third-party dependency that is not under /root/reference: GNU libc 2.35 (Ubuntu 22.04 image), whose
 //      expf/logf are Szabolcs Nagy's table+polynomial routines evaluated in double precision
 //      (glibc sysdeps/ieee754/flt-32/e_expf.c, e_logf.c; tables e_exp2f_data.c, e_logf_data.c; published in
-//      ARM optimized-routines).  They are restated here with the hardware's f64 units (exp table in registers, log
-//      table in LDS).  Result: <= 0.502 ulp and bit-identical to the host libm over the whole input ranges -- every
+//      ARM optimized-routines).  They are restated here with the hardware's f64 units (tables in LDS).  Result: <= 0.502 ulp and bit-identical to the host libm over the whole input ranges -- every
 //      float in [-104, -0] for exp, every float in [1, 6] for log (tests/test_gpu_libm.py, 1.14e9 inputs).
 //      Why it is the default: the relaxation amplifies any SYSTEMATIC error of the update by ~R^2 (R = domain
 //      radius in cells, 1e4..1e6); v_log_f32 is biased by -0.1..-0.4 ulp and v_exp_f32 by -0.1 ulp near 1
@@ -78,43 +77,56 @@ __constant__ const double kLogTab[32] = {
     0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2,  0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2,
 };
 
-// Where the tables live.  exp: in registers, one entry per lane (lane L holds 2^((L & 31)/32) as two dwords), fetched
-// with ds_bpermute_b32 through the LDS crossbar: no LDS memory, and the byte address is just k << 2.  ds_bpermute reads
-// the SOURCE lane's register, so every lane of the wave must be active where it is used: the kernels keep all 64 lanes
-// live (pitch is a multiple of 256 floats).  log: in LDS, 64 entries of 16 bytes read with one ds_read_b128.  A
-// ds_bpermute costs 24 cycles per wave per SIMD on gfx950, a ds_read_b128 16 (tools/ubench_alu2.hip), and the four
-// permutes a register-resident log entry needs made the crossbar the co-limiter of the kernel next to the VALU.
+// Where the tables live: in LDS, both.  log: 64 entries of 16 bytes read with one ds_read_b128.  exp: the 32 entries
+// 2^(j/32) replicated 8 times (256 doubles), so that the byte offset of entry k mod 32 is (k & 0xff) << 3 -- ONE
+// instruction with sub-dword addressing (v_lshlrev_b32_sdwa ... src1_sel:BYTE_0) -- read with one ds_read_b64.
+// Earlier forms kept the tables in registers, one entry per lane, fetched with ds_bpermute_b32: that costs 24 cycles per
+// wave per SIMD on the LDS crossbar against 8.4 for a ds_read_b64 and 16 for a ds_read_b128 (tools/ubench_alu2.hip), and
+// the crossbar was the co-limiter of the kernel next to the VALU (8192^2 sweep: 155.8 us with the exp table on the
+// crossbar, 152.9 with a 32-entry LDS table addressed by and + shift, 149.7 with the replicated table; same box).
 // The log table is expanded over the binade index k = 0..3 (arguments in [0.7, 11.2) cover the sums of 4 or 6 terms
 // <= 1 with one term == 1): entry 16 k + i = {invc_i 2^-k, logc_i + k ln2}, so the kernel needs neither k, nor a
 // multiply, nor the normalised argument z = s 2^-k (s invc_i 2^-k is the same real number as z invc_i, so the fma that
 // forms r rounds alike).
 struct MathTab {
-    int e_lo, e_hi;      // 2^((L & 31)/32)
     const double2 *ln;   // LDS: {invc, logc + k ln2} x 64
+    const double *ex;    // LDS: 2^((j & 31)/32), j = 0..255
 };
 constexpr int kLnTabEntries = 64;
+constexpr int kExTabEntries = 256;
+constexpr int kMathLdsDoubles = 2 * kLnTabEntries + kExTabEntries;   // 3 KiB per workgroup
 
-// Call from every thread of the workgroup (it holds a barrier); `ln_lds` = kLnTabEntries double2 of LDS.
-__device__ __forceinline__ MathTab math_tables_load(double2 *ln_lds)
+// Staging is split in two so that a kernel can put its first row loads between them: math_tables_fetch() starts the
+// loads of this lane's table entries from constant memory, math_tables_commit() writes them to LDS.  EVERY WAVE WRITES
+// THE WHOLE TABLE (lane L: exp entries L, L + 64, L + 128, L + 192 -- one value, the table is periodic in 32 -- and
+// log entry L): the waves of a workgroup write identical bytes, a wave's own LDS instructions execute in order, so a
+// wave may read as soon as it has written and NO workgroup barrier is needed -- which also means a wave that finds no
+// work may leave before its siblings get here.  `lds` = kMathLdsDoubles doubles of LDS, 16-byte aligned.
+struct MathTabRegs {
+    uint64_t ex;
+    double invc, y0;
+};
+__device__ __forceinline__ MathTabRegs math_tables_fetch()
+{
+    const int lane = threadIdx.x & 63, k = lane >> 4, i = lane & 15;
+    MathTabRegs r;
+    r.ex = kExpTab[lane & 31] + ((uint64_t)(lane & 31) << 47);
+    r.invc = __builtin_ldexp(kLogTab[2 * i], -k);  // exact: a power of two
+    r.y0 = kLogTab[2 * i + 1] + (double)k * 0x1.62e42fefa39efp-1;
+    return r;
+}
+__device__ __forceinline__ MathTab math_tables_commit(const MathTabRegs &r, double *lds)
 {
     const int lane = threadIdx.x & 63;
-    const uint64_t e = kExpTab[lane & 31] + ((uint64_t)(lane & 31) << 47);
-    const int k = lane >> 4, i = lane & 15;
-    if (threadIdx.x < kLnTabEntries)
-        ln_lds[lane] = double2{__builtin_ldexp(kLogTab[2 * i], -k) /* exact */, kLogTab[2 * i + 1] + (double)k * 0x1.62e42fefa39efp-1};
-    __syncthreads();
-    MathTab t;
-    t.e_lo = (int)(uint32_t)e; t.e_hi = (int)(uint32_t)(e >> 32);
-    t.ln = ln_lds;
-    return t;
+    double2 *ln = reinterpret_cast<double2 *>(lds);
+    double *ex = lds + 2 * kLnTabEntries;
+    static_assert(kExTabEntries == 256 && kLnTabEntries == 64, "four exp entries and one log entry per lane");
+#pragma unroll
+    for (int j = 0; j < kExTabEntries; j += 64) reinterpret_cast<uint64_t *>(ex)[lane + j] = r.ex;
+    ln[lane] = double2{r.invc, r.y0};
+    return MathTab{ln, ex};
 }
-
-__device__ __forceinline__ double bperm_f64(int byte_addr, int lo, int hi)
-{
-    const uint32_t l = (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, lo);
-    const uint32_t h = (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, hi);
-    return __builtin_bit_cast(double, ((uint64_t)h << 32) | l);
-}
+__device__ __forceinline__ MathTab math_tables_load(double *lds) { return math_tables_commit(math_tables_fetch(), lds); }
 
 // e^x for x <= 0.  glibc e_expf.c: z = x N/ln2, k = round(z), r = z - k, s = 2^(k/N) from the table, cubic in r,
 // all in double, one rounding to float at the end.  Differences to the C source that do not change the float result
@@ -132,8 +144,9 @@ __device__ __forceinline__ float precise_exp(float x, const MathTab &tab)
     const double r = __builtin_fma(xd, kInvLn2N, -kd);
     // glibc forms s = 2^(k/N) by adding k << 47 to the table word; 2^((k mod N)/N) scaled by ldexp is the same number
     // and, unlike the integer add, degrades to 0 for the x = -1e6 terms (neighbours that are obstacles) without a clamp.
-    // Lane (k mod 64) holds entry k mod 32: the permute takes the lane from address bits 7..2, so k << 2 needs no mask.
-    const double s0 = bperm_f64(ki << 2, tab.e_lo, tab.e_hi);
+    int off;  // (k & 0xff) << 3: byte 0 of k, shifted, in one instruction
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off) : "v"(3), "v"(ki));
+    const double s0 = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab.ex) + off);
     double y = __builtin_fma(0x1.c6af84b912394p-20, r, 0x1.ebfce50fac4f3p-13);
     y = __builtin_fma(y, r, 0x1.62e42ff0c52d6p-6);
     y = __builtin_fma(y, r, 1.0);

@@ -98,9 +98,14 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
         df_tables_to_lds(ldsf);
         __syncthreads();
     }
-    __shared__ double2 ln_lds[kLnTabEntries];  // glibc's logf table (precise math only)
-    MathTab lds = {};  // libm tables (precise math only): exp entries in registers, log entries in LDS
-    if (MATH == kMathPrecise) lds = math_tables_load(ln_lds);
+    __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];  // glibc's expf / logf tables (precise math only)
+    // libm tables in LDS (precise math only): fetched here, written to LDS only after the first task's row loads are
+    // under way, so that the fetch from constant memory hides behind them (the small ROS maps run one row per wave:
+    // 3.45 -> 2.95 us per sweep of the 482 x 482 map)
+    MathTab lds = {};
+    MathTabRegs tab_regs = {};
+    if (MATH == kMathPrecise) tab_regs = math_tables_fetch();
+    bool tables_pending = MATH == kMathPrecise;
     const int lane = threadIdx.x & (kWave - 1);
     // wave-uniform quantities are forced into SGPRs: the row loop, its addresses and branches are scalar
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -238,9 +243,13 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
     // small grids -- go through a plain loop.
     auto row_at = [&](int i) { return rfirst + dir * i; };  // i-th row of the march
     const int nfull = nrows & ~3;
+    float4 q0 = ld(row_at(-1)), q1 = ld(row_at(0)), q2 = ld(row_at(1)), q3;
+    RowSide sa = side(row_at(0)), sb;  // row sides run one row ahead, alternating between two sets of SGPRs
+    if (tables_pending) {  // wave-uniform, once per wave
+        lds = math_tables_commit(tab_regs, math_lds);
+        tables_pending = false;
+    }
     if (nfull > 0) {
-        float4 q0 = ld(row_at(-1)), q1 = ld(row_at(0)), q2 = ld(row_at(1)), q3;
-        RowSide sa = side(row_at(0)), sb;  // row sides run one row ahead, alternating between two sets of SGPRs
         for (int i = 0; i < nfull; i += 4) {
             q3 = ld(row_at(i + 2)); sb = side(row_at(i + 1));
             row_step(row_at(i), q0, q1, q2, sa);
@@ -252,7 +261,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
             row_step(row_at(i + 3), q3, q0, q1, sb);
         }
     }
-    for (int i = nfull; i < nrows; ++i) {
+    if (nfull == 0 && nrows > 0) row_step(row_at(0), q0, q1, q2, sa);  // the one-row tasks of the small grids land here
+    for (int i = nfull == 0 ? 1 : nfull; i < nrows; ++i) {
         const int r = row_at(i);
         row_step(r, ld(r - dir), ld(r), ld(r + dir), side(r));
     }
@@ -302,9 +312,9 @@ template <int MATH>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Sweep2dArgs a)
 {
     __shared__ __attribute__((aligned(16))) float ldsf[kDfLdsFloats];
-    __shared__ double2 ln_lds[kLnTabEntries];
+    __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];
     MathTab lds = {};
-    if (MATH == kMathPrecise) lds = math_tables_load(ln_lds);
+    if (MATH == kMathPrecise) lds = math_tables_load(math_lds);
     if (MATH == kMathDf32) {
         df_tables_to_lds(ldsf);
         __syncthreads();
@@ -472,8 +482,8 @@ __global__ void set_cells_2d_kernel(float *u, uint32_t *maskw, int rows, int col
 __global__ void eval_math_kernel(const float *in, float *out, size_t n, int which)
 {
     __shared__ __attribute__((aligned(16))) float ldsf[kDfLdsFloats];
-    __shared__ double2 ln_lds[kLnTabEntries];
-    const MathTab lds = math_tables_load(ln_lds);
+    __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];
+    const MathTab lds = math_tables_load(math_lds);
     df_tables_to_lds(ldsf);
     __syncthreads();
     // the table fetch is a cross-lane permute: all 64 lanes must stay active, so the loop count is wave-uniform and

@@ -45,9 +45,9 @@ struct Sweep3dArgs {
 template <bool CHECK, int MATH, bool RB, bool TRACK>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3dArgs a)
 {
-    __shared__ double2 ln_lds[kLnTabEntries];  // glibc's logf table (precise math only)
-    MathTab lds = {};  // libm tables (precise math only): exp entries in registers, log entries in LDS
-    if (MATH == kMathPrecise) lds = math_tables_load(ln_lds);
+    __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];  // glibc's expf / logf tables (precise math only)
+    MathTab lds = {};  // libm tables in LDS (precise math only)
+    if (MATH == kMathPrecise) lds = math_tables_load(math_lds);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (TRACK) wake_reset_next(a.wake);
