@@ -259,17 +259,37 @@ __device__ __forceinline__ float sel(lmask m, float if_set, float if_clear)
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
     return r;
 }
-__device__ __forceinline__ float sel_one_or(lmask m, float if_clear)  // m ? 1.0f : if_clear
+// ---- selects as writes under a narrowed EXEC mask ------------------------------------------------------------------
+// "r = m ? a op b : r" for a cheap op (f32 add / sub) costs less as the instruction itself executed by the lanes of m
+// only than as the instruction plus a v_cndmask: 2-operand f32 adds issue in 2.4 cycles, a select in 4.4, and the two
+// s_mov that narrow and restore EXEC run on the scalar unit (8192^2 sweep 150.2 -> 147.6 us, same box; the lock select
+// of the kernels, a plain move, did not gain and stays a v_cndmask).  m must be a subset of the active lanes (it always
+// is: the masks are ballots); EXEC is restored to what it was.
+__device__ __forceinline__ void sub_where(float &r, lmask m, float a, float b)  // lanes of m: r = a - b
 {
-    float r;
-    asm("v_cndmask_b32_e64 %0, %1, 1.0, %2" : "=v"(r) : "v"(if_clear), "s"(m));
-    return r;
+    lmask save;
+    asm("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %2\n\tv_sub_f32 %0, %3, %4\n\ts_mov_b64 exec, %1"
+        : "+v"(r), "=&s"(save) : "s"(m), "v"(a), "v"(b));
 }
-__device__ __forceinline__ float sel_or_one(lmask m, float if_set)  // m ? if_set : 1.0f
+__device__ __forceinline__ void add_where(float &r, lmask m, float a, float b)  // lanes of m: r = a + b
 {
-    float r;
-    asm("v_cndmask_b32_e64 %0, 1.0, %1, %2" : "=v"(r) : "v"(if_set), "s"(m));
-    return r;
+    lmask save;
+    asm("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %2\n\tv_add_f32 %0, %3, %4\n\ts_mov_b64 exec, %1"
+        : "+v"(r), "=&s"(save) : "s"(m), "v"(a), "v"(b));
+}
+__device__ __forceinline__ void add_one_where(float &r, lmask m, float a)  // lanes of m: r = a + 1
+{
+    lmask save;
+    asm("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %2\n\tv_add_f32 %0, 1.0, %3\n\ts_mov_b64 exec, %1"
+        : "+v"(r), "=&s"(save) : "s"(m), "v"(a));
+}
+// lanes of m: t = a + 1, then r = t + b (the two additions of the "maximum is in the vertical pair" case, one narrowing)
+__device__ __forceinline__ void add_one_add_where(float &r, lmask m, float a, float b)
+{
+    lmask save;
+    float t;
+    asm("s_mov_b64 %2, exec\n\ts_mov_b64 exec, %3\n\tv_add_f32 %1, 1.0, %4\n\tv_add_f32 %0, %1, %5\n\ts_mov_b64 exec, %2"
+        : "+v"(r), "=&v"(t), "=&s"(save) : "s"(m), "v"(a), "v"(b));
 }
 
 template <int MATH>
@@ -304,12 +324,18 @@ __device__ __forceinline__ float cell_update_2d(float up, float down, float left
         const float hv = max2(up, down), lv = __builtin_fminf(up, down);
         mx = max2(max2(hv, left), right);
         const lmask P = lanes_eq(hv, mx), Q = lanes_eq(left, mx), PQ = P | Q;
-        const float ea = precise_exp(lv - mx, lds);
-        const float eb = precise_exp(sel(P, left, hv) - mx, lds);
-        const float ec = precise_exp(sel(PQ, right, left) - mx, lds);
-        float s = ea + sel_one_or(P, eb);
-        s = s + sel(P, eb, sel_one_or(Q, ec));
-        s = s + sel_or_one(PQ, ec);
+        // the selects are writes under a narrowed EXEC mask (above): every lane first takes the "right is the maximum"
+        // form, the lanes of Q and then of P overwrite it with theirs
+        float db = hv - mx, dc = left - mx;
+        sub_where(db, P, left, mx);
+        sub_where(dc, PQ, right, mx);
+        const float ea = precise_exp(lv - mx, lds), eb = precise_exp(db, lds), ec = precise_exp(dc, lds);
+        const float t1 = ea + eb;
+        float t2 = t1 + ec;
+        add_one_where(t2, Q, t1);
+        add_one_add_where(t2, P, ea, eb);   // P wins over Q: (ea + 1) + eb
+        float s = t2 + 1.0f;
+        add_where(s, PQ, t2, ec);
         const float t = mx + precise_ln(s, lds);
         return (float)((double)t - kLn4);
     }
