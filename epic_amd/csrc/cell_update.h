@@ -263,33 +263,30 @@ __device__ __forceinline__ float sel(lmask m, float if_set, float if_clear)
 // "r = m ? a op b : r" for a cheap op (f32 add / sub) costs less as the instruction itself executed by the lanes of m
 // only than as the instruction plus a v_cndmask: 2-operand f32 adds issue in 2.4 cycles, a select in 4.4, and the two
 // s_mov that narrow and restore EXEC run on the scalar unit (8192^2 sweep 150.2 -> 147.6 us, same box; the lock select
-// of the kernels, a plain move, did not gain and stays a v_cndmask).  m must be a subset of the active lanes (it always
-// is: the masks are ballots); EXEC is restored to what it was.
+// of the kernels, a plain move, did not gain and stays a v_cndmask).  EXEC is set back to ALL LANES afterwards, not to a
+// saved copy (one s_mov less per select, 147.8 -> 146.5 us): the update must be called with all 64 lanes active -- which
+// the sweep kernels guarantee anyway (rows are padded to whole wave strips; the DPP neighbour shifts need it too).
 __device__ __forceinline__ void sub_where(float &r, lmask m, float a, float b)  // lanes of m: r = a - b
 {
-    lmask save;
-    asm("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %2\n\tv_sub_f32 %0, %3, %4\n\ts_mov_b64 exec, %1"
-        : "+v"(r), "=&s"(save) : "s"(m), "v"(a), "v"(b));
+    asm("s_mov_b64 exec, %1\n\tv_sub_f32 %0, %2, %3\n\ts_mov_b64 exec, -1"
+        : "+v"(r) : "s"(m), "v"(a), "v"(b));
 }
 __device__ __forceinline__ void add_where(float &r, lmask m, float a, float b)  // lanes of m: r = a + b
 {
-    lmask save;
-    asm("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %2\n\tv_add_f32 %0, %3, %4\n\ts_mov_b64 exec, %1"
-        : "+v"(r), "=&s"(save) : "s"(m), "v"(a), "v"(b));
+    asm("s_mov_b64 exec, %1\n\tv_add_f32 %0, %2, %3\n\ts_mov_b64 exec, -1"
+        : "+v"(r) : "s"(m), "v"(a), "v"(b));
 }
 __device__ __forceinline__ void add_one_where(float &r, lmask m, float a)  // lanes of m: r = a + 1
 {
-    lmask save;
-    asm("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %2\n\tv_add_f32 %0, 1.0, %3\n\ts_mov_b64 exec, %1"
-        : "+v"(r), "=&s"(save) : "s"(m), "v"(a));
+    asm("s_mov_b64 exec, %1\n\tv_add_f32 %0, 1.0, %2\n\ts_mov_b64 exec, -1"
+        : "+v"(r) : "s"(m), "v"(a));
 }
 // lanes of m: t = a + 1, then r = t + b (the two additions of the "maximum is in the vertical pair" case, one narrowing)
 __device__ __forceinline__ void add_one_add_where(float &r, lmask m, float a, float b)
 {
-    lmask save;
     float t;
-    asm("s_mov_b64 %2, exec\n\ts_mov_b64 exec, %3\n\tv_add_f32 %1, 1.0, %4\n\tv_add_f32 %0, %1, %5\n\ts_mov_b64 exec, %2"
-        : "+v"(r), "=&v"(t), "=&s"(save) : "s"(m), "v"(a), "v"(b));
+    asm("s_mov_b64 exec, %2\n\tv_add_f32 %1, 1.0, %3\n\tv_add_f32 %0, %1, %4\n\ts_mov_b64 exec, -1"
+        : "+v"(r), "=&v"(t) : "s"(m), "v"(a), "v"(b));
 }
 
 template <int MATH>
