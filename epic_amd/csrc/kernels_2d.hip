@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
     const int r0 = a.row_begin + chunk * a.rows_per_task;
     const int r1 = min(r0 + a.rows_per_task, a.row_end);
 
-    const int col0 = strip * kStripCols;  // pitch % 256 == 0: every lane of every strip is in bounds (DPP / bpermute want all lanes live)
+    const int col0 = strip * kStripCols;  // pitch % 256 == 0: every lane of every strip is in bounds (DPP and the masked adds want all lanes live)
 
     // Addressing costs no VALU instruction: rows are reached through buffer descriptors (base = a few rows above the
     // task, so that byte offsets stay far below 4 GiB on any grid) with the lane part of the address in a VGPR that
@@ -486,7 +486,7 @@ __global__ void eval_math_kernel(const float *in, float *out, size_t n, int whic
     const MathTab lds = math_tables_load(math_lds);
     df_tables_to_lds(ldsf);
     __syncthreads();
-    // the table fetch is a cross-lane permute: all 64 lanes must stay active, so the loop count is wave-uniform and
+    // all 64 lanes stay active (as in the sweeps, whose update assumes it), so the loop count is wave-uniform and
     // out-of-range lanes work on a clamped index and skip the store
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
