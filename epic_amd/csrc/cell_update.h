@@ -266,26 +266,29 @@ __device__ __forceinline__ float sel(lmask m, float if_set, float if_clear)
 // of the kernels, a plain move, did not gain and stays a v_cndmask).  EXEC is set back to ALL LANES afterwards, not to a
 // saved copy (one s_mov less per select, 147.8 -> 146.5 us): the update must be called with all 64 lanes active -- which
 // the sweep kernels guarantee anyway (rows are padded to whole wave strips; the DPP neighbour shifts need it too).
+// The statements are `asm volatile`: executed where they are written, never sunk into a lane-masked region of the
+// compiler's own (where "all lanes" would be wrong); it also schedules better (145.8 -> 144.1 us).  DPP instructions
+// must keep their distance from these EXEC writes: see wave_from_left().
 __device__ __forceinline__ void sub_where(float &r, lmask m, float a, float b)  // lanes of m: r = a - b
 {
-    asm("s_mov_b64 exec, %1\n\tv_sub_f32 %0, %2, %3\n\ts_mov_b64 exec, -1"
+    asm volatile("s_mov_b64 exec, %1\n\tv_sub_f32 %0, %2, %3\n\ts_mov_b64 exec, -1"
         : "+v"(r) : "s"(m), "v"(a), "v"(b));
 }
 __device__ __forceinline__ void add_where(float &r, lmask m, float a, float b)  // lanes of m: r = a + b
 {
-    asm("s_mov_b64 exec, %1\n\tv_add_f32 %0, %2, %3\n\ts_mov_b64 exec, -1"
+    asm volatile("s_mov_b64 exec, %1\n\tv_add_f32 %0, %2, %3\n\ts_mov_b64 exec, -1"
         : "+v"(r) : "s"(m), "v"(a), "v"(b));
 }
 __device__ __forceinline__ void add_one_where(float &r, lmask m, float a)  // lanes of m: r = a + 1
 {
-    asm("s_mov_b64 exec, %1\n\tv_add_f32 %0, 1.0, %2\n\ts_mov_b64 exec, -1"
+    asm volatile("s_mov_b64 exec, %1\n\tv_add_f32 %0, 1.0, %2\n\ts_mov_b64 exec, -1"
         : "+v"(r) : "s"(m), "v"(a));
 }
 // lanes of m: t = a + 1, then r = t + b (the two additions of the "maximum is in the vertical pair" case, one narrowing)
 __device__ __forceinline__ void add_one_add_where(float &r, lmask m, float a, float b)
 {
     float t;
-    asm("s_mov_b64 exec, %2\n\tv_add_f32 %1, 1.0, %3\n\tv_add_f32 %0, %1, %4\n\ts_mov_b64 exec, -1"
+    asm volatile("s_mov_b64 exec, %2\n\tv_add_f32 %1, 1.0, %3\n\tv_add_f32 %0, %1, %4\n\ts_mov_b64 exec, -1"
         : "+v"(r), "=&v"(t) : "s"(m), "v"(a), "v"(b));
 }
 
@@ -371,19 +374,24 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t raw_buffer(const void *base)
 constexpr int kStoreNonTemporal = 2;  // cache-policy operand of the buffer store builtins: the "nt" bit
 
 // Full-wave (64-lane) shifts by one lane: one v_mov_b32_dpp each on gfx9-family ISAs.
+// A DPP instruction must not issue within 5 wait states of a write to EXEC (and 2 of a VALU write to its source
+// VGPR).  The compiler inserts those for the EXEC writes it knows about; the masked adds above narrow and restore EXEC
+// inside inline assembly, which it does not see (measured: a DPP two instructions after such a restore picked up the
+// narrowed mask and left lanes 12..15 of every row of 16 with the old value).  The shifts are therefore written out
+// with their own s_nop in front, whatever precedes them.
 // lane i receives lane i-1's `v`; lane 0 keeps `edge`.
 __device__ __forceinline__ float wave_from_left(float v, float edge)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge),
-                                                                 __builtin_bit_cast(int, v), 0x138 /*wave_shr:1*/,
-                                                                 0xf, 0xf, false));
+    float r = edge;
+    asm volatile("s_nop 4\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(v));
+    return r;
 }
 // lane i receives lane i+1's `v`; lane 63 keeps `edge`.
 __device__ __forceinline__ float wave_from_right(float v, float edge)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge),
-                                                                 __builtin_bit_cast(int, v), 0x130 /*wave_shl:1*/,
-                                                                 0xf, 0xf, false));
+    float r = edge;
+    asm volatile("s_nop 4\n\tv_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(v));
+    return r;
 }
 
 // max over the 64 lanes of a non-negative float, result valid in every lane.
