@@ -120,11 +120,15 @@ def test_fixed_sweeps_2d_vs_oracle_jacobi(m, seed, dens):
         assert gdelta == wdelta, (gdelta, wdelta)
 
 
-@pytest.mark.parametrize("m,rpt", [([66000, 300], 0), ([6, 80000], 0), ([1200, 9000], 64), ([40000, 520], 5)])
+@pytest.mark.parametrize("m,rpt", [([66000, 300], 0), ([6, 80000], 0), ([1200, 9000], 64), ([40000, 520], 5),
+                                   ([200, 700], 16), ([96, 300], 8), ([33, 257], 4)])
 def test_extreme_aspect_ratios(m, rpt):
     """More rows than a grid dimension may hold in y (65535), hundreds of strips per row, the tallest tasks: the buffer
     addressing (32-bit row offsets from a per-task base), the row-per-block mask packing and the scalar row sides must
-    hold on all of them.  Goals at both ends so that every part of the grid sees moving values."""
+    hold on all of them.  Goals at both ends so that every part of the grid sees moving values.  The small grids with
+    multi-row tasks run the pipelined four-row path with a single wave per SIMD, i.e. with a wave's instructions issuing
+    back to back -- the setting in which a missing wait state (EXEC write -> DPP, cell_update.h) shows; the tall ones
+    make a wave of a list-driven launch walk several tiles."""
     u0, locked = synthetic_grid(m, 17, 0.05)
     free = np.flatnonzero(locked == 0)
     for idx in (free[0], free[free.size // 2], free[-1]):
