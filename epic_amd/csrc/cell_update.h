@@ -397,6 +397,7 @@ __device__ __forceinline__ float wave_from_right(float v, float edge)
 // max over the 64 lanes of a non-negative float, result valid in every lane.
 __device__ __forceinline__ float wave_max(float v)
 {
+    asm volatile("s_nop 4");  // the shuffles may be DPP: keep them 5 wait states away from any EXEC write (see above)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = max2(v, __shfl_xor(v, off, 64));
     return v;
