@@ -115,18 +115,27 @@ __device__ __forceinline__ MathTabRegs math_tables_fetch()
     r.y0 = kLogTab[2 * i + 1] + (double)k * 0x1.62e42fefa39efp-1;
     return r;
 }
-__device__ __forceinline__ MathTab math_tables_commit(const MathTabRegs &r, double *lds)
+// Where the two tables sit inside `lds`: pure address arithmetic on the kernel's __shared__ array, so that the LDS
+// offsets of the lookups are compile-time constants (keep it out of loop-carried variables: a table pointer that went
+// through the task loop of the list-driven kernels cost one v_add_u32 per lookup).
+__device__ __forceinline__ MathTab math_tables_at(double *lds)
+{
+    return MathTab{reinterpret_cast<double2 *>(lds), lds + 2 * kLnTabEntries};
+}
+__device__ __forceinline__ void math_tables_commit(const MathTabRegs &r, double *lds)
 {
     const int lane = threadIdx.x & 63;
-    double2 *ln = reinterpret_cast<double2 *>(lds);
-    double *ex = lds + 2 * kLnTabEntries;
+    const MathTab t = math_tables_at(lds);
     static_assert(kExTabEntries == 256 && kLnTabEntries == 64, "four exp entries and one log entry per lane");
 #pragma unroll
-    for (int j = 0; j < kExTabEntries; j += 64) reinterpret_cast<uint64_t *>(ex)[lane + j] = r.ex;
-    ln[lane] = double2{r.invc, r.y0};
-    return MathTab{ln, ex};
+    for (int j = 0; j < kExTabEntries; j += 64) reinterpret_cast<uint64_t *>(const_cast<double *>(t.ex))[lane + j] = r.ex;
+    const_cast<double2 *>(t.ln)[lane] = double2{r.invc, r.y0};
 }
-__device__ __forceinline__ MathTab math_tables_load(double *lds) { return math_tables_commit(math_tables_fetch(), lds); }
+__device__ __forceinline__ MathTab math_tables_load(double *lds)
+{
+    math_tables_commit(math_tables_fetch(), lds);
+    return math_tables_at(lds);
+}
 
 // e^x for x <= 0.  glibc e_expf.c: z = x N/ln2, k = round(z), r = z - k, s = 2^(k/N) from the table, cubic in r,
 // all in double, one rounding to float at the end.  Differences to the C source that do not change the float result

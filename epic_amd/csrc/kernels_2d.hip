@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
     // libm tables in LDS (precise math only): fetched here, written to LDS only after the first task's row loads are
     // under way, so that the fetch from constant memory hides behind them (the small ROS maps run one row per wave:
     // 3.45 -> 2.95 us per sweep of the 482 x 482 map)
-    MathTab lds = {};
+    const MathTab lds = math_tables_at(math_lds);
     MathTabRegs tab_regs = {};
     if (MATH == kMathPrecise) tab_regs = math_tables_fetch();
     bool tables_pending = MATH == kMathPrecise;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
     float4 q0 = ld(row_at(-1)), q1 = ld(row_at(0)), q2 = ld(row_at(1)), q3;
     RowSide sa = side(row_at(0)), sb;  // row sides run one row ahead, alternating between two sets of SGPRs
     if (tables_pending) {  // wave-uniform, once per wave
-        lds = math_tables_commit(tab_regs, math_lds);
+        math_tables_commit(tab_regs, math_lds);
         tables_pending = false;
     }
     if (nfull > 0) {
