@@ -262,6 +262,11 @@ __device__ __forceinline__ v2f df_pair_update_2d(v2f up, v2f dn, v2f lf, v2f rt,
 // out in the VOP3 form, on masks that come from v_cmp (ballot of a comparison) and are combined with scalar s_or.
 typedef uint64_t lmask;
 __device__ __forceinline__ lmask lanes_eq(float a, float b) { return __builtin_amdgcn_ballot_w64(a == b); }
+// lanes whose two values differ as BIT PATTERNS (activity tracking: "was this cell rewritten with different bits")
+__device__ __forceinline__ lmask lanes_ne(float a, float b)
+{
+    return __builtin_amdgcn_ballot_w64(__builtin_bit_cast(uint32_t, a) != __builtin_bit_cast(uint32_t, b));
+}
 __device__ __forceinline__ float sel(lmask m, float if_set, float if_clear)
 {
     float r;

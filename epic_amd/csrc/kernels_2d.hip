@@ -170,7 +170,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
 
     // activity tracking: cells of this lane rewritten with different bits -- anywhere, in its first / last column
     // (meaningful in lane 0 / lane 63), in the task's first / last row
-    bool chg_any = false, chg_x = false, chg_w = false, chg_top = false, chg_bot = false;
+    // (lane masks in SGPRs: four compares per row, everything else on the scalar unit)
+    lmask chg_any = 0, chg_x = 0, chg_w = 0, chg_top = 0, chg_bot = 0;
     // One row: up / c / dn are rows r-1, r, r+1 of u_in, h the two strip-edge values of row r.
     auto row_step = [&](int r, const float4 &up, const float4 &c, const float4 &dn, const RowSide &h) {
         const float lf = wave_from_left(c.w, h.l);   // u[r][col-1]
@@ -224,8 +225,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
             dmax = max2(dmax, fabsf(c.w - o.w));
         }
         if (TRACK) {
-            const bool cx = f2u(o.x) != f2u(c.x), cw = f2u(o.w) != f2u(c.w);
-            const bool rc = cx | cw | (f2u(o.y) != f2u(c.y)) | (f2u(o.z) != f2u(c.z));
+            const lmask cx = lanes_ne(o.x, c.x), cw = lanes_ne(o.w, c.w);
+            const lmask rc = cx | cw | lanes_ne(o.y, c.y) | lanes_ne(o.z, c.z);
             chg_any |= rc;
             chg_x |= cx;
             chg_w |= cw;
@@ -269,10 +270,10 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
 
     if (TRACK) {
         // wake the tiles that read what this task changed: itself, and the neighbour across each edge that changed
-        const bool any = __ballot(chg_any) != 0;                       // (ballots first: all lanes take part)
-        const bool first_col = (__ballot(chg_x) & 1ull) != 0;         // lane 0 holds column 0 of the strip
-        const bool last_col = (__ballot(chg_w) >> 63) != 0;           // lane 63 holds column 255
-        const bool first_row = __ballot(chg_top) != 0, last_row = __ballot(chg_bot) != 0;
+        const bool any = chg_any != 0;
+        const bool first_col = (chg_x & 1ull) != 0;         // lane 0 holds column 0 of the strip
+        const bool last_col = (chg_w >> 63) != 0;           // lane 63 holds column 255
+        const bool first_row = chg_top != 0, last_row = chg_bot != 0;
         int t = task;
         bool want = any;                                                                     // lane 0: the tile itself
         if (lane == 1) { t = task - 1; want = strip > 0 && first_col; }                      // its left neighbour

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3d
         return RowSide{row[hcol_l], row[hcol_r], mk[0], mk[1], mk[2], mk[3]};
     };
 
-    bool chg_any = false, chg_x = false, chg_w = false, chg_top = false, chg_bot = false;  // as in the 2-D kernel
+    lmask chg_any = 0, chg_x = 0, chg_w = 0, chg_top = 0, chg_bot = 0;  // lane masks, as in the 2-D kernel
 
     // One row: up / c / dn = rows x1 - 1, x1, x1 + 1 of the plane, pa / pb = row x1 of the planes x0 - 1 and x0 + 1.
     auto row_step = [&](int r, const float4 &up, const float4 &c, const float4 &dn, const float4 &pa, const float4 &pb,
@@ -145,8 +145,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3d
             dmax = max2(dmax, fabsf(c.w - o.w));
         }
         if (TRACK) {
-            const bool cx = f2u(o.x) != f2u(c.x), cw = f2u(o.w) != f2u(c.w);
-            const bool rc2 = cx | cw | (f2u(o.y) != f2u(c.y)) | (f2u(o.z) != f2u(c.z));
+            const lmask cx = lanes_ne(o.x, c.x), cw = lanes_ne(o.w, c.w);
+            const lmask rc2 = cx | cw | lanes_ne(o.y, c.y) | lanes_ne(o.z, c.z);
             chg_any |= rc2;
             chg_x |= cx;
             chg_w |= cw;
@@ -181,9 +181,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3d
     if (TRACK) {
         // wake the tiles that read what this task changed: itself, the in-plane neighbours across the edges that
         // changed, and the same tile of the two neighbouring planes (every cell has an x0 - 1 and an x0 + 1 neighbour)
-        const bool any = __ballot(chg_any) != 0;
-        const bool first_col = (__ballot(chg_x) & 1ull) != 0, last_col = (__ballot(chg_w) >> 63) != 0;
-        const bool first_row = __ballot(chg_top) != 0, last_row = __ballot(chg_bot) != 0;
+        const bool any = chg_any != 0;
+        const bool first_col = (chg_x & 1ull) != 0, last_col = (chg_w >> 63) != 0;
+        const bool first_row = chg_top != 0, last_row = chg_bot != 0;
         const int per_plane = a.nchunks * a.nstrips;
         int t = tile;
         bool want = any;
