@@ -42,8 +42,14 @@ struct Sweep3dArgs {
 
 // RB = true: the reference's 3-D red-black half-sweep in place (in == out): cells with (x0 + x1 + x2 + currentIteration)
 // even are recomputed (harmonic_cpu.cpp:89-102), all six neighbours have the other colour.
+// At least 5 waves per SIMD: left alone, the list-driven precise variant takes 146 VGPRs (3 waves per SIMD); held to
+// 5 waves it relaxes the 512^3 benchmark in 1.285 s instead of 1.33 (7 waves: 1.31; no spills either way).
+#ifndef EPIC_SWEEP3D_WAVES
+#define EPIC_SWEEP3D_WAVES 5
+#endif
+#define EPIC_SWEEP3D_OCC __attribute__((amdgpu_waves_per_eu(EPIC_SWEEP3D_WAVES)))
 template <bool CHECK, int MATH, bool RB, bool TRACK>
-__global__ __launch_bounds__(kWave * kWavesPerBlock) void sweep3d_kernel(Sweep3dArgs a)
+__global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP3D_OCC void sweep3d_kernel(Sweep3dArgs a)
 {
     __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];  // glibc's expf / logf tables (precise math only)
     MathTab lds = {};  // libm tables in LDS (precise math only)
