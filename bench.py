@@ -46,8 +46,9 @@ def parse():
     ap.add_argument("--stagger", type=int, default=100, help="sweeps per step (numIterationsToStaggerCheck)")
     ap.add_argument("--rows-per-task", type=int, default=0)
     ap.add_argument("--cpu-half-sweeps", type=int, default=40, help="bounded CPU sample (about 0.35 s each at 8192^2)")
-    ap.add_argument("--math", choices=("precise", "df32", "fast", "traffic"), default="precise",
-                    help="precise = libm-equivalent exp/log (the parity mode, default); fast = v_exp_f32/v_log_f32")
+    ap.add_argument("--math", choices=("precise", "tol", "df32", "fast", "traffic"), default="precise",
+                    help="precise = libm-equivalent exp/log (bit-exact parity mode, default); tol = one exp-class split per "
+                         "cell shared by its neighbours (tolerance parity mode); fast = v_exp_f32/v_log_f32")
     ap.add_argument("--scheme", choices=("jacobi", "redblack"), default="jacobi",
                     help="jacobi = ping-pong sweep of every cell (default); redblack = the reference's in-place half-sweeps")
     ap.add_argument("--halo", type=int, default=8, help="N > 1: ghost rows per side = sweeps between two halo exchanges")
@@ -197,7 +198,7 @@ def main():
         assert E.harmonic_initialize_gpu(h, 1024) == 0
         if args.rows_per_task:
             E.epic_hip_set_rows_per_task(h, args.rows_per_task)
-        assert E.epic_hip_set_math_mode(h, {"precise": 0, "fast": 1, "traffic": 2, "df32": 3}[args.math]) == 0
+        assert E.epic_hip_set_math_mode(h, {"precise": 0, "fast": 1, "traffic": 2, "df32": 3, "tol": 4}[args.math]) == 0
         assert E.epic_hip_set_scheme(h, 1 if args.scheme == "redblack" else 0) == 0
         assert E.epic_hip_set_activity_tracking(h, 1 if args.track else 0) == 0
         ms = ct.c_float(0.0)

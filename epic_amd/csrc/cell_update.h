@@ -51,6 +51,7 @@ constexpr int kMathPrecise = 0;
 constexpr int kMathFast = 1;
 constexpr int kMathTraffic = 2;  // diagnostic: neighbours averaged with 3 adds -- same loads/stores, almost no ALU
 constexpr int kMathDf32 = 3;     // packed-f32 double-float exp/log (2-D kernel), see below
+constexpr int kMathTol = 4;      // one exp-class evaluation per cell (shared by its neighbours) + one f64 log: the tolerance mode, see below
 
 // ---- libm-equivalent expf / logf in f64 (glibc 2.35 algorithm, see header) --------------------------------
 
@@ -164,7 +165,7 @@ __device__ __forceinline__ float precise_exp(float x, const MathTab &tab)
 
 // ln(s) for s in [0.7, 11.2).  glibc e_logf.c: s = 2^k z with z in [OFF, 2 OFF) split into 16 sub-intervals,
 // r = z invc - 1, ln s = log1p(r) + logc + k ln2 with a cubic for log1p, all in double.
-__device__ __forceinline__ float precise_ln(float sf, const MathTab &tab)
+__device__ __forceinline__ double precise_ln_d(float sf, const MathTab &tab)  // the value before glibc's final rounding
 {
     const uint32_t tmp = __builtin_bit_cast(uint32_t, sf) - 0x3f330000u;
     // table entry 16 k + i = bits 24..19 of tmp; its byte offset is that times 16
@@ -174,9 +175,9 @@ __device__ __forceinline__ float precise_ln(float sf, const MathTab &tab)
     const double r2 = r * r;
     double y = __builtin_fma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);
     y = __builtin_fma(-0x1.00ea348b88334p-2, r2, y);
-    y = __builtin_fma(y, r2, y0 + r);
-    return (float)y;
+    return __builtin_fma(y, r2, y0 + r);
 }
+__device__ __forceinline__ float precise_ln(float sf, const MathTab &tab) { return (float)precise_ln_d(sf, tab); }
 
 // ---- kMathDf32: nearly-correctly-rounded exp/log in f32 "double-float" arithmetic, two cells per instruction ------
 // On gfx950 an f64 op, a conversion and a v_fma_f32 all issue at ~4.3 cycles per wave, but v_pk_fma_f32 /
@@ -255,6 +256,99 @@ __device__ __forceinline__ v2f df_pair_update_2d(v2f up, v2f dn, v2f lf, v2f rt,
     return v2f{(float)((double)t.x - kLn4), (float)((double)t.y - kLn4)};
 }
 
+// ---- kMathTol: one exp-class evaluation and one log per CELL instead of per NEIGHBOUR -------------------------------
+// The reference evaluates u' = mx + ln(sum_i e^(u_i - mx)) - ln 2n with 2n expf and one logf per cell
+// (harmonic_cpu.cpp:60-70), and every u_i goes through expf 2n times per sweep, once for each of its neighbours.  Here
+// every cell's potential is split ONCE per sweep into  e^u = q 2^n :
+//     n = rint(u log2 e),  f = u log2 e - n in [-1/2, 1/2]  (log2 e as hi + lo, two fma),  q = 2^f in [0.707, 1.414]
+//     by a degree-7 f32 polynomial (tools/gen_exp2_poly.py: 0.003 ulp approximation error, mean 4e-4 ulp),
+// all of it element-wise on the row a lane has just loaded -- so it runs as PACKED f32 (v_pk_fma_f32: two cells per
+// instruction, and the dwordx4 a lane loads is two aligned register pairs already).  The neighbours of a cell reuse
+// those pairs:
+//     N = max n_i,   S = ((q_a 2^(n_a-N) + q_b 2^(n_b-N)) + q_c 2^(n_c-N)) + ...    f32, the reference's order
+//     l = (float)(ln S + (N ln2 - mx))   = ln of the reference's s (S / q_mx), f64 inside, rounded to f32 where the
+//                                          reference rounds logf(s)
+//     t = mx + l,   u' = (float)((double)t - ln 2n)                                  as the reference
+// The rounding stages of the reference -- f32 sum, l to f32, mx + l to f32, the f64 subtraction to f32 -- are all there;
+// what differs is the noise inside the sum (the terms carry the rounding of q instead of the rounding of expf, ~4e-8
+// relative either way, zero mean).  The terms are never formed by subtracting the maximum first, so Jacobi's two
+// interleaved chains see the same term for the same neighbour value; on the reference's maps Jacobi, red-black and any
+// tiling end in ONE fixed point with max |du| = 0 exactly, which is what lets the reference's absolute termination test
+// fire under Jacobi (df32 above ends in two fixed points one ulp apart on umass).
+// tools/tol_study.c is the same arithmetic on the CPU, operation for operation, and relaxes the reference's maps with
+// it; oracle/harmonic_oracle.c holds the checker's copy (oracle_tol_*), against which the kernels are bit-identical.
+// n is carried as the BIT PATTERN of zm = u log2 e + 1.5 * 2^23 (an integer-valued float whose low mantissa bits are n
+// in two's complement): bit patterns of such floats order and subtract like the integers, so max and differences need
+// no conversion.  |u| <= 1e6 (the seed of obstacles / unreached cells) keeps n inside the 22 bits the trick has.
+constexpr float kTolLog2eHi = 0x1.715476p+0f, kTolLog2eLo = 0x1.4ae0bep-26f;  // hi + lo = log2(e) to 49 bits
+constexpr float kTolMagic = 12582912.0f;                                      // 1.5 * 2^23
+constexpr uint32_t kTolMagicBits = 0x4b400000u;
+constexpr double kLn2d = 0x1.62e42fefa39efp-1;
+
+struct Split2 { v2f q; v2f zm; };  // zm's bit patterns carry n
+__device__ __forceinline__ Split2 tol_split2(v2f u)
+{
+    Split2 s;
+    s.zm = pk_fma(u, splat(kTolLog2eHi), splat(kTolMagic));
+    const v2f nf = s.zm - splat(kTolMagic);
+    v2f f = pk_fma(u, splat(kTolLog2eHi), -nf);
+    f = pk_fma(u, splat(kTolLog2eLo), f);
+    v2f p = pk_fma(f, splat(0x1.e5ba06p-17f), splat(0x1.44227cp-13f));
+    p = pk_fma(f, p, splat(0x1.5da0f4p-10f));
+    p = pk_fma(f, p, splat(0x1.3b2a4ap-7f));
+    p = pk_fma(f, p, splat(0x1.c6b072p-5f));
+    p = pk_fma(f, p, splat(0x1.ebfbep-3f));
+    p = pk_fma(f, p, splat(0x1.62e43p-1f));
+    s.q = pk_fma(f, p, splat(1.0f));
+    return s;
+}
+// a row of four cells: q and the bit patterns of zm
+struct Split4 { float qx, qy, qz, qw; uint32_t nx, ny, nz, nw; };
+__device__ __forceinline__ Split4 tol_split4(const float4 &u)
+{
+    const Split2 a = tol_split2(v2f{u.x, u.y}), b = tol_split2(v2f{u.z, u.w});
+    return Split4{a.q.x, a.q.y, b.q.x, b.q.y, f2u(a.zm.x), f2u(a.zm.y), f2u(b.zm.x), f2u(b.zm.y)};
+}
+__device__ __forceinline__ uint32_t umax2(uint32_t a, uint32_t b) { return a > b ? a : b; }
+// One term: q 2^(n - N).  v_ldexp_f32 takes the full i32 exponent: a neighbour at the seed (-1e6: n - N ~ -1.4e6) gives 0.
+__device__ __forceinline__ float tol_term(float q, uint32_t n, uint32_t nmax) { return __builtin_ldexpf(q, (int)(n - nmax)); }
+// The reference's last steps on s_ref = S / q_mx, whose logarithm is ln S - (mx - N ln2):
+//     l = (float)(ln S + (N ln2 - mx))   ONE rounding to f32, where the reference rounds logf(s)
+//     t = mx + l                         f32, as the reference
+//     u' = (float)((double)t - ln 2n)    as the reference (kLn4 / kLn6)
+__device__ __forceinline__ float tol_finish(float s, uint32_t nmax, float mx, double ln2n, const MathTab &tab)
+{
+    const double nd = (double)(int)(nmax - kTolMagicBits);
+    const float l = (float)(precise_ln_d(s, tab) + __builtin_fma(nd, kLn2d, -(double)mx));
+    const float t = mx + l;
+    return (float)((double)t - ln2n);
+}
+// neighbours in the reference's order of summation: up, down, left, right (harmonic_cpu.cpp:65-68); u* = their values
+__device__ __forceinline__ float tol_update_2d(float uu, float ud, float ul, float ur, float qu, uint32_t nu, float qd,
+                                               uint32_t nd, float ql, uint32_t nl, float qr, uint32_t nr, const MathTab &tab)
+{
+    const uint32_t nmax = umax2(umax2(umax2(nu, nd), nl), nr);
+    const float mx = max2(max2(max2(uu, ud), ul), ur);
+    float s = tol_term(qu, nu, nmax) + tol_term(qd, nd, nmax);
+    s = s + tol_term(ql, nl, nmax);
+    s = s + tol_term(qr, nr, nmax);
+    return tol_finish(s, nmax, mx, kLn4, tab);
+}
+// x0-1, x0+1, x1-1, x1+1, x2-1, x2+1 (harmonic_cpu.cpp:118-123)
+__device__ __forceinline__ float tol_update_3d(float u0, float u1, float u2, float u3, float u4, float u5, float q0, uint32_t n0,
+                                               float q1, uint32_t n1, float q2, uint32_t n2, float q3, uint32_t n3, float q4,
+                                               uint32_t n4, float q5, uint32_t n5, const MathTab &tab)
+{
+    const uint32_t nmax = umax2(umax2(umax2(umax2(umax2(n0, n1), n2), n3), n4), n5);
+    const float mx = max2(max2(max2(max2(max2(u0, u1), u2), u3), u4), u5);
+    float s = tol_term(q0, n0, nmax) + tol_term(q1, n1, nmax);
+    s = s + tol_term(q2, n2, nmax);
+    s = s + tol_term(q3, n3, nmax);
+    s = s + tol_term(q4, n4, nmax);
+    s = s + tol_term(q5, n5, nmax);
+    return tol_finish(s, nmax, mx, kLn6, tab);
+}
+
 // ---- selects on lane masks held in SGPR pairs ----------------------------------------------------------------------
 // Measured on gfx950 (tools/ubench_alu2.hip, profiles/r01_ubench_alu2.txt): v_cndmask_b32 in its VOP2 form (mask in
 // VCC) issues in ~22 cycles unless it directly follows the compare that wrote VCC; the VOP3 form with the mask in an
@@ -269,9 +363,15 @@ __device__ __forceinline__ lmask lanes_ne(float a, float b)
 }
 __device__ __forceinline__ float sel(lmask m, float if_set, float if_clear)
 {
+#ifndef EPIC_ASM_SELECTS
+    // the lane mask handed to the compiler as the i1 it is: one v_cndmask_b32_e64 on the SGPR pair (checked in the ISA:
+    // all selects of the sweep kernels come out in the VOP3 form), and the compiler sees the instruction
+    return __builtin_amdgcn_inverse_ballot_w64(m) ? if_set : if_clear;
+#else  // the same instruction written out (A/B builds: make EXTRA=-DEPIC_ASM_SELECTS)
     float r;
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
     return r;
+#endif
 }
 // ---- selects as writes under a narrowed EXEC mask ------------------------------------------------------------------
 // "r = m ? a op b : r" for a cheap op (f32 add / sub) costs less as the instruction itself executed by the lanes of m
@@ -281,30 +381,38 @@ __device__ __forceinline__ float sel(lmask m, float if_set, float if_clear)
 // saved copy (one s_mov less per select, 147.8 -> 146.5 us): the update must be called with all 64 lanes active -- which
 // the sweep kernels guarantee anyway (rows are padded to whole wave strips; the DPP neighbour shifts need it too).
 // The statements are `asm volatile`: executed where they are written, never sunk into a lane-masked region of the
-// compiler's own (where "all lanes" would be wrong); it also schedules better (145.8 -> 144.1 us).  DPP instructions
-// must keep their distance from these EXEC writes: see wave_from_left().
+// compiler's own (where "all lanes" would be wrong); it also schedules better (145.8 -> 144.1 us).
+// EXEC IS ON THE CLOBBER LIST: the compiler then knows that the statement writes EXEC and keeps the wait states the
+// hardware wants between an EXEC write and a DPP instruction (5) by itself -- without the clobber it scheduled a DPP
+// shift two instructions behind such a restore, which left lanes 12..15 of every 16 with stale neighbours.  (clang
+// warns that EXEC is a reserved register that "may not be preserved": it is not -- it is all-lanes afterwards, which is
+// what it was before, the precondition stated above.)  tools/isa_hazards.py checks the distance in the generated ISA.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void sub_where(float &r, lmask m, float a, float b)  // lanes of m: r = a - b
 {
     asm volatile("s_mov_b64 exec, %1\n\tv_sub_f32 %0, %2, %3\n\ts_mov_b64 exec, -1"
-        : "+v"(r) : "s"(m), "v"(a), "v"(b));
+        : "+v"(r) : "s"(m), "v"(a), "v"(b) : "exec");
 }
 __device__ __forceinline__ void add_where(float &r, lmask m, float a, float b)  // lanes of m: r = a + b
 {
     asm volatile("s_mov_b64 exec, %1\n\tv_add_f32 %0, %2, %3\n\ts_mov_b64 exec, -1"
-        : "+v"(r) : "s"(m), "v"(a), "v"(b));
+        : "+v"(r) : "s"(m), "v"(a), "v"(b) : "exec");
 }
 __device__ __forceinline__ void add_one_where(float &r, lmask m, float a)  // lanes of m: r = a + 1
 {
     asm volatile("s_mov_b64 exec, %1\n\tv_add_f32 %0, 1.0, %2\n\ts_mov_b64 exec, -1"
-        : "+v"(r) : "s"(m), "v"(a));
+        : "+v"(r) : "s"(m), "v"(a) : "exec");
 }
 // lanes of m: t = a + 1, then r = t + b (the two additions of the "maximum is in the vertical pair" case, one narrowing)
 __device__ __forceinline__ void add_one_add_where(float &r, lmask m, float a, float b)
 {
     float t;
     asm volatile("s_mov_b64 exec, %2\n\tv_add_f32 %1, 1.0, %3\n\tv_add_f32 %0, %1, %4\n\ts_mov_b64 exec, -1"
-        : "+v"(r), "=&v"(t) : "s"(m), "v"(a), "v"(b));
+        : "+v"(r), "=&v"(t) : "s"(m), "v"(a), "v"(b) : "exec");
 }
+
+#pragma clang diagnostic pop
 
 template <int MATH>
 __device__ __forceinline__ float m_exp(float x, const MathTab &lds)
@@ -387,31 +495,55 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t raw_buffer(const void *base)
 }
 constexpr int kStoreNonTemporal = 2;  // cache-policy operand of the buffer store builtins: the "nt" bit
 
-// Full-wave (64-lane) shifts by one lane: one v_mov_b32_dpp each on gfx9-family ISAs.
-// A DPP instruction must not issue within 5 wait states of a write to EXEC (and 2 of a VALU write to its source
-// VGPR).  The compiler inserts those for the EXEC writes it knows about; the masked adds above narrow and restore EXEC
-// inside inline assembly, which it does not see (measured: a DPP two instructions after such a restore picked up the
-// narrowed mask and left lanes 12..15 of every row of 16 with the old value).  The shifts are therefore written out
-// with their own s_nop in front, whatever precedes them.
+// One row of a lane (16 bytes) to memory, non-temporal.
+// HAZARD (measured on gfx950, ROCm 7.2): a VALU instruction that writes a data register of a 16-byte buffer store in the
+// instruction slots right behind the store can still reach the store -- with v_pk_fma_f32 directly behind it, lanes
+// 12..15 of every 16 of the SECOND data register went to memory with the new value (the first Horner step of the next
+// row's split instead of u).  The compiler's hazard recognizer knows this hazard but exempts stores whose soffset is an
+// SGPR, which is how every store here is addressed, so it pads nothing.  store_row() therefore keeps the four data
+// registers alive past the store (they are operands of the statement behind it, which the "memory" clobber orders after
+// the store) and pads four wait states before anything else may issue.  tools/isa_hazards.py scans the generated ISA
+// for any VALU write to store data within that distance (tests/test_isa_hazards.py).
+typedef unsigned vu4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_row(const __amdgpu_buffer_rsrc_t &rsrc, float x, float y, float z, float w, unsigned lane_off,
+                                          unsigned row_off)
+{
+    const vu4_t data = {__builtin_bit_cast(uint32_t, x), __builtin_bit_cast(uint32_t, y), __builtin_bit_cast(uint32_t, z),
+                        __builtin_bit_cast(uint32_t, w)};
+    __builtin_amdgcn_raw_buffer_store_b128(data, rsrc, lane_off, row_off, kStoreNonTemporal);
+    asm volatile("s_nop 3" : : "v"(data) : "memory");
+}
+
+// Full-wave (64-lane) shifts by one lane: one v_mov_b32_dpp each on gfx9-family ISAs, through the compiler's builtin so
+// that its hazard recognizer places the wait states a DPP instruction needs (5 behind a write to EXEC -- the masked adds
+// above declare theirs --, 2 behind a VALU write to its source VGPR).  EPIC_ASM_DPP selects the round-1 form with the
+// instruction written out behind an s_nop 4 (A/B builds).
 // lane i receives lane i-1's `v`; lane 0 keeps `edge`.
 __device__ __forceinline__ float wave_from_left(float v, float edge)
 {
+#ifndef EPIC_ASM_DPP
+    return u2f(__builtin_amdgcn_update_dpp(f2u(edge), f2u(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+#else
     float r = edge;
     asm volatile("s_nop 4\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(v));
     return r;
+#endif
 }
 // lane i receives lane i+1's `v`; lane 63 keeps `edge`.
 __device__ __forceinline__ float wave_from_right(float v, float edge)
 {
+#ifndef EPIC_ASM_DPP
+    return u2f(__builtin_amdgcn_update_dpp(f2u(edge), f2u(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+#else
     float r = edge;
     asm volatile("s_nop 4\n\tv_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(v));
     return r;
+#endif
 }
 
 // max over the 64 lanes of a non-negative float, result valid in every lane.
 __device__ __forceinline__ float wave_max(float v)
 {
-    asm volatile("s_nop 4");  // the shuffles may be DPP: keep them 5 wait states away from any EXEC write (see above)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = max2(v, __shfl_xor(v, off, 64));
     return v;

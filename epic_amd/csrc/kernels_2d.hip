@@ -104,8 +104,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
     // 3.45 -> 2.95 us per sweep of the 482 x 482 map)
     const MathTab lds = math_tables_at(math_lds);
     MathTabRegs tab_regs = {};
-    if (MATH == kMathPrecise) tab_regs = math_tables_fetch();
-    bool tables_pending = MATH == kMathPrecise;
+    constexpr bool TOL = MATH == kMathTol;  // one split (exp-class evaluation) per cell, shared by its neighbours (cell_update.h)
+    if (MATH == kMathPrecise || TOL) tab_regs = math_tables_fetch();
+    bool tables_pending = MATH == kMathPrecise || TOL;
     const int lane = threadIdx.x & (kWave - 1);
     // wave-uniform quantities are forced into SGPRs: the row loop, its addresses and branches are scalar
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -173,11 +174,28 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
     // (lane masks in SGPRs: four compares per row, everything else on the scalar unit)
     lmask chg_any = 0, chg_x = 0, chg_w = 0, chg_top = 0, chg_bot = 0;
     // One row: up / c / dn are rows r-1, r, r+1 of u_in, h the two strip-edge values of row r.
-    auto row_step = [&](int r, const float4 &up, const float4 &c, const float4 &dn, const RowSide &h) {
+    // (tol math: su / sc / sd are the splits of the three rows, computed once per row as it enters the window)
+    auto row_step = [&](int r, const float4 &up, const float4 &c, const float4 &dn, const RowSide &h, const Split4 &su,
+                        const Split4 &sc, const Split4 &sd) {
         const float lf = wave_from_left(c.w, h.l);   // u[r][col-1]
         const float rt = wave_from_right(c.x, h.r);  // u[r][col+4]
         float4 o;
-        if (RB) {
+        if (TOL) {
+            // the two strip-edge cells of the row: wave-uniform values, split as one packed pair
+            const Split2 hs = tol_split2(v2f{h.l, h.r});
+            const float ql = wave_from_left(sc.qw, hs.q.x), qr = wave_from_right(sc.qx, hs.q.y);
+            const uint32_t nl = f2u(wave_from_left(u2f(sc.nw), hs.zm.x)), nr = f2u(wave_from_right(u2f(sc.nx), hs.zm.y));
+            o = c;
+            const bool odd_cols = !RB || ((r + a.parity) & 1) == 0, even_cols = !RB || !odd_cols;  // scalar
+            if (even_cols) {
+                o.x = sel(h.m0, c.x, tol_update_2d(up.x, dn.x, lf, c.y, su.qx, su.nx, sd.qx, sd.nx, ql, nl, sc.qy, sc.ny, lds));
+                o.z = sel(h.m2, c.z, tol_update_2d(up.z, dn.z, c.y, c.w, su.qz, su.nz, sd.qz, sd.nz, sc.qy, sc.ny, sc.qw, sc.nw, lds));
+            }
+            if (odd_cols) {
+                o.y = sel(h.m1, c.y, tol_update_2d(up.y, dn.y, c.x, c.z, su.qy, su.ny, sd.qy, sd.ny, sc.qx, sc.nx, sc.qz, sc.nz, lds));
+                o.w = sel(h.m3, c.w, tol_update_2d(up.w, dn.w, c.z, rt, su.qw, su.nw, sd.qw, sd.nw, sc.qz, sc.nz, qr, nr, lds));
+            }
+        } else if (RB) {
             o = c;
             if (((r + a.parity) & 1) == 0) {  // scalar: this row's active cells sit in the odd columns (.y, .w)
                 float ny, nw;
@@ -212,7 +230,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
             o.z = cell_update_2d<MATH>(up.z, dn.z, c.y, c.w, lds);
             o.w = cell_update_2d<MATH>(up.w, dn.w, c.z, rt, lds);
         }
-        if (!RB) {
+        if (!RB && !TOL) {
             o.x = sel(h.m0, c.x, o.x);
             o.y = sel(h.m1, c.y, o.y);
             o.z = sel(h.m2, c.z, o.z);
@@ -234,7 +252,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
             if (r == r1 - 1) chg_bot = rc;
         }
         // non-temporal: the row is not read again before the next sweep (traffic-only build 115.6 -> 96.6 us with it)
-        __builtin_amdgcn_raw_buffer_store_b128(vu4{f2u(o.x), f2u(o.y), f2u(o.z), f2u(o.w)}, rout, lane16, row_off(r), kStoreNonTemporal);
+        store_row(rout, o.x, o.y, o.z, o.w, lane16, row_off(r));
     };
 
     // Software pipeline, rotated by hand over a 4-row register ring so that no register moves (and hence no
@@ -250,22 +268,34 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
         math_tables_commit(tab_regs, math_lds);
         tables_pending = false;
     }
+    // tol math: the splits ride the same ring as the rows; a row is split when it enters the window as the row below
+    Split4 s0 = {}, s1 = {}, s2 = {}, s3 = {};
+    auto split = [&](const float4 &q) { return TOL ? tol_split4(q) : Split4{}; };
+    if (TOL) { s0 = split(q0); s1 = split(q1); }
     if (nfull > 0) {
         for (int i = 0; i < nfull; i += 4) {
             q3 = ld(row_at(i + 2)); sb = side(row_at(i + 1));
-            row_step(row_at(i), q0, q1, q2, sa);
+            s2 = split(q2);
+            row_step(row_at(i), q0, q1, q2, sa, s0, s1, s2);
             q0 = ld(row_at(i + 3)); sa = side(row_at(i + 2));
-            row_step(row_at(i + 1), q1, q2, q3, sb);
+            s3 = split(q3);
+            row_step(row_at(i + 1), q1, q2, q3, sb, s1, s2, s3);
             q1 = ld(row_at(i + 4)); sb = side(row_at(i + 3));
-            row_step(row_at(i + 2), q2, q3, q0, sa);
+            s0 = split(q0);
+            row_step(row_at(i + 2), q2, q3, q0, sa, s2, s3, s0);
             q2 = ld(row_at(i + 5)); sa = side(row_at(i + 4));
-            row_step(row_at(i + 3), q3, q0, q1, sb);
+            s1 = split(q1);
+            row_step(row_at(i + 3), q3, q0, q1, sb, s3, s0, s1);
         }
     }
-    if (nfull == 0 && nrows > 0) row_step(row_at(0), q0, q1, q2, sa);  // the one-row tasks of the small grids land here
+    if (nfull == 0 && nrows > 0) {  // the one-row tasks of the small grids land here
+        s2 = split(q2);
+        row_step(row_at(0), q0, q1, q2, sa, s0, s1, s2);
+    }
     for (int i = nfull == 0 ? 1 : nfull; i < nrows; ++i) {
         const int r = row_at(i);
-        row_step(r, ld(r - dir), ld(r), ld(r + dir), side(r));
+        const float4 ru = ld(r - dir), rc = ld(r), rd = ld(r + dir);
+        row_step(r, ru, rc, rd, side(r), split(ru), split(rc), split(rd));
     }
 
     if (TRACK) {
@@ -412,8 +442,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
         const float4 x = stage(r, true, mp, mq, mr, kcur);    // colour B of row r from the fresh A cells around it
         kcur = knext;
         if (owner)  // non-temporal, as in the plain sweep
-            __builtin_amdgcn_raw_buffer_store_b128(vu4{f2u(x.x), f2u(x.y), f2u(x.z), f2u(x.w)}, rout, lane_off, row_off(r),
-                                                   kStoreNonTemporal);
+            store_row(rout, x.x, x.y, x.z, x.w, lane_off, row_off(r));
     };
     int r = r0;
     for (; r + 3 <= r1; r += 3) {
@@ -535,6 +564,7 @@ void launch_sweep_2d_math(int math, int nblocks, hipStream_t stream, const Sweep
     if (math == kMathFast) hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathFast, RB, TRACK>), grid, block, 0, stream, a);
     else if (math == kMathTraffic) hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathTraffic, RB, TRACK>), grid, block, 0, stream, a);
     else if (math == kMathDf32) hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathDf32, RB, TRACK>), grid, block, 0, stream, a);
+    else if (math == kMathTol) hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathTol, RB, TRACK>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathPrecise, RB, TRACK>), grid, block, 0, stream, a);
 }
 template <bool CHECK, bool RB>

@@ -163,6 +163,7 @@ EPIC_ERROR_DEVICE_MALLOC = 4
 MATH_PRECISE = 0
 MATH_FAST = 1
 MATH_DF32 = 3
+MATH_TOL = 4
 SCHEME_JACOBI = 0
 SCHEME_REDBLACK = 1
 EPIC_CELL_TYPE_GOAL = 0

@@ -8,10 +8,10 @@
  * It restates, in plain C, the algorithm of the reference's CPU solver
  * (/root/reference/libepic/src/harmonic/harmonic_cpu.cpp) so that a checker exists on
  * the GPU box, where /root/reference does not.  Every function cites the reference
- * lines it follows.  Parity status: PINNED -- tests/test_oracle_vs_ref.py compares it
- * bit for bit with the reference sources compiled here into oracle/_ref/ (see Makefile)
- * and tests/test_oracle_golden.py with the committed vectors in tests/golden/ that were
- * produced by that reference build (tests/golden/generate_goldens.py).
+ * lines it follows.  Parity status: PINNED -- tests/test_oracle.py compares it bit for bit
+ * with the reference sources compiled here into oracle/_ref/ (see Makefile) and with the
+ * committed vectors in tests/golden/ that were produced by that reference build
+ * (tests/golden/generate_goldens.py).
  *
  * Build: gcc -O3 -std=c11 -shared -fPIC (NO -ffast-math, NO -march=native: the
  * reference is built with plain -O3, libepic/Makefile:1-21, and its rounding sequence

@@ -1,0 +1,249 @@
+/*
+ * tol_checker.c -- CPU statement of the library's `tol` math mode (epic_amd/csrc/cell_update.h: tol_split2 /
+ * tol_update_2d / tol_update_3d), operation for operation.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE (same rule as harmonic_oracle.c: only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load liboracle.so; nothing under epic_amd/ links or calls it).
+ *
+ * What it is NOT: the reference's arithmetic.  The reference evaluates, per cell, 2n expf and one logf
+ * (/root/reference/libepic/src/harmonic/harmonic_cpu.cpp:60-70, :110-123; restated in harmonic_oracle.c).  The tol mode
+ * computes the same update u' = ln(sum_i e^(u_i)) - ln 2n from ONE split e^u = q 2^n per cell, shared by the cell's
+ * neighbours, keeps every rounding stage of the reference (f32 sum, l to f32, mx + l to f32, f64 subtraction to f32) and
+ * differs from it only in the noise inside the sum.
+ * Parity with the REFERENCE is therefore a tolerance statement (1e-5 max(1, |u|), against the reference-generated
+ * goldens in tests/golden/), tested on the device and here.  This file exists so that the KERNELS (tiling, strip seams,
+ * halo splits, masks, red-black colouring, work lists) can still be checked at tolerance 0: the device result must equal
+ * this code bit for bit, sweep for sweep.  tools/tol_study.c includes it to relax the reference's maps on the CPU.
+ *
+ * Needs correctly rounded fmaf / fma (libm's are) and no contraction (-std=c11 implies -ffp-contract=off).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct TolHarmonic {  /* the reference's struct layout, libepic/include/epic/harmonic/harmonic.h:44-64 */
+    unsigned int n;
+    unsigned int *m;
+    float *u;
+    unsigned int *locked;
+    float epsilon;
+    float delta;
+    unsigned int numIterationsToStaggerCheck;
+    unsigned int currentIteration;
+    unsigned int *d_m;
+    float *d_u;
+    unsigned int *d_locked;
+    float *d_delta;
+} TolHarmonic;
+
+static inline uint32_t tol_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+#define TOL_LH 0x1.715476p+0f   /* log2(e) = LH + LL to 49 bits */
+#define TOL_LL 0x1.4ae0bep-26f
+#define TOL_MAGIC 12582912.0f   /* 1.5 * 2^23 */
+#define TOL_MAGIC_BITS 0x4b400000u
+
+/* e^u = q 2^n; *zb = bit pattern of the float whose low mantissa bits are n (cell_update.h: tol_split2) */
+static inline void tol_split(float u, float *q, uint32_t *zb)
+{
+    const float zm = fmaf(u, TOL_LH, TOL_MAGIC);
+    const float nf = zm - TOL_MAGIC;
+    float f = fmaf(u, TOL_LH, -nf);
+    f = fmaf(u, TOL_LL, f);
+    float p = fmaf(f, 0x1.e5ba06p-17f, 0x1.44227cp-13f);
+    p = fmaf(f, p, 0x1.5da0f4p-10f);
+    p = fmaf(f, p, 0x1.3b2a4ap-7f);
+    p = fmaf(f, p, 0x1.c6b072p-5f);
+    p = fmaf(f, p, 0x1.ebfbep-3f);
+    p = fmaf(f, p, 0x1.62e43p-1f);
+    *q = fmaf(f, p, 1.0f);
+    *zb = tol_f2u(zm);
+}
+
+/* glibc logf's table (sysdeps/ieee754/flt-32/e_logf_data.c) and cubic, evaluated in double and NOT rounded to float
+ * (cell_update.h: precise_ln_d, including its table layout {invc 2^-k, logc + k ln2}) */
+static const double kTolLogTab[32] = {
+    0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2, 0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2,
+    0x1.49539f0f010bp+0,  -0x1.01eae7f513a67p-2, 0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3,
+    0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3, 0x1.25e227b0b8eap+0,  -0x1.1aa2bc79c81p-3,
+    0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4, 0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4,
+    0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5, 0x1p+0,               0x0p+0,
+    0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5,  0x1.ca4b31f026aap-1,  0x1.c5e53aa362eb4p-4,
+    0x1.b2036576afce6p-1, 0x1.526e57720db08p-3,  0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3,
+    0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2,  0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2,
+};
+static inline double tol_ln_core(double sd, int i, int k)   /* entry 16 k + i = {invc 2^-k, logc + k ln2} */
+{
+    const double invc = ldexp(kTolLogTab[2 * i], -k), y0 = kTolLogTab[2 * i + 1] + (double)k * 0x1.62e42fefa39efp-1;
+    const double r = fma(sd, invc, -1.0);
+    const double r2 = r * r;
+    double y = fma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);
+    y = fma(-0x1.00ea348b88334p-2, r2, y);
+    return fma(y, r2, y0 + r);
+}
+static inline double tol_ln(float sf)
+{
+    const uint32_t tmp = tol_f2u(sf) - 0x3f330000u;
+    return tol_ln_core((double)sf, (tmp >> 19) & 15, (int)(tmp >> 23) & 3);
+}
+static inline uint32_t tol_umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+static inline float tol_fmax(float a, float b) { return a < b ? b : a; }
+static inline float tol_term(float q, uint32_t zb, uint32_t nmax)
+{
+    int e = (int)(zb - nmax);
+    if (e < -300) e = -300;   /* ldexpf(q, anything below -174) is 0 either way; keeps the int argument in range */
+    return ldexpf(q, e);
+}
+/* The reference's last steps on s_ref = S / q_mx, whose logarithm is ln S - (mx - N ln2) (cell_update.h: tol_finish):
+ * l rounded to f32 where the reference rounds logf(s), t = mx + l in f32, then the f64 subtraction of ln(2n). */
+static inline float tol_finish(float s, uint32_t nmax, float mx, double ln2n)
+{
+    const double nd = (double)(int)(nmax - TOL_MAGIC_BITS);
+    const float l = (float)(tol_ln(s) + fma(nd, 0x1.62e42fefa39efp-1, -(double)mx));
+    const float t = mx + l;
+    return (float)((double)t - ln2n);
+}
+
+static float tol_cell_2d(const float *u, const float *q, const uint32_t *zb, size_t c, size_t m1)
+{
+    const size_t a = c - m1, b = c + m1, l = c - 1, r = c + 1;   /* up, down, left, right: harmonic_cpu.cpp:65-68 */
+    const uint32_t nmax = tol_umax(tol_umax(tol_umax(zb[a], zb[b]), zb[l]), zb[r]);
+    float s = tol_term(q[a], zb[a], nmax) + tol_term(q[b], zb[b], nmax);
+    s = s + tol_term(q[l], zb[l], nmax);
+    s = s + tol_term(q[r], zb[r], nmax);
+    const float mx = tol_fmax(tol_fmax(tol_fmax(u[a], u[b]), u[l]), u[r]);
+    return tol_finish(s, nmax, mx, 0x1.62e42fefa39efp+0);
+}
+
+static float tol_cell_3d(const float *u, const float *q, const uint32_t *zb, size_t c, size_t s0, size_t s1)
+{
+    const size_t nb[6] = {c - s0, c + s0, c - s1, c + s1, c - 1, c + 1};   /* harmonic_cpu.cpp:118-123 */
+    uint32_t nmax = zb[nb[0]];
+    for (int i = 1; i < 6; i++) nmax = tol_umax(nmax, zb[nb[i]]);
+    float s = tol_term(q[nb[0]], zb[nb[0]], nmax) + tol_term(q[nb[1]], zb[nb[1]], nmax);
+    for (int i = 2; i < 6; i++) s = s + tol_term(q[nb[i]], zb[nb[i]], nmax);
+    float mx = u[nb[0]];
+    for (int i = 1; i < 6; i++) mx = tol_fmax(mx, u[nb[i]]);
+    return tol_finish(s, nmax, mx, 0x1.cab0bfa2a2002p+0 /* log(6.0) */);
+}
+
+static size_t tol_cells(const TolHarmonic *h)
+{
+    size_t c = 1;
+    for (unsigned int i = 0; i < h->n; i++) c *= h->m[i];
+    return c;
+}
+
+/* One iteration over `in`: Jacobi (colour < 0: every unlocked interior cell, in -> out, out pre-filled with in) or the
+ * reference's red-black colour rule in place (in == out): 2-D (x0 + x1 + iteration) odd, 3-D (x0 + x1 + x2 + iteration)
+ * even (harmonic_cpu.cpp:46-51, :89-102).  q / zb: scratch of one float / word per cell.  Returns max |du|. */
+static float tol_iterate(const TolHarmonic *h, const float *in, float *out, int colour_iteration, float *q, uint32_t *zb)
+{
+    const size_t cells = tol_cells(h);
+    float d = 0.0f;
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < cells; i++) tol_split(in[i], &q[i], &zb[i]);
+    if (h->n == 2) {
+        const unsigned int m0 = h->m[0], m1 = h->m[1];
+#pragma omp parallel for schedule(static) reduction(max : d)
+        for (unsigned int x0 = 1; x0 < m0 - 1; x0++)
+            for (unsigned int x1 = 1; x1 + 1 < m1; x1++) {
+                const size_t c = (size_t)x0 * m1 + x1;
+                if (h->locked[c]) continue;
+                if (colour_iteration >= 0 && ((x0 + x1 + (unsigned int)colour_iteration) & 1u) == 0) continue;
+                const float v = tol_cell_2d(in, q, zb, c, m1);
+                d = tol_fmax(d, fabsf(in[c] - v));
+                out[c] = v;
+            }
+    } else {
+        const unsigned int m0 = h->m[0], m1 = h->m[1], m2 = h->m[2];
+        const size_t s0 = (size_t)m1 * m2, s1 = m2;
+#pragma omp parallel for schedule(static) reduction(max : d)
+        for (unsigned int x0 = 1; x0 < m0 - 1; x0++)
+            for (unsigned int x1 = 1; x1 + 1 < m1; x1++)
+                for (unsigned int x2 = 1; x2 + 1 < m2; x2++) {
+                    const size_t c = x0 * s0 + x1 * s1 + x2;
+                    if (h->locked[c]) continue;
+                    if (colour_iteration >= 0 && ((x0 + x1 + x2 + (unsigned int)colour_iteration) & 1u) != 0) continue;
+                    const float v = tol_cell_3d(in, q, zb, c, s0, s1);
+                    d = tol_fmax(d, fabsf(in[c] - v));
+                    out[c] = v;
+                }
+    }
+    return d;
+}
+
+/* `iterations` iterations on h->u in place; scheme 0 = Jacobi, 1 = red-black.  h->delta = max |du| of the LAST
+ * iteration; currentIteration advances. */
+int oracle_tol_run(TolHarmonic *h, unsigned int iterations, int scheme)
+{
+    if (h == NULL || h->m == NULL || h->u == NULL || h->locked == NULL || (h->n != 2 && h->n != 3)) return 2;
+    const size_t cells = tol_cells(h);
+    float *a = h->u, *b = scheme == 0 ? (float *)malloc(cells * sizeof(float)) : NULL;
+    float *q = (float *)malloc(cells * sizeof(float));
+    uint32_t *zb = (uint32_t *)malloc(cells * sizeof(uint32_t));
+    if (!q || !zb || (scheme == 0 && !b)) { free(b); free(q); free(zb); return 2; }
+    for (unsigned int s = 0; s < iterations; s++) {
+        if (scheme == 0) {
+            memcpy(b, a, cells * sizeof(float));
+            h->delta = tol_iterate(h, a, b, -1, q, zb);
+            float *t = a; a = b; b = t;
+        } else {
+            h->delta = tol_iterate(h, a, a, (int)(h->currentIteration & 1u), q, zb);
+        }
+        h->currentIteration++;
+    }
+    if (a != h->u) { memcpy(h->u, a, cells * sizeof(float)); free(a); }
+    else free(b);
+    free(q); free(zb);
+    return 0;
+}
+
+/* The reference's driver loop (harmonic_cpu.cpp:136-178) around the tol iteration: a check when
+ * currentIteration % stagger == 0, exit right after a converged check with currentIteration >= max(m). */
+int oracle_tol_complete(TolHarmonic *h, int scheme)
+{
+    if (h == NULL || h->m == NULL || h->u == NULL || h->locked == NULL || h->epsilon <= 0.0f ||
+        (h->n != 2 && h->n != 3) || h->numIterationsToStaggerCheck == 0)
+        return 2;
+    unsigned int mMax = 0;
+    for (unsigned int i = 0; i < h->n; i++) mMax = h->m[i] > mMax ? h->m[i] : mMax;
+    const size_t cells = tol_cells(h);
+    float *a = h->u, *b = scheme == 0 ? (float *)malloc(cells * sizeof(float)) : NULL;
+    float *q = (float *)malloc(cells * sizeof(float));
+    uint32_t *zb = (uint32_t *)malloc(cells * sizeof(uint32_t));
+    if (!q || !zb || (scheme == 0 && !b)) { free(b); free(q); free(zb); return 2; }
+    h->currentIteration = 0;
+    h->delta = h->epsilon + 1.0f;
+    int converged = 0;
+    while (!converged || h->currentIteration < mMax) {
+        const int check = (h->currentIteration % h->numIterationsToStaggerCheck) == 0;
+        float d;
+        if (scheme == 0) {
+            memcpy(b, a, cells * sizeof(float));
+            d = tol_iterate(h, a, b, -1, q, zb);
+            float *t = a; a = b; b = t;
+        } else {
+            d = tol_iterate(h, a, a, (int)(h->currentIteration & 1u), q, zb);
+        }
+        h->currentIteration++;
+        if (check) { h->delta = d; converged = d < h->epsilon; }
+        else converged = 0;
+        if (h->currentIteration > 4000000u) break;   /* a mode that does not settle must not hang the test run */
+    }
+    if (a != h->u) { memcpy(h->u, a, cells * sizeof(float)); free(a); }
+    else free(b);
+    free(q); free(zb);
+    return converged ? 0 : 3;
+}
+
+/* split statistics hook for the tests: e^u against q 2^n */
+void oracle_tol_split(const float *u, size_t n, float *q, int *e)
+{
+    for (size_t i = 0; i < n; i++) {
+        uint32_t zb;
+        tol_split(u[i], &q[i], &zb);
+        e[i] = (int)(zb - TOL_MAGIC_BITS);
+    }
+}

@@ -94,6 +94,10 @@ def oracle():
         lib.oracle_synthetic.restype = None
         lib.oracle_cell_updates.restype = ct.c_uint64
         lib.oracle_reset_counters.restype = None
+        lib.oracle_tol_run.argtypes = (P, ct.c_uint, ct.c_int)      # oracle/tol_checker.c
+        lib.oracle_tol_complete.argtypes = (P, ct.c_int)
+        lib.oracle_tol_split.argtypes = (ct.POINTER(ct.c_float), ct.c_size_t, ct.POINTER(ct.c_float), ct.POINTER(ct.c_int))
+        lib.oracle_tol_split.restype = None
         lib.oracle_libm_mismatches.restype = ct.c_size_t
         lib.oracle_libm_mismatches.argtypes = (ct.c_int, ct.c_uint32, ct.c_size_t, ct.c_void_p, ct.POINTER(ct.c_size_t),
                                                ct.c_int)
