@@ -266,8 +266,8 @@ __device__ __forceinline__ v2f df_pair_update_2d(v2f up, v2f dn, v2f lf, v2f rt,
 // instruction, and the dwordx4 a lane loads is two aligned register pairs already).  The neighbours of a cell reuse
 // those pairs:
 //     N = max n_i,   S = ((q_a 2^(n_a-N) + q_b 2^(n_b-N)) + q_c 2^(n_c-N)) + ...    f32, the reference's order
-//     l = (float)(ln S + (N ln2 - mx))   = ln of the reference's s (S / q_mx), f64 inside, rounded to f32 where the
-//                                          reference rounds logf(s)
+//     l = (float)(ln S - f_mx ln2)       = ln of the reference's s (S / q_mx; f_mx = mx log2 e - N), f64 inside, rounded
+//                                          to f32 where the reference rounds logf(s)
 //     t = mx + l,   u' = (float)((double)t - ln 2n)                                  as the reference
 // The rounding stages of the reference -- f32 sum, l to f32, mx + l to f32, the f64 subtraction to f32 -- are all there;
 // what differs is the noise inside the sum (the terms carry the rounding of q instead of the rounding of expf, ~4e-8
@@ -312,41 +312,50 @@ __device__ __forceinline__ Split4 tol_split4(const float4 &u)
 __device__ __forceinline__ uint32_t umax2(uint32_t a, uint32_t b) { return a > b ? a : b; }
 // One term: q 2^(n - N).  v_ldexp_f32 takes the full i32 exponent: a neighbour at the seed (-1e6: n - N ~ -1.4e6) gives 0.
 __device__ __forceinline__ float tol_term(float q, uint32_t n, uint32_t nmax) { return __builtin_ldexpf(q, (int)(n - nmax)); }
-// The reference's last steps on s_ref = S / q_mx, whose logarithm is ln S - (mx - N ln2):
-//     l = (float)(ln S + (N ln2 - mx))   ONE rounding to f32, where the reference rounds logf(s)
+// Everything a cell's update needs from the maximum mx of its neighbours: N (as the bit pattern of zm, the same fma as in
+// tol_split2, so it IS the largest of the neighbours' patterns) and f = mx log2 e - N, the fraction the split of that
+// neighbour found, recomputed from mx in three f32 instructions -- cheaper than selecting it among the neighbours.
+struct TolMax { float mx, f; uint32_t nmax; };
+__device__ __forceinline__ TolMax tol_max(float mx)
+{
+    const float zm = __builtin_fmaf(mx, kTolLog2eHi, kTolMagic);
+    const float nf = zm - kTolMagic;
+    float f = __builtin_fmaf(mx, kTolLog2eHi, -nf);
+    f = __builtin_fmaf(mx, kTolLog2eLo, f);
+    return TolMax{mx, f, f2u(zm)};
+}
+// The reference's last steps on s_ref = S / q_mx = S 2^-f, whose logarithm is ln S - f ln2:
+//     l = (float)(ln S - f ln2)          ONE rounding to f32, where the reference rounds logf(s)
 //     t = mx + l                         f32, as the reference
 //     u' = (float)((double)t - ln 2n)    as the reference (kLn4 / kLn6)
-__device__ __forceinline__ float tol_finish(float s, uint32_t nmax, float mx, double ln2n, const MathTab &tab)
+__device__ __forceinline__ float tol_finish(float s, const TolMax &m, double ln2n, const MathTab &tab)
 {
-    const double nd = (double)(int)(nmax - kTolMagicBits);
-    const float l = (float)(precise_ln_d(s, tab) + __builtin_fma(nd, kLn2d, -(double)mx));
-    const float t = mx + l;
+    const float l = (float)__builtin_fma(-(double)m.f, kLn2d, precise_ln_d(s, tab));
+    const float t = m.mx + l;
     return (float)((double)t - ln2n);
 }
 // neighbours in the reference's order of summation: up, down, left, right (harmonic_cpu.cpp:65-68); u* = their values
 __device__ __forceinline__ float tol_update_2d(float uu, float ud, float ul, float ur, float qu, uint32_t nu, float qd,
                                                uint32_t nd, float ql, uint32_t nl, float qr, uint32_t nr, const MathTab &tab)
 {
-    const uint32_t nmax = umax2(umax2(umax2(nu, nd), nl), nr);
-    const float mx = max2(max2(max2(uu, ud), ul), ur);
-    float s = tol_term(qu, nu, nmax) + tol_term(qd, nd, nmax);
-    s = s + tol_term(ql, nl, nmax);
-    s = s + tol_term(qr, nr, nmax);
-    return tol_finish(s, nmax, mx, kLn4, tab);
+    const TolMax m = tol_max(max2(max2(max2(uu, ud), ul), ur));
+    float s = tol_term(qu, nu, m.nmax) + tol_term(qd, nd, m.nmax);
+    s = s + tol_term(ql, nl, m.nmax);
+    s = s + tol_term(qr, nr, m.nmax);
+    return tol_finish(s, m, kLn4, tab);
 }
 // x0-1, x0+1, x1-1, x1+1, x2-1, x2+1 (harmonic_cpu.cpp:118-123)
 __device__ __forceinline__ float tol_update_3d(float u0, float u1, float u2, float u3, float u4, float u5, float q0, uint32_t n0,
                                                float q1, uint32_t n1, float q2, uint32_t n2, float q3, uint32_t n3, float q4,
                                                uint32_t n4, float q5, uint32_t n5, const MathTab &tab)
 {
-    const uint32_t nmax = umax2(umax2(umax2(umax2(umax2(n0, n1), n2), n3), n4), n5);
-    const float mx = max2(max2(max2(max2(max2(u0, u1), u2), u3), u4), u5);
-    float s = tol_term(q0, n0, nmax) + tol_term(q1, n1, nmax);
-    s = s + tol_term(q2, n2, nmax);
-    s = s + tol_term(q3, n3, nmax);
-    s = s + tol_term(q4, n4, nmax);
-    s = s + tol_term(q5, n5, nmax);
-    return tol_finish(s, nmax, mx, kLn6, tab);
+    const TolMax m = tol_max(max2(max2(max2(max2(max2(u0, u1), u2), u3), u4), u5));
+    float s = tol_term(q0, n0, m.nmax) + tol_term(q1, n1, m.nmax);
+    s = s + tol_term(q2, n2, m.nmax);
+    s = s + tol_term(q3, n3, m.nmax);
+    s = s + tol_term(q4, n4, m.nmax);
+    s = s + tol_term(q5, n5, m.nmax);
+    return tol_finish(s, m, kLn6, tab);
 }
 
 // ---- selects on lane masks held in SGPR pairs ----------------------------------------------------------------------

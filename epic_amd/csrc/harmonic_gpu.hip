@@ -195,6 +195,7 @@ int auto_rows_per_task(const Ctx *c)
     // Small grids (the ROS maps are 0.1-1 Mcell) cannot fill the chip at all: there one row per wave is best
     // (310 x 940: 4.3 us per sweep at 1 row per task vs 11.4 us at 8, both measured).
     long long r = (long long)c->rows * nstrips / 32768;
+    if (c->math == 4 && r >= 8) return (int)std::min<long long>(60, std::max<long long>(10, (r + 2) / 10 * 10));  // tol: the row loop runs in trips of 10 (kernels_2d.hip)
     if (r >= 8) r = r / 8 * 8;
     else if (r >= 4) r = 4;
     else if (r >= 2) r = 2;

@@ -90,8 +90,14 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nblk)
 #else
 #define EPIC_SWEEP_OCC
 #endif
+// (the untracked tol kernels are asked for 6 waves per SIMD -- 80 VGPRs --, which they reach without spilling; left
+// alone the five-row ring takes 83.  The tracked and the red-black check variants would spill: they keep what they get.
+// No sweep kernel may use scratch: tools/isa_hazards.py checks it.)
+template <bool CHECK, int MATH, bool RB, bool TRACK> struct SweepOcc {
+    static constexpr int kMinWaves = (MATH == kMathTol && !TRACK && !(RB && CHECK)) ? 6 : 1;
+};
 template <bool CHECK, int MATH, bool RB, bool TRACK>
-__global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d_kernel(Sweep2dArgs a)
+__global__ __launch_bounds__(kWave * kWavesPerBlock, (SweepOcc<CHECK, MATH, RB, TRACK>::kMinWaves)) EPIC_SWEEP_OCC void sweep2d_kernel(Sweep2dArgs a)
 {
     __shared__ __attribute__((aligned(16))) float ldsf[kDfLdsFloats];  // df32 tables (df32 math only)
     if (MATH == kMathDf32) {
@@ -261,6 +267,44 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
     // costs four v_readfirstlane per row for the exit values alone); the ragged rest -- and the one-row tasks of the
     // small grids -- go through a plain loop.
     auto row_at = [&](int i) { return rfirst + dir * i; };  // i-th row of the march
+    auto split = [&](const float4 &q) { return TOL ? tol_split4(q) : Split4{}; };
+    if constexpr (TOL) {
+        // The tol arithmetic leaves the kernel close to the memory roofline, where what counts is the number of bytes in
+        // flight: rows are loaded TWO steps ahead (two 1 KiB loads per wave outstanding instead of one; one step ahead
+        // the chip ran at 4.9 TB/s with 6 waves per SIMD, 110 us per 8192^2 sweep).  Five rows rotate through five register
+        // sets -- the arrays below are indexed by constants once the inner loop is unrolled, so nothing is moved --, the
+        // splits ride the same ring (a row is split when it enters the window as the row below), the row sides alternate
+        // between two sets of SGPRs as before; 10 = lcm(5, 2) steps per trip.
+        constexpr int kRing = 5, kTrip = 10;
+        float4 q[kRing];
+        Split4 s[kRing];
+        RowSide h[2];
+        q[0] = ld(row_at(-1)); q[1] = ld(row_at(0)); q[2] = ld(row_at(1)); q[3] = ld(row_at(2));
+        h[0] = side(row_at(0));
+        if (tables_pending) {  // wave-uniform, once per wave
+            math_tables_commit(tab_regs, math_lds);
+            tables_pending = false;
+        }
+        const int ntrip = nrows / kTrip * kTrip;
+        if (ntrip > 0) {
+            s[0] = split(q[0]); s[1] = split(q[1]);
+            for (int i = 0; i < ntrip; i += kTrip) {
+#pragma unroll
+                for (int j = 0; j < kTrip; ++j) {
+                    q[(j + 4) % kRing] = ld(row_at(i + j + 3));
+                    h[(j + 1) & 1] = side(row_at(i + j + 1));
+                    s[(j + 2) % kRing] = split(q[(j + 2) % kRing]);
+                    row_step(row_at(i + j), q[j % kRing], q[(j + 1) % kRing], q[(j + 2) % kRing], h[j & 1], s[j % kRing],
+                             s[(j + 1) % kRing], s[(j + 2) % kRing]);
+                }
+            }
+        }
+        for (int i = ntrip; i < nrows; ++i) {  // ragged rest, and the short tasks of the small grids
+            const int r = row_at(i);
+            const float4 ru = ld(r - dir), rc = ld(r), rd = ld(r + dir);
+            row_step(r, ru, rc, rd, side(r), split(ru), split(rc), split(rd));
+        }
+    } else {
     const int nfull = nrows & ~3;
     float4 q0 = ld(row_at(-1)), q1 = ld(row_at(0)), q2 = ld(row_at(1)), q3;
     RowSide sa = side(row_at(0)), sb;  // row sides run one row ahead, alternating between two sets of SGPRs
@@ -268,35 +312,25 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP_OCC void sweep2d
         math_tables_commit(tab_regs, math_lds);
         tables_pending = false;
     }
-    // tol math: the splits ride the same ring as the rows; a row is split when it enters the window as the row below
-    Split4 s0 = {}, s1 = {}, s2 = {}, s3 = {};
-    auto split = [&](const float4 &q) { return TOL ? tol_split4(q) : Split4{}; };
-    if (TOL) { s0 = split(q0); s1 = split(q1); }
+    const Split4 none = {};
     if (nfull > 0) {
         for (int i = 0; i < nfull; i += 4) {
             q3 = ld(row_at(i + 2)); sb = side(row_at(i + 1));
-            s2 = split(q2);
-            row_step(row_at(i), q0, q1, q2, sa, s0, s1, s2);
+            row_step(row_at(i), q0, q1, q2, sa, none, none, none);
             q0 = ld(row_at(i + 3)); sa = side(row_at(i + 2));
-            s3 = split(q3);
-            row_step(row_at(i + 1), q1, q2, q3, sb, s1, s2, s3);
+            row_step(row_at(i + 1), q1, q2, q3, sb, none, none, none);
             q1 = ld(row_at(i + 4)); sb = side(row_at(i + 3));
-            s0 = split(q0);
-            row_step(row_at(i + 2), q2, q3, q0, sa, s2, s3, s0);
+            row_step(row_at(i + 2), q2, q3, q0, sa, none, none, none);
             q2 = ld(row_at(i + 5)); sa = side(row_at(i + 4));
-            s1 = split(q1);
-            row_step(row_at(i + 3), q3, q0, q1, sb, s3, s0, s1);
+            row_step(row_at(i + 3), q3, q0, q1, sb, none, none, none);
         }
     }
-    if (nfull == 0 && nrows > 0) {  // the one-row tasks of the small grids land here
-        s2 = split(q2);
-        row_step(row_at(0), q0, q1, q2, sa, s0, s1, s2);
-    }
+    if (nfull == 0 && nrows > 0) row_step(row_at(0), q0, q1, q2, sa, none, none, none);  // the one-row tasks of the small grids land here
     for (int i = nfull == 0 ? 1 : nfull; i < nrows; ++i) {
         const int r = row_at(i);
-        const float4 ru = ld(r - dir), rc = ld(r), rd = ld(r + dir);
-        row_step(r, ru, rc, rd, side(r), split(ru), split(rc), split(rd));
+        row_step(r, ld(r - dir), ld(r), ld(r + dir), side(r), none, none, none);
     }
+    }  // !TOL
 
     if (TRACK) {
         // wake the tiles that read what this task changed: itself, and the neighbour across each edge that changed

@@ -44,12 +44,18 @@ struct Sweep3dArgs {
 // even are recomputed (harmonic_cpu.cpp:89-102), all six neighbours have the other colour.
 // At least 5 waves per SIMD: left alone, the list-driven precise variant takes 146 VGPRs (3 waves per SIMD); held to
 // 5 waves it relaxes the 512^3 benchmark in 1.285 s instead of 1.33 (7 waves: 1.31; no spills either way).
+// (With the selects and lane shifts going through compiler builtins the list-driven variants need a few registers more:
+// held to 5 waves the tracked precise Jacobi kernel spilled 228 registers, so the tracked variants are held to 4 and
+// that one -- whose allocation the compiler blows up to 146 registers whatever it is told -- to 3.
+// No sweep kernel may use scratch: tools/isa_hazards.py checks the generated ISA.)
 #ifndef EPIC_SWEEP3D_WAVES
 #define EPIC_SWEEP3D_WAVES 5
 #endif
-#define EPIC_SWEEP3D_OCC __attribute__((amdgpu_waves_per_eu(EPIC_SWEEP3D_WAVES)))
+template <bool CHECK, bool RB, bool TRACK> struct Sweep3dOcc {
+    static constexpr int kMinWaves = !TRACK ? EPIC_SWEEP3D_WAVES : (!CHECK && !RB) ? EPIC_SWEEP3D_WAVES - 2 : EPIC_SWEEP3D_WAVES - 1;
+};
 template <bool CHECK, int MATH, bool RB, bool TRACK>
-__global__ __launch_bounds__(kWave * kWavesPerBlock) EPIC_SWEEP3D_OCC void sweep3d_kernel(Sweep3dArgs a)
+__global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, RB, TRACK>::kMinWaves)) void sweep3d_kernel(Sweep3dArgs a)
 {
     __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];  // glibc's expf / logf tables (precise math only)
     MathTab lds = {};  // libm tables in LDS (precise math only)

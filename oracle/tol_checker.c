@@ -87,7 +87,6 @@ static inline double tol_ln(float sf)
     const uint32_t tmp = tol_f2u(sf) - 0x3f330000u;
     return tol_ln_core((double)sf, (tmp >> 19) & 15, (int)(tmp >> 23) & 3);
 }
-static inline uint32_t tol_umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 static inline float tol_fmax(float a, float b) { return a < b ? b : a; }
 static inline float tol_term(float q, uint32_t zb, uint32_t nmax)
 {
@@ -95,37 +94,46 @@ static inline float tol_term(float q, uint32_t zb, uint32_t nmax)
     if (e < -300) e = -300;   /* ldexpf(q, anything below -174) is 0 either way; keeps the int argument in range */
     return ldexpf(q, e);
 }
-/* The reference's last steps on s_ref = S / q_mx, whose logarithm is ln S - (mx - N ln2) (cell_update.h: tol_finish):
- * l rounded to f32 where the reference rounds logf(s), t = mx + l in f32, then the f64 subtraction of ln(2n). */
-static inline float tol_finish(float s, uint32_t nmax, float mx, double ln2n)
+/* N and f = mx log2 e - N from the maximum of the neighbours (cell_update.h: tol_max): the same fma as in tol_split, so
+ * the bit pattern IS the largest of the neighbours' patterns. */
+typedef struct { float mx, f; uint32_t nmax; } TolMax;
+static inline TolMax tol_max(float mx)
 {
-    const double nd = (double)(int)(nmax - TOL_MAGIC_BITS);
-    const float l = (float)(tol_ln(s) + fma(nd, 0x1.62e42fefa39efp-1, -(double)mx));
-    const float t = mx + l;
+    const float zm = fmaf(mx, TOL_LH, TOL_MAGIC);
+    const float nf = zm - TOL_MAGIC;
+    float f = fmaf(mx, TOL_LH, -nf);
+    f = fmaf(mx, TOL_LL, f);
+    const TolMax m = {mx, f, tol_f2u(zm)};
+    return m;
+}
+/* The reference's last steps on s_ref = S / q_mx = S 2^-f (cell_update.h: tol_finish): l rounded to f32 where the reference
+ * rounds logf(s), t = mx + l in f32, then the f64 subtraction of ln(2n). */
+static inline float tol_finish(float s, TolMax m, double ln2n)
+{
+    const float l = (float)fma(-(double)m.f, 0x1.62e42fefa39efp-1, tol_ln(s));
+    const float t = m.mx + l;
     return (float)((double)t - ln2n);
 }
 
 static float tol_cell_2d(const float *u, const float *q, const uint32_t *zb, size_t c, size_t m1)
 {
     const size_t a = c - m1, b = c + m1, l = c - 1, r = c + 1;   /* up, down, left, right: harmonic_cpu.cpp:65-68 */
-    const uint32_t nmax = tol_umax(tol_umax(tol_umax(zb[a], zb[b]), zb[l]), zb[r]);
-    float s = tol_term(q[a], zb[a], nmax) + tol_term(q[b], zb[b], nmax);
-    s = s + tol_term(q[l], zb[l], nmax);
-    s = s + tol_term(q[r], zb[r], nmax);
-    const float mx = tol_fmax(tol_fmax(tol_fmax(u[a], u[b]), u[l]), u[r]);
-    return tol_finish(s, nmax, mx, 0x1.62e42fefa39efp+0);
+    const TolMax m = tol_max(tol_fmax(tol_fmax(tol_fmax(u[a], u[b]), u[l]), u[r]));
+    float s = tol_term(q[a], zb[a], m.nmax) + tol_term(q[b], zb[b], m.nmax);
+    s = s + tol_term(q[l], zb[l], m.nmax);
+    s = s + tol_term(q[r], zb[r], m.nmax);
+    return tol_finish(s, m, 0x1.62e42fefa39efp+0);
 }
 
 static float tol_cell_3d(const float *u, const float *q, const uint32_t *zb, size_t c, size_t s0, size_t s1)
 {
     const size_t nb[6] = {c - s0, c + s0, c - s1, c + s1, c - 1, c + 1};   /* harmonic_cpu.cpp:118-123 */
-    uint32_t nmax = zb[nb[0]];
-    for (int i = 1; i < 6; i++) nmax = tol_umax(nmax, zb[nb[i]]);
-    float s = tol_term(q[nb[0]], zb[nb[0]], nmax) + tol_term(q[nb[1]], zb[nb[1]], nmax);
-    for (int i = 2; i < 6; i++) s = s + tol_term(q[nb[i]], zb[nb[i]], nmax);
     float mx = u[nb[0]];
     for (int i = 1; i < 6; i++) mx = tol_fmax(mx, u[nb[i]]);
-    return tol_finish(s, nmax, mx, 0x1.cab0bfa2a2002p+0 /* log(6.0) */);
+    const TolMax m = tol_max(mx);
+    float s = tol_term(q[nb[0]], zb[nb[0]], m.nmax) + tol_term(q[nb[1]], zb[nb[1]], m.nmax);
+    for (int i = 2; i < 6; i++) s = s + tol_term(q[nb[i]], zb[nb[i]], m.nmax);
+    return tol_finish(s, m, 0x1.cab0bfa2a2002p+0 /* log(6.0) */);
 }
 
 static size_t tol_cells(const TolHarmonic *h)
