@@ -51,15 +51,18 @@ struct Sweep3dArgs {
 #ifndef EPIC_SWEEP3D_WAVES
 #define EPIC_SWEEP3D_WAVES 5
 #endif
-template <bool CHECK, bool RB, bool TRACK> struct Sweep3dOcc {
-    static constexpr int kMinWaves = !TRACK ? EPIC_SWEEP3D_WAVES : (!CHECK && !RB) ? EPIC_SWEEP3D_WAVES - 2 : EPIC_SWEEP3D_WAVES - 1;
+template <bool CHECK, int MATH, bool RB, bool TRACK> struct Sweep3dOcc {
+    static constexpr int kMinWaves = MATH == kMathTol ? (TRACK ? EPIC_SWEEP3D_WAVES - 2 : EPIC_SWEEP3D_WAVES - 1)  // tol: 8 more registers per row in the window
+                                     : !TRACK ? EPIC_SWEEP3D_WAVES
+                                     : (!CHECK && !RB) ? EPIC_SWEEP3D_WAVES - 2 : EPIC_SWEEP3D_WAVES - 1;
 };
 template <bool CHECK, int MATH, bool RB, bool TRACK>
-__global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, RB, TRACK>::kMinWaves)) void sweep3d_kernel(Sweep3dArgs a)
+__global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB, TRACK>::kMinWaves)) void sweep3d_kernel(Sweep3dArgs a)
 {
     __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];  // glibc's expf / logf tables (precise math only)
-    MathTab lds = {};  // libm tables in LDS (precise math only)
-    if (MATH == kMathPrecise) lds = math_tables_load(math_lds);
+    constexpr bool TOL = MATH == kMathTol;  // one split per cell, shared by the six cells it is a neighbour of (cell_update.h)
+    MathTab lds = {};  // libm tables in LDS (precise and tol math)
+    if (MATH == kMathPrecise || TOL) lds = math_tables_load(math_lds);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (TRACK) wake_reset_next(a.wake);
@@ -126,12 +129,33 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, RB, TRAC
     lmask chg_any = 0, chg_x = 0, chg_w = 0, chg_top = 0, chg_bot = 0;  // lane masks, as in the 2-D kernel
 
     // One row: up / c / dn = rows x1 - 1, x1, x1 + 1 of the plane, pa / pb = row x1 of the planes x0 - 1 and x0 + 1.
+    // (tol math: su / sc / sd are the splits of the plane's three rows, made once per row as it enters the window; the
+    // rows of the two neighbouring planes are split where they are used)
     auto row_step = [&](int r, const float4 &up, const float4 &c, const float4 &dn, const float4 &pa, const float4 &pb,
-                        const RowSide &h) {
+                        const RowSide &h, const Split4 &su, const Split4 &sc, const Split4 &sd) {
         const float lf = wave_from_left(c.w, h.l);
         const float rt = wave_from_right(c.x, h.r);
         float4 o;
-        if (RB) {
+        if (TOL) {
+            const Split4 sa = tol_split4(pa), sb = tol_split4(pb);
+            const Split2 hs = tol_split2(v2f{h.l, h.r});  // the two strip-edge cells of the row
+            const float ql = wave_from_left(sc.qw, hs.q.x), qr = wave_from_right(sc.qx, hs.q.y);
+            const uint32_t nl = f2u(wave_from_left(u2f(sc.nw), hs.zm.x)), nr = f2u(wave_from_right(u2f(sc.nx), hs.zm.y));
+            o = c;
+            const bool even_cols = !RB || ((x0 + r + a.parity) & 1) == 0, odd_cols = !RB || !even_cols;  // scalar
+            if (even_cols) {
+                o.x = sel(h.m0, c.x, tol_update_3d(pa.x, pb.x, up.x, dn.x, lf, c.y, sa.qx, sa.nx, sb.qx, sb.nx, su.qx, su.nx,
+                                                   sd.qx, sd.nx, ql, nl, sc.qy, sc.ny, lds));
+                o.z = sel(h.m2, c.z, tol_update_3d(pa.z, pb.z, up.z, dn.z, c.y, c.w, sa.qz, sa.nz, sb.qz, sb.nz, su.qz, su.nz,
+                                                   sd.qz, sd.nz, sc.qy, sc.ny, sc.qw, sc.nw, lds));
+            }
+            if (odd_cols) {
+                o.y = sel(h.m1, c.y, tol_update_3d(pa.y, pb.y, up.y, dn.y, c.x, c.z, sa.qy, sa.ny, sb.qy, sb.ny, su.qy, su.ny,
+                                                   sd.qy, sd.ny, sc.qx, sc.nx, sc.qz, sc.nz, lds));
+                o.w = sel(h.m3, c.w, tol_update_3d(pa.w, pb.w, up.w, dn.w, c.z, rt, sa.qw, sa.nw, sb.qw, sb.nw, su.qw, su.nw,
+                                                   sd.qw, sd.nw, sc.qz, sc.nz, qr, nr, lds));
+            }
+        } else if (RB) {
             o = c;
             if (((x0 + r + a.parity) & 1) == 0) {  // scalar: even x2 columns (.x, .z) are this row's active cells
                 const float nx = cell_update_3d<MATH>(pa.x, pb.x, up.x, dn.x, lf, c.y, lds);
@@ -171,24 +195,32 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, RB, TRAC
     // Register rings rotated by hand (no moves between a load and its use): the plane's own rows run two rows ahead
     // over four registers, the rows of the neighbouring planes and the scalar row sides one row ahead over two.
     const int nrows = r1 - r0, nfull = nrows & ~3;
+    auto split = [&](const float4 &q) { return TOL ? tol_split4(q) : Split4{}; };
     if (nfull > 0) {
         float4 q0 = ld(rc, r0 - 1), q1 = ld(rc, r0), q2 = ld(rc, r0 + 1), q3;
         float4 aa = ld(ra, r0), ba = ld(rb, r0), ab, bb;
         RowSide sa = side(r0), sb;
+        Split4 s0 = split(q0), s1 = split(q1), s2 = {}, s3 = {};
         for (int i = 0; i < nfull; i += 4) {
             const int r = r0 + i;
             q3 = ld(rc, r + 2); ab = ld(ra, r + 1); bb = ld(rb, r + 1); sb = side(r + 1);
-            row_step(r, q0, q1, q2, aa, ba, sa);
+            s2 = split(q2);
+            row_step(r, q0, q1, q2, aa, ba, sa, s0, s1, s2);
             q0 = ld(rc, r + 3); aa = ld(ra, r + 2); ba = ld(rb, r + 2); sa = side(r + 2);
-            row_step(r + 1, q1, q2, q3, ab, bb, sb);
+            s3 = split(q3);
+            row_step(r + 1, q1, q2, q3, ab, bb, sb, s1, s2, s3);
             q1 = ld(rc, r + 4); ab = ld(ra, r + 3); bb = ld(rb, r + 3); sb = side(r + 3);
-            row_step(r + 2, q2, q3, q0, aa, ba, sa);
+            s0 = split(q0);
+            row_step(r + 2, q2, q3, q0, aa, ba, sa, s2, s3, s0);
             q2 = ld(rc, r + 5); aa = ld(ra, r + 4); ba = ld(rb, r + 4); sa = side(r + 4);
-            row_step(r + 3, q3, q0, q1, ab, bb, sb);
+            s1 = split(q1);
+            row_step(r + 3, q3, q0, q1, ab, bb, sb, s3, s0, s1);
         }
     }
-    for (int r = r0 + nfull; r < r1; ++r)  // ragged tail
-        row_step(r, ld(rc, r - 1), ld(rc, r), ld(rc, r + 1), ld(ra, r), ld(rb, r), side(r));
+    for (int r = r0 + nfull; r < r1; ++r) {  // ragged tail
+        const float4 ru = ld(rc, r - 1), rm = ld(rc, r), rd = ld(rc, r + 1);
+        row_step(r, ru, rm, rd, ld(ra, r), ld(rb, r), side(r), split(ru), split(rm), split(rd));
+    }
 
     if (TRACK) {
         // wake the tiles that read what this task changed: itself, the in-plane neighbours across the edges that
@@ -250,6 +282,7 @@ template <bool CHECK, bool RB, bool TRACK>
 void launch_sweep_3d_track(int math, dim3 grid, dim3 block, hipStream_t stream, const Sweep3dArgs &a)
 {
     if (math == kMathFast) hipLaunchKernelGGL((sweep3d_kernel<CHECK, kMathFast, RB, TRACK>), grid, block, 0, stream, a);
+    else if (math == kMathTol) hipLaunchKernelGGL((sweep3d_kernel<CHECK, kMathTol, RB, TRACK>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((sweep3d_kernel<CHECK, kMathPrecise, RB, TRACK>), grid, block, 0, stream, a);
 }
 template <bool CHECK, bool RB>
@@ -269,6 +302,7 @@ hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, i
     if (pitch <= 0 || (pitch % 256) != 0 || m0 <= 0 || m1 <= 0 || plane_begin < 0 || plane_end > m0)
         return hipErrorInvalidValue;
     if ((parity >= 0) != (in == out)) return hipErrorInvalidValue;
+    if (math != kMathPrecise && math != kMathFast && math != kMathTol) return hipErrorInvalidValue;  // no df32 / traffic build in 3-D
     if ((long long)pitch * 4 * (kRowsPerTask + 12) > 0x7fffffffLL) return hipErrorInvalidValue;  // 32-bit row offsets
     Sweep3dArgs a;
     a.in = in;

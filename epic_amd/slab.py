@@ -74,7 +74,10 @@ class HipBackend:
         if self.E.epic_hip_device_count() < 1:
             raise RuntimeError("epic_amd.slab: no HIP device -- the slab solver has no CPU path")
         self.rows_per_task = int(rows_per_task) or 16
-        self.math = 1 if math == "fast" else 0
+        modes = {"precise": 0, "fast": 1, "traffic": 2, "df32": 3, "tol": 4}
+        if math not in modes:
+            raise ValueError("epic_amd.slab: unknown math mode %r (one of %s)" % (math, ", ".join(sorted(modes))))
+        self.math = modes[math]
 
     def pitch_for(self, cols):
         return int(self.E.epic_hip_pitch_for_cols(cols))
