@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <vector>
 #include <mutex>
@@ -67,6 +68,28 @@ struct Ctx {
     static size_t wake_words(size_t tiles) { return 3 * kL * kCS + 2 * tiles + 2 * kL * epic_hip::sweep_2d_list_cap(tiles); }
     static size_t wake_zeroed_words(size_t tiles) { return 3 * kL * kCS + 2 * tiles; }  // counters and marks; lists need no init
     bool redblack = false;         // 2-D scheme: false = Jacobi ping-pong (default), true = in-place red-black (EPIC_HIP_SCHEME)
+    // Multi-device mode (EPIC_HIP_DEVICES=0,1,... ; 2-D grids): the rows are cut into one slab per listed device, every
+    // interior side carries `halo` ghost rows that are swept like owned rows and traded every `halo` iterations (see the
+    // "several devices in one process" section below).  buf / maskw / d_delta / stream above then stay unused.
+    struct Slab {
+        int dev = 0;                 // HIP device ordinal (the list may name a device more than once)
+        int lo = 0, hi = 0;          // owned global rows [lo, hi)
+        int g_top = 0, g_bot = 0;    // ghost rows above / below
+        int rows = 0;                // local rows, ghosts included
+        float *buf[2] = {nullptr, nullptr};
+        uint32_t *maskw = nullptr;
+        unsigned *d_delta = nullptr;
+        float *h_delta = nullptr;    // pinned
+        hipStream_t stream = nullptr, comm = nullptr;   // interior sweeps / boundary bands + halo copies
+        hipEvent_t ev_prev = nullptr, ev_band = nullptr, ev_comm = nullptr;
+        int first() const { return g_top; }              // first owned local row
+        int last() const { return rows - 1 - g_bot; }    // last owned local row
+        int top() const { return lo - g_top; }           // global row of local row 0
+    };
+    std::vector<Slab> slabs;
+    std::vector<int> devices;      // EPIC_HIP_DEVICES as given (validated); fewer than 2 entries: single-device mode
+    int halo = 8, since = 0;       // ghost rows per interior side (EPIC_HIP_HALO); iterations since the last exchange
+    bool multi() const { return !slabs.empty(); }
     size_t u_bytes() const { return (size_t)rows * pitch * sizeof(float); }
     size_t mask_bytes() const
     {
@@ -79,6 +102,10 @@ std::unordered_map<Harmonic *, Ctx *> g_ctx;
 
 void resolve_tracking(Ctx *c);
 void drop_graphs(Ctx *c);  // captured launch sequences hold the buffer addresses: drop them whenever a buffer goes away
+bool multi_plan(Ctx *c);   // multi-device mode (EPIC_HIP_DEVICES): see "several devices in one process" below
+void multi_destroy(Ctx *c);
+bool multi_holds_anything(const Ctx *c);
+bool multi_ready(const Ctx *c);
 
 void report(const char *fn, const char *msg) { fprintf(stderr, "Error[%s]: %s\n", fn, msg); }
 
@@ -105,6 +132,16 @@ bool dims_from(const Harmonic *h, Ctx *c)
     return true;
 }
 
+// dims_from() on the context that owns device state: also (re)decides single- or multi-device mode.  Changing dimensions
+// while one kind of state is still resident is refused by the callers (same_dims), so the layout never changes under
+// live buffers.
+bool dims_into_ctx(const Harmonic *h, Ctx *c)
+{
+    if (!dims_from(h, c)) return false;
+    if (!c->devices.empty()) multi_plan(c);
+    return true;
+}
+
 bool same_dims(const Harmonic *h, const Ctx *c)
 {
     if ((int)h->n != c->n) return false;
@@ -123,8 +160,9 @@ Ctx *get_ctx(Harmonic *h, bool create)
         // A Harmonic whose fields are all null but which we still track was freed and re-created by the
         // caller without uninitialize: drop the stale device state.
         if (h->d_m == nullptr && h->d_u == nullptr && h->d_locked == nullptr && h->d_delta == nullptr &&
-            (c->buf[0] || c->maskw || c->d_m || c->d_delta)) {
+            (c->buf[0] || c->maskw || c->d_m || c->d_delta || multi_holds_anything(c))) {
             drop_graphs(c);
+            if (c->multi()) multi_destroy(c);
             for (float *&b : c->buf) { if (b) (void)hipFree(b); b = nullptr; }
             if (c->maskw) (void)hipFree(c->maskw);
             if (c->d_m) (void)hipFree(c->d_m);
@@ -156,6 +194,25 @@ Ctx *get_ctx(Harmonic *h, bool create)
     if (e && strcmp(e, "redblack") == 0) c->redblack = true;
     e = getenv("EPIC_HIP_TRACK");
     if (e && (strcmp(e, "0") == 0 || strcmp(e, "1") == 0)) c->track_mode = atoi(e);
+    e = getenv("EPIC_HIP_HALO");
+    if (e && atoi(e) >= 1) c->halo = atoi(e);
+    e = getenv("EPIC_HIP_DEVICES");
+    if (e && *e) {  // "0,1,2,3"; a device may be named more than once ("0,0,0,0": four slabs on one GPU)
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); ndev = 0; }
+        std::vector<int> devs;
+        bool ok = true;
+        for (const char *p = e; *p;) {
+            char *end = nullptr;
+            const long d = strtol(p, &end, 10);
+            if (end == p || d < 0 || d >= ndev) { ok = false; break; }
+            devs.push_back((int)d);
+            p = (*end == ',') ? end + 1 : end;
+            if (*end && *end != ',') { ok = false; break; }
+        }
+        if (ok && devs.size() <= 64) c->devices = devs;
+        else fprintf(stderr, "Warning[epic_hip]: EPIC_HIP_DEVICES=%s ignored (%d device(s) visible)\n", e, ndev);
+    }
     g_ctx[h] = c;
     return c;
 }
@@ -166,8 +223,9 @@ void drop_ctx_if_empty(Harmonic *h)
     auto it = g_ctx.find(h);
     if (it == g_ctx.end()) return;
     Ctx *c = it->second;
-    if (c->buf[0] || c->maskw || c->d_m || c->d_delta) return;
+    if (c->buf[0] || c->maskw || c->d_m || c->d_delta || multi_holds_anything(c)) return;
     drop_graphs(c);
+    if (c->multi()) multi_destroy(c);
     if (c->wake) (void)hipFree(c->wake);
     c->wake = nullptr;
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
@@ -180,7 +238,7 @@ void drop_ctx_if_empty(Harmonic *h)
 // are launch-bound either way (3.2-4 us per sweep without, 5-6.7 us with lists, measured), so "automatic" leaves them alone.
 void resolve_tracking(Ctx *c)
 {
-    c->track = c->track_mode == 1 || (c->track_mode == 2 && (long long)c->rows * c->pitch > (1ll << 22));
+    c->track = !c->multi() && (c->track_mode == 1 || (c->track_mode == 2 && (long long)c->rows * c->pitch > (1ll << 22)));
 }
 
 int auto_rows_per_task(const Ctx *c)
@@ -205,13 +263,20 @@ int auto_rows_per_task(const Ctx *c)
 
 bool ready(const Harmonic *h, const Ctx *c)
 {
+    if (c && c->multi()) return multi_ready(c) && h->d_u && h->d_locked;
     return c && c->buf[0] && c->buf[1] && c->maskw && h->d_u && h->d_locked;
 }
 
+float *current_u(const Ctx *c) { return c->multi() ? c->slabs[0].buf[c->cur] : c->buf[c->cur]; }
+bool has_delta(const Ctx *c) { return c->multi() ? c->slabs[0].d_delta != nullptr : c->d_delta != nullptr; }
+
 // One iteration, enqueued: a Jacobi sweep (buffers swap) or, in the red-black scheme (2-D), the reference's half-sweep
 // of the colour selected by `iteration` in place.  check != 0 also zeroes and fills the device delta word.
+hipError_t multi_sweep(Ctx *c, bool check, unsigned iteration);
+
 hipError_t enqueue_sweep(Ctx *c, bool check, unsigned iteration)
 {
+    if (c->multi()) return multi_sweep(c, check, iteration);
     hipError_t e;
     if (check) {
         e = hipMemsetAsync(c->d_delta, 0, sizeof(unsigned), c->stream);
@@ -304,7 +369,7 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
     static const bool no_fuse = getenv("EPIC_HIP_NO_FUSE") != nullptr;
     // (the fused pass has its own 248-column tiling and no work lists: it is used when tracking is off)
     // (and the precise / fast / df32 arithmetic only: the tol math runs the in-place half-sweeps)
-    const bool fuse = c->redblack && c->n == 2 && !no_fuse && !c->track && c->math != 4 && (long long)c->rows * c->pitch >= (1ll << 22);
+    const bool fuse = c->redblack && c->n == 2 && !no_fuse && !c->track && !c->multi() && c->math != 4 && (long long)c->rows * c->pitch >= (1ll << 22);
     unsigned i = 0;
     while (fuse && count - i >= 2) {
         hipError_t e = epic_hip::launch_rb_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch,
@@ -325,7 +390,7 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
     const bool small = (long long)c->rows * c->pitch <= (1ll << 22);
     static const bool no_graph = getenv("EPIC_HIP_NO_GRAPH") != nullptr;
     // a captured sequence bakes in the work-list buffers and list mode: run eagerly until the forced iterations are over
-    if (!small || count < 8 || no_graph || (c->track && (c->force > 0 || c->act_tiles == 0)))
+    if (!small || count < 8 || no_graph || c->multi() || (c->track && (c->force > 0 || c->act_tiles == 0)))
         return enqueue_plain_run(c, count, first);
     const auto key = std::make_tuple(count, c->cur + 2 * (c->track ? 1 + c->phase : 0), (int)(first & 1u), c->math,
                                      (int)c->redblack, auto_rows_per_task(c));
@@ -353,8 +418,11 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
     return e;
 }
 
+int multi_read_delta(Harmonic *h, Ctx *c, const char *fn);
+
 int read_delta(Harmonic *h, Ctx *c, const char *fn)
 {
+    if (c->multi()) return multi_read_delta(h, c, fn);
     if (hipMemcpyAsync(c->h_delta, c->d_delta, sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
         report(fn, "Failed to copy memory from device to host for the max delta.");
         return EPIC_ERROR_MEMCPY_TO_HOST;
@@ -367,8 +435,12 @@ int read_delta(Harmonic *h, Ctx *c, const char *fn)
     return EPIC_SUCCESS;
 }
 
+int multi_upload_u(Harmonic *h, Ctx *c, const char *fn);
+int multi_upload_locked(Harmonic *h, Ctx *c, const char *fn);
+
 int upload_u(Harmonic *h, Ctx *c, const char *fn)
 {
+    if (c->multi()) return multi_upload_u(h, c, fn);
     c->force = 2;  // new values: no tile may be left out on the strength of the old work lists
     // padding columns hold the obstacle seed; both buffers, so that whichever is read first is complete
     if (c->pitch != c->cols) {
@@ -391,6 +463,7 @@ int upload_u(Harmonic *h, Ctx *c, const char *fn)
 
 int upload_locked(Harmonic *h, Ctx *c, const char *fn)
 {
+    if (c->multi()) return multi_upload_locked(h, c, fn);
     c->force = 2;
     const size_t cells = (size_t)c->rows * c->cols;
     uint32_t *tmp = nullptr;
@@ -413,6 +486,353 @@ int upload_locked(Harmonic *h, Ctx *c, const char *fn)
         }
     }
     (void)hipFree(tmp);
+    return rc;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// several devices in one process (EPIC_HIP_DEVICES): SURVEY.md section 8(e) -- the ABI is a plain in-process C call, so
+// the callers that only ever make that call (the ROS plugin: harmonic_complete_gpu, src/epic_nav_core_plugin.cpp:256)
+// get a whole node by setting one environment variable.  Not in the reference (it has no multi-GPU code).
+//
+// The rows of a 2-D grid are cut into one slab per listed device.  Every interior side of a slab carries G = `halo` ghost
+// rows that are swept like owned rows, with their true masks; the outermost ghost row has nothing beyond it to be computed
+// from, so with every iteration one more ghost row goes stale from the outside in, and after G iterations the neighbours
+// trade their G outermost owned rows (hipMemcpyPeerAsync over xGMI) -- the bytes of one row per iteration in G times
+// fewer, G times larger copies.  On the iteration that ends with an exchange the two boundary bands of a slab are swept
+// first, on a second stream, and copied out while the interior is swept on the compute stream.  Every owned cell sees
+// exactly the values a single-domain iteration would give it: results are bit-identical to the single-device path for
+// any number of slabs and any G (tests/test_gpu_multi_device.py runs the parity suite with EPIC_HIP_DEVICES=0,0,0,0).
+// Red-black: the colour of a local row is the colour of its GLOBAL row (parity shifted by the slab's first global row).
+// Activity tracking is off in this mode (the work lists are per grid, not per slab).
+// ---------------------------------------------------------------------------------------------------------
+struct DeviceGuard {  // the caller's current device is restored whatever happens in between
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; } }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+void multi_free_u(Ctx *c)
+{
+    for (auto &sl : c->slabs) {
+        (void)hipSetDevice(sl.dev);
+        if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+        if (sl.comm) (void)hipStreamSynchronize(sl.comm);
+        for (float *&b : sl.buf) { if (b) (void)hipFree(b); b = nullptr; }
+    }
+}
+void multi_free_mask(Ctx *c)
+{
+    for (auto &sl : c->slabs) {
+        (void)hipSetDevice(sl.dev);
+        if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+        if (sl.maskw) (void)hipFree(sl.maskw);
+        sl.maskw = nullptr;
+    }
+}
+void multi_free_delta(Ctx *c)
+{
+    for (auto &sl : c->slabs) {
+        (void)hipSetDevice(sl.dev);
+        if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+        if (sl.d_delta) (void)hipFree(sl.d_delta);
+        sl.d_delta = nullptr;
+    }
+}
+bool multi_holds_anything(const Ctx *c)
+{
+    for (const auto &sl : c->slabs)
+        if (sl.buf[0] || sl.maskw || sl.d_delta) return true;
+    return false;
+}
+void multi_destroy(Ctx *c)  // streams, events, pinned words; the slabs themselves
+{
+    DeviceGuard g;
+    multi_free_u(c); multi_free_mask(c); multi_free_delta(c);
+    for (auto &sl : c->slabs) {
+        (void)hipSetDevice(sl.dev);
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
+        if (sl.comm) (void)hipStreamDestroy(sl.comm);
+        for (hipEvent_t e : {sl.ev_prev, sl.ev_band, sl.ev_comm}) if (e) (void)hipEventDestroy(e);
+        if (sl.h_delta) (void)hipHostFree(sl.h_delta);
+    }
+    c->slabs.clear();
+}
+
+// Decide the mode for the dimensions now in *c and, in multi-device mode, lay the slabs out (no device memory yet).
+// Single-device mode when fewer than two devices are listed, the grid is not 2-D or it is too small to cut.
+bool multi_plan(Ctx *c)
+{
+    const int want = (int)c->devices.size();
+    const bool multi = want >= 2 && c->n == 2 && c->rows >= 4 * want;
+    if (!multi) {
+        if (!c->slabs.empty() && !multi_holds_anything(c)) multi_destroy(c);
+        return false;
+    }
+    if ((int)c->slabs.size() == want && c->slabs.back().hi == c->rows) return true;  // already laid out for these dimensions
+    if (!c->slabs.empty()) multi_destroy(c);
+    DeviceGuard g;
+    const int base = c->rows / want, rem = c->rows % want;
+    const int halo = std::max(1, std::min(c->halo, base / 2));
+    int lo = 0;
+    c->slabs.resize(want);
+    for (int k = 0; k < want; k++) {
+        Ctx::Slab &sl = c->slabs[k];
+        sl.dev = c->devices[k];
+        sl.lo = lo;
+        sl.hi = lo + base + (k < rem ? 1 : 0);
+        lo = sl.hi;
+        sl.g_top = k > 0 ? halo : 0;
+        sl.g_bot = k < want - 1 ? halo : 0;
+        sl.rows = (sl.hi - sl.lo) + sl.g_top + sl.g_bot;
+        bool ok = hipSetDevice(sl.dev) == hipSuccess &&
+                  hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&sl.comm, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&sl.ev_prev, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&sl.ev_band, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&sl.ev_comm, hipEventDisableTiming) == hipSuccess &&
+                  hipHostMalloc((void **)&sl.h_delta, 64, hipHostMallocDefault) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            multi_destroy(c);
+            return false;
+        }
+        for (int j = 0; j < k; j++)  // direct copies between the devices where the fabric allows them
+            if (c->slabs[j].dev != sl.dev) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, sl.dev, c->slabs[j].dev) == hipSuccess && can) {
+                    (void)hipDeviceEnablePeerAccess(c->slabs[j].dev, 0);
+                    (void)hipSetDevice(c->slabs[j].dev);
+                    (void)hipDeviceEnablePeerAccess(sl.dev, 0);
+                    (void)hipSetDevice(sl.dev);
+                }
+                (void)hipGetLastError();  // "already enabled" is fine
+            }
+    }
+    c->halo = halo;
+    c->since = 0;
+    c->track = false;
+    return true;
+}
+
+bool multi_ready(const Ctx *c)
+{
+    if (c->slabs.empty()) return false;
+    for (const auto &sl : c->slabs)
+        if (!sl.buf[0] || !sl.buf[1] || !sl.maskw) return false;
+    return true;
+}
+
+void multi_sync(Ctx *c)
+{
+    for (auto &sl : c->slabs) {
+        (void)hipSetDevice(sl.dev);
+        (void)hipStreamSynchronize(sl.comm);
+        (void)hipStreamSynchronize(sl.stream);
+    }
+}
+
+int multi_upload_u(Harmonic *h, Ctx *c, const char *fn)
+{
+    DeviceGuard g;
+    for (auto &sl : c->slabs) {
+        if (hipSetDevice(sl.dev) != hipSuccess) return EPIC_ERROR_DEVICE_MALLOC;
+        for (int b = 0; b < 2; b++)
+            if (epic_hip::launch_fill(sl.buf[b], (size_t)sl.rows * c->pitch, -1e6f, sl.stream) != hipSuccess) {
+                report(fn, "Failed to initialise device-side memory for the potential values.");
+                return EPIC_ERROR_KERNEL_EXECUTION;
+            }
+        if (hipStreamSynchronize(sl.stream) != hipSuccess) return EPIC_ERROR_DEVICE_SYNCHRONIZE;
+        if (hipMemcpy2D(sl.buf[0], (size_t)c->pitch * sizeof(float), h->u + (size_t)sl.top() * c->cols,
+                        (size_t)c->cols * sizeof(float), (size_t)c->cols * sizeof(float), (size_t)sl.rows,
+                        hipMemcpyHostToDevice) != hipSuccess) {
+            report(fn, "Failed to copy memory from host to device for the potential values.");
+            return EPIC_ERROR_MEMCPY_TO_DEVICE;
+        }
+    }
+    c->cur = 0;
+    c->since = 0;
+    h->d_u = c->slabs[0].buf[0];
+    return EPIC_SUCCESS;
+}
+
+int multi_upload_locked(Harmonic *h, Ctx *c, const char *fn)
+{
+    DeviceGuard g;
+    for (auto &sl : c->slabs) {
+        if (hipSetDevice(sl.dev) != hipSuccess) return EPIC_ERROR_DEVICE_MALLOC;
+        const size_t cells = (size_t)sl.rows * c->cols;
+        uint32_t *tmp = nullptr;
+        if (hipMalloc((void **)&tmp, cells * sizeof(uint32_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            report(fn, "Failed to allocate device-side staging memory for the locked cells.");
+            return EPIC_ERROR_DEVICE_MALLOC;
+        }
+        int rc = EPIC_SUCCESS;
+        if (hipMemcpy(tmp, h->locked + (size_t)sl.top() * c->cols, cells * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            report(fn, "Failed to copy memory from host to device for the locked cells.");
+            rc = EPIC_ERROR_MEMCPY_TO_DEVICE;
+        } else if (epic_hip::launch_pack_mask_2d(tmp, sl.rows, c->cols, c->pitch, sl.g_top > 0, sl.g_bot > 0, sl.maskw,
+                                                 sl.stream) != hipSuccess ||
+                   hipStreamSynchronize(sl.stream) != hipSuccess) {
+            report(fn, "Failed to execute the 'pack mask' kernel.");
+            rc = EPIC_ERROR_KERNEL_EXECUTION;
+        }
+        (void)hipFree(tmp);
+        if (rc != EPIC_SUCCESS) return rc;
+    }
+    c->since = 0;  // the ghost rows were just uploaded with everything else: exact
+    return EPIC_SUCCESS;
+}
+
+// Copy `nrows` rows between two slabs' buffers on `stream` (a stream of the destination's device).
+hipError_t multi_copy_rows(const Ctx *c, const Ctx::Slab &dst, float *dbuf, int drow, const Ctx::Slab &src, const float *sbuf,
+                           int srow, int nrows, hipStream_t stream)
+{
+    const size_t bytes = (size_t)nrows * c->pitch * sizeof(float);
+    float *d = dbuf + (size_t)drow * c->pitch;
+    const float *sp = sbuf + (size_t)srow * c->pitch;
+    if (dst.dev == src.dev) return hipMemcpyAsync(d, sp, bytes, hipMemcpyDeviceToDevice, stream);
+    return hipMemcpyPeerAsync(d, dst.dev, sp, src.dev, bytes, stream);
+}
+
+// One iteration of the whole grid, enqueued on every slab's streams.
+hipError_t multi_sweep(Ctx *c, bool check, unsigned iteration)
+{
+    DeviceGuard g;
+    const int rpt = auto_rows_per_task(c);
+    const bool exchange = c->since + 1 >= c->halo;
+    const int G = c->halo;
+    hipError_t e = hipSuccess;
+    auto fail = [&](hipError_t x) { if (e == hipSuccess && x != hipSuccess) e = x; return x != hipSuccess; };
+    for (auto &sl : c->slabs) {
+        if (fail(hipSetDevice(sl.dev))) return e;
+        float *src = sl.buf[c->cur], *dst = c->redblack ? src : sl.buf[c->cur ^ 1];
+        const int parity = c->redblack ? (int)((iteration + (unsigned)sl.top()) & 1u) : -1;
+        unsigned *d = check ? sl.d_delta : nullptr;
+        if (check && fail(hipMemsetAsync(sl.d_delta, 0, sizeof(unsigned), sl.stream))) return e;
+        auto rows = [&](int lo, int hi, unsigned *dd, hipStream_t st) {
+            return epic_hip::launch_sweep_2d(src, dst, sl.maskw, sl.rows, c->pitch, lo, hi, rpt, c->math, parity, dd, st);
+        };
+        if (!exchange) {
+            // ghost rows (still exact deep enough) are swept like any other row; they do not count for max |du|
+            if (check && (sl.g_top || sl.g_bot)) {
+                if (fail(rows(0, sl.first(), nullptr, sl.stream)) || fail(rows(sl.first(), sl.last() + 1, d, sl.stream)) ||
+                    fail(rows(sl.last() + 1, sl.rows, nullptr, sl.stream)))
+                    return e;
+            } else if (fail(rows(0, sl.rows, d, sl.stream))) {
+                return e;
+            }
+        } else {
+            // the outermost G owned rows of each interior side first, on the second stream; the ghost rows are not swept,
+            // the exchange replaces them
+            const int top_hi = sl.g_top ? sl.first() + G : sl.first();
+            const int bot_lo = sl.g_bot ? sl.last() + 1 - G : sl.last() + 1;
+            if (fail(hipEventRecord(sl.ev_prev, sl.stream)) || fail(hipStreamWaitEvent(sl.comm, sl.ev_prev, 0))) return e;
+            if (sl.g_top && fail(rows(sl.first(), top_hi, d, sl.comm))) return e;
+            if (sl.g_bot && fail(rows(bot_lo, sl.last() + 1, d, sl.comm))) return e;
+            if (fail(hipEventRecord(sl.ev_band, sl.comm))) return e;
+            if (fail(rows(top_hi, bot_lo, d, sl.stream))) return e;
+        }
+    }
+    if (exchange) {
+        for (size_t k = 0; k + 1 < c->slabs.size(); k++) {
+            Ctx::Slab &a = c->slabs[k], &b = c->slabs[k + 1];
+            float *da = c->redblack ? a.buf[c->cur] : a.buf[c->cur ^ 1], *db = c->redblack ? b.buf[c->cur] : b.buf[c->cur ^ 1];
+            // a's last G owned rows -> b's top ghost rows (on b's second stream, after a's bands and b's own)
+            if (fail(hipSetDevice(b.dev)) || fail(hipStreamWaitEvent(b.comm, a.ev_band, 0)) ||
+                fail(multi_copy_rows(c, b, db, 0, a, da, a.last() + 1 - G, G, b.comm)))
+                return e;
+            // b's first G owned rows -> a's bottom ghost rows
+            if (fail(hipSetDevice(a.dev)) || fail(hipStreamWaitEvent(a.comm, b.ev_band, 0)) ||
+                fail(multi_copy_rows(c, a, da, a.rows - G, b, db, b.first(), G, a.comm)))
+                return e;
+        }
+        for (auto &sl : c->slabs)
+            if (fail(hipSetDevice(sl.dev)) || fail(hipEventRecord(sl.ev_comm, sl.comm))) return e;
+        // the next iteration of a slab starts when its own bands and incoming copies are done AND the neighbours have read
+        // the rows they copy out of it
+        for (size_t k = 0; k < c->slabs.size(); k++) {
+            Ctx::Slab &sl = c->slabs[k];
+            if (fail(hipSetDevice(sl.dev)) || fail(hipStreamWaitEvent(sl.stream, sl.ev_comm, 0))) return e;
+            if (k > 0 && fail(hipStreamWaitEvent(sl.stream, c->slabs[k - 1].ev_comm, 0))) return e;
+            if (k + 1 < c->slabs.size() && fail(hipStreamWaitEvent(sl.stream, c->slabs[k + 1].ev_comm, 0))) return e;
+        }
+        c->since = 0;
+    } else {
+        c->since++;
+    }
+    if (!c->redblack) c->cur ^= 1;
+    return hipSuccess;
+}
+
+int multi_read_delta(Harmonic *h, Ctx *c, const char *fn)
+{
+    DeviceGuard g;
+    for (auto &sl : c->slabs) {
+        if (hipSetDevice(sl.dev) != hipSuccess ||
+            hipStreamSynchronize(sl.comm) != hipSuccess ||  // the boundary bands of a check iteration ran there
+            hipMemcpyAsync(sl.h_delta, sl.d_delta, sizeof(float), hipMemcpyDeviceToHost, sl.stream) != hipSuccess) {
+            report(fn, "Failed to copy memory from device to host for the max delta.");
+            return EPIC_ERROR_MEMCPY_TO_HOST;
+        }
+    }
+    float d = 0.0f;
+    for (auto &sl : c->slabs) {
+        if (hipSetDevice(sl.dev) != hipSuccess || hipStreamSynchronize(sl.stream) != hipSuccess) {
+            report(fn, "Failed to synchronize the device after the 'update and check' kernel.");
+            return EPIC_ERROR_DEVICE_SYNCHRONIZE;
+        }
+        d = std::max(d, *sl.h_delta);  // the host-side max of the per-device words
+    }
+    h->delta = d;
+    return EPIC_SUCCESS;
+}
+
+int multi_get_values(Harmonic *h, Ctx *c, const char *fn)
+{
+    DeviceGuard g;
+    multi_sync(c);
+    for (auto &sl : c->slabs) {
+        if (hipSetDevice(sl.dev) != hipSuccess ||
+            hipMemcpy2D(h->u + (size_t)sl.lo * c->cols, (size_t)c->cols * sizeof(float),
+                        sl.buf[c->cur] + (size_t)sl.first() * c->pitch, (size_t)c->pitch * sizeof(float),
+                        (size_t)c->cols * sizeof(float), (size_t)(sl.hi - sl.lo), hipMemcpyDeviceToHost) != hipSuccess) {
+            report(fn, "Failed to copy memory from device to host for the potential values.");
+            return EPIC_ERROR_MEMCPY_TO_HOST;
+        }
+    }
+    return EPIC_SUCCESS;
+}
+
+// harmonic_utilities_set_cells_2d_gpu on the slabs: every slab applies the edits that fall into its local rows -- owned
+// AND ghost rows, so that neighbours agree without an exchange.
+int multi_set_cells(Ctx *c, unsigned k, const unsigned *v, const unsigned *types, const char *fn)
+{
+    DeviceGuard g;
+    multi_sync(c);
+    int rc = EPIC_SUCCESS;
+    for (auto &sl : c->slabs) {
+        unsigned *d_v = nullptr, *d_types = nullptr;
+        if (hipSetDevice(sl.dev) != hipSuccess || hipMalloc((void **)&d_v, 2 * (size_t)k * sizeof(unsigned)) != hipSuccess ||
+            hipMalloc((void **)&d_types, (size_t)k * sizeof(unsigned)) != hipSuccess) {
+            (void)hipGetLastError();
+            report(fn, "Failed to allocate device-side memory for the cell locations and types.");
+            rc = EPIC_ERROR_DEVICE_MALLOC;
+        } else if (hipMemcpyAsync(d_v, v, 2 * (size_t)k * sizeof(unsigned), hipMemcpyHostToDevice, sl.stream) != hipSuccess ||
+                   hipMemcpyAsync(d_types, types, (size_t)k * sizeof(unsigned), hipMemcpyHostToDevice, sl.stream) != hipSuccess) {
+            report(fn, "Failed to copy memory from host to device for the cell locations and types.");
+            rc = EPIC_ERROR_MEMCPY_TO_DEVICE;
+        } else if (epic_hip::launch_set_cells_2d(sl.buf[c->cur], sl.maskw, sl.rows, c->cols, c->pitch, k, d_v, d_types, sl.stream,
+                                                 sl.top(), c->rows, sl.g_top > 0, sl.g_bot > 0) != hipSuccess) {
+            report(fn, "Failed to execute the 'set cells' kernel.");
+            rc = EPIC_ERROR_KERNEL_EXECUTION;
+        }
+        if (hipStreamSynchronize(sl.stream) != hipSuccess && rc == EPIC_SUCCESS) rc = EPIC_ERROR_DEVICE_SYNCHRONIZE;
+        if (d_v) (void)hipFree(d_v);
+        if (d_types) (void)hipFree(d_types);
+        if (rc != EPIC_SUCCESS) break;
+    }
     return rc;
 }
 
@@ -446,6 +866,10 @@ int harmonic_initialize_dimension_size_gpu(Harmonic *harmonic)  // harmonic_mode
     }
     if (hipMemcpy(c->d_m, harmonic->m, harmonic->n * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) {
         report(fn, "Failed to copy memory from host to device for the dimension size.");
+        (void)hipFree(c->d_m);  // (the reference leaks it here, harmonic_model_gpu.cu:50-55)
+        c->d_m = nullptr;
+        harmonic->d_m = nullptr;
+        drop_ctx_if_empty(harmonic);
         return EPIC_ERROR_MEMCPY_TO_DEVICE;
     }
     harmonic->d_m = c->d_m;
@@ -486,13 +910,29 @@ int harmonic_initialize_potential_values_gpu(Harmonic *harmonic)  // harmonic_mo
         report(fn, "Failed to allocate device-side memory for the potential values.");
         return EPIC_ERROR_DEVICE_MALLOC;
     }
-    if (c->maskw && !same_dims(harmonic, c)) {
+    if ((c->maskw || (c->multi() && c->slabs[0].maskw)) && !same_dims(harmonic, c)) {
         report(fn, "Invalid input (dimensions differ from the locked cells already on the device).");
         return EPIC_ERROR_INVALID_DATA;
     }
     drop_graphs(c);
     for (float *&b : c->buf) { if (b) (void)hipFree(b); b = nullptr; }
-    dims_from(harmonic, c);
+    if (c->multi()) { DeviceGuard g; multi_free_u(c); }
+    dims_into_ctx(harmonic, c);
+    if (c->multi()) {  // one pair of buffers per slab, each on its device
+        DeviceGuard g;
+        for (auto &sl : c->slabs)
+            for (int b = 0; b < 2; b++)
+                if (hipSetDevice(sl.dev) != hipSuccess ||
+                    hipMalloc((void **)&sl.buf[b], (size_t)sl.rows * c->pitch * sizeof(float)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    report(fn, "Failed to allocate device-side memory for the potential values.");
+                    multi_free_u(c);
+                    harmonic->d_u = nullptr;
+                    drop_ctx_if_empty(harmonic);
+                    return EPIC_ERROR_DEVICE_MALLOC;
+                }
+        return upload_u(harmonic, c, fn);
+    }
     for (int b = 0; b < 2; b++) {
         if (hipMalloc((void **)&c->buf[b], c->u_bytes()) != hipSuccess) {
             (void)hipGetLastError();
@@ -514,6 +954,7 @@ int harmonic_uninitialize_potential_values_gpu(Harmonic *harmonic)  // harmonic_
     if (c) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         drop_graphs(c);
+        if (c->multi()) { DeviceGuard g; multi_free_u(c); }
         for (float *&b : c->buf) {
             if (b && hipFree(b) != hipSuccess) {
                 report("harmonic_uninitialize_potential_values_gpu", "Failed to free device-side memory for the potential values.");
@@ -544,13 +985,32 @@ int harmonic_initialize_locked_gpu(Harmonic *harmonic)  // harmonic_model_gpu.cu
         report(fn, "Failed to allocate device-side memory for the locked cells.");
         return EPIC_ERROR_DEVICE_MALLOC;
     }
-    if (c->buf[0] && !same_dims(harmonic, c)) {
+    if ((c->buf[0] || (c->multi() && c->slabs[0].buf[0])) && !same_dims(harmonic, c)) {
         report(fn, "Invalid input (dimensions differ from the potential values already on the device).");
         return EPIC_ERROR_INVALID_DATA;
     }
     drop_graphs(c);
     if (c->maskw) { (void)hipFree(c->maskw); c->maskw = nullptr; }
-    dims_from(harmonic, c);
+    if (c->multi()) { DeviceGuard g; multi_free_mask(c); }
+    dims_into_ctx(harmonic, c);
+    if (c->multi()) {
+        {
+            DeviceGuard g;
+            for (auto &sl : c->slabs)
+                if (hipSetDevice(sl.dev) != hipSuccess ||
+                    hipMalloc((void **)&sl.maskw, sizeof(uint32_t) * epic_hip::mask_words_2d(sl.rows, c->pitch)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    report(fn, "Failed to allocate device-side memory for the locked cells.");
+                    multi_free_mask(c);
+                    harmonic->d_locked = nullptr;
+                    drop_ctx_if_empty(harmonic);
+                    return EPIC_ERROR_DEVICE_MALLOC;
+                }
+        }
+        int rc = upload_locked(harmonic, c, fn);
+        if (rc == EPIC_SUCCESS) harmonic->d_locked = c->slabs[0].maskw;
+        return rc;
+    }
     if (hipMalloc((void **)&c->maskw, c->mask_bytes()) != hipSuccess) {
         (void)hipGetLastError();
         report(fn, "Failed to allocate device-side memory for the locked cells.");
@@ -568,6 +1028,7 @@ int harmonic_uninitialize_locked_gpu(Harmonic *harmonic)  // harmonic_model_gpu.
     if (harmonic == nullptr) return EPIC_ERROR_INVALID_DATA;
     int rc = EPIC_SUCCESS;
     Ctx *c = find_ctx(harmonic);
+    if (c && c->multi()) { DeviceGuard g; multi_free_mask(c); }
     if (c && c->maskw) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         drop_graphs(c);
@@ -595,6 +1056,7 @@ int harmonic_update_model_gpu(Harmonic *harmonic)  // harmonic_model_gpu.cu:172-
         report(fn, "Invalid data.");
         return EPIC_ERROR_INVALID_DATA;
     }
+    if (c->multi()) { DeviceGuard g; multi_sync(c); }
     if (hipStreamSynchronize(c->stream) != hipSuccess) return EPIC_ERROR_DEVICE_SYNCHRONIZE;
     int rc = upload_u(harmonic, c, fn);
     if (rc != EPIC_SUCCESS) return rc;
@@ -619,6 +1081,20 @@ int harmonic_initialize_gpu(Harmonic *harmonic, unsigned int numThreads)  // har
         return EPIC_ERROR_DEVICE_MALLOC;
     }
     if (c->d_delta) { (void)hipFree(c->d_delta); c->d_delta = nullptr; }
+    if (c->multi()) {  // one delta word per slab; the host takes the maximum
+        DeviceGuard g;
+        multi_free_delta(c);
+        for (auto &sl : c->slabs)
+            if (hipSetDevice(sl.dev) != hipSuccess || hipMalloc((void **)&sl.d_delta, 64) != hipSuccess) {
+                (void)hipGetLastError();
+                report(fn, "Failed to allocate device-side memory for delta.");
+                multi_free_delta(c);
+                drop_ctx_if_empty(harmonic);
+                return EPIC_ERROR_DEVICE_MALLOC;
+            }
+        harmonic->d_delta = reinterpret_cast<float *>(c->slabs[0].d_delta);
+        return EPIC_SUCCESS;
+    }
     if (hipMalloc((void **)&c->d_delta, 64) != hipSuccess) {
         (void)hipGetLastError();
         report(fn, "Failed to allocate device-side memory for delta.");
@@ -634,6 +1110,7 @@ int harmonic_uninitialize_gpu(Harmonic *harmonic)  // harmonic_gpu.cu:307-324
     if (harmonic == nullptr) return EPIC_ERROR_INVALID_DATA;
     int rc = EPIC_SUCCESS;
     Ctx *c = find_ctx(harmonic);
+    if (c && c->multi()) { DeviceGuard g; multi_free_delta(c); }
     if (c && c->d_delta) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         if (hipFree(c->d_delta) != hipSuccess) {
@@ -660,7 +1137,7 @@ int harmonic_update_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmoni
         report(fn, "Failed to execute the 'Jacobi update' kernel.");
         return EPIC_ERROR_KERNEL_EXECUTION;
     }
-    harmonic->d_u = c->buf[c->cur];
+    harmonic->d_u = current_u(c);
     harmonic->currentIteration++;
     return EPIC_SUCCESS;
 }
@@ -670,7 +1147,7 @@ int harmonic_update_and_check_gpu(Harmonic *harmonic, unsigned int numThreads)  
     static const char *fn = "harmonic_update_and_check_gpu";
     (void)numThreads;
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
-    if (!harmonic || !ready(harmonic, c) || c->d_delta == nullptr || harmonic->d_delta == nullptr) {
+    if (!harmonic || !ready(harmonic, c) || !has_delta(c) || harmonic->d_delta == nullptr) {
         report(fn, "Invalid data.");
         return EPIC_ERROR_INVALID_DATA;
     }
@@ -678,7 +1155,7 @@ int harmonic_update_and_check_gpu(Harmonic *harmonic, unsigned int numThreads)  
         report(fn, "Failed to execute the 'Jacobi update and check' kernel.");
         return EPIC_ERROR_KERNEL_EXECUTION;
     }
-    harmonic->d_u = c->buf[c->cur];
+    harmonic->d_u = current_u(c);
     int rc = read_delta(harmonic, c, fn);
     if (rc != EPIC_SUCCESS) return rc;
     harmonic->currentIteration++;
@@ -689,10 +1166,11 @@ int harmonic_get_potential_values_gpu(Harmonic *harmonic)  // harmonic_gpu.cu:41
 {
     static const char *fn = "harmonic_get_potential_values_gpu";
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
-    if (!harmonic || harmonic->u == nullptr || !c || !c->buf[0] || harmonic->d_u == nullptr) {
+    if (!harmonic || harmonic->u == nullptr || !c || !(c->buf[0] || (c->multi() && c->slabs[0].buf[0])) || harmonic->d_u == nullptr) {
         report(fn, "Invalid data.");
         return EPIC_ERROR_INVALID_DATA;
     }
+    if (c->multi()) return multi_get_values(harmonic, c, fn);
     if (hipStreamSynchronize(c->stream) != hipSuccess) {
         report(fn, "Failed to synchronize the device before reading the potential values.");
         return EPIC_ERROR_DEVICE_SYNCHRONIZE;
@@ -759,7 +1237,7 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
                 report(fn, "Failed to perform the Jacobi update step.");
                 return EPIC_ERROR_KERNEL_EXECUTION;
             }
-            harmonic->d_u = c->buf[c->cur];
+            harmonic->d_u = current_u(c);
             harmonic->currentIteration += batch;
             result = EPIC_SUCCESS;
         }
@@ -816,6 +1294,7 @@ int harmonic_utilities_set_cells_2d_gpu(Harmonic *harmonic, unsigned int numThre
         report(fn, "Invalid data.");
         return EPIC_ERROR_INVALID_DATA;
     }
+    if (c->multi()) return multi_set_cells(c, k, v, types, fn);
     unsigned *d_v = nullptr, *d_types = nullptr;
     int rc = EPIC_SUCCESS;
     c->force = 2;  // cells and mask bits change under the work lists
@@ -866,7 +1345,7 @@ int epic_hip_update_n_gpu(Harmonic *harmonic, unsigned int sweeps, int check_las
 {
     static const char *fn = "epic_hip_update_n_gpu";
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
-    if (!harmonic || !ready(harmonic, c) || (check_last && c->d_delta == nullptr)) {
+    if (!harmonic || !ready(harmonic, c) || (check_last && !has_delta(c))) {
         report(fn, "Invalid data.");
         return EPIC_ERROR_INVALID_DATA;
     }
@@ -877,7 +1356,7 @@ int epic_hip_update_n_gpu(Harmonic *harmonic, unsigned int sweeps, int check_las
         return EPIC_ERROR_KERNEL_EXECUTION;
     }
     harmonic->currentIteration += plain;
-    harmonic->d_u = c->buf[c->cur];
+    harmonic->d_u = current_u(c);
     if (check_last && sweeps > 0) {
         int rc = read_delta(harmonic, c, fn);
         if (rc != EPIC_SUCCESS) return rc;
@@ -891,9 +1370,32 @@ int epic_hip_timed_sweeps_gpu(Harmonic *harmonic, unsigned int sweeps, unsigned 
 {
     static const char *fn = "epic_hip_timed_sweeps_gpu";
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
-    if (!harmonic || !elapsed_ms || !ready(harmonic, c) || (check_every && c->d_delta == nullptr)) {
+    if (!harmonic || !elapsed_ms || !ready(harmonic, c) || (check_every && !has_delta(c))) {
         report(fn, "Invalid data.");
         return EPIC_ERROR_INVALID_DATA;
+    }
+    if (c->multi()) {
+        // several devices: no single stream sees the whole batch, so the batch is bracketed by host clocks around
+        // "every stream of every slab idle" (the batches this is used for run for milliseconds to seconds)
+        { DeviceGuard g; multi_sync(c); }
+        const auto t0 = std::chrono::steady_clock::now();
+        int rc = EPIC_SUCCESS;
+        bool checked = false;
+        unsigned done = 0;
+        while (done < sweeps && rc == EPIC_SUCCESS) {
+            const unsigned it = harmonic->currentIteration;
+            const bool check = check_every && it % check_every == 0;
+            if (enqueue_sweep(c, check, it) != hipSuccess) rc = EPIC_ERROR_KERNEL_EXECUTION;
+            checked = checked || check;
+            harmonic->currentIteration++;
+            done++;
+        }
+        if (rc != EPIC_SUCCESS) report(fn, "Failed to execute the 'update' kernel.");
+        harmonic->d_u = current_u(c);
+        if (rc == EPIC_SUCCESS && checked) rc = read_delta(harmonic, c, fn);
+        { DeviceGuard g; multi_sync(c); }
+        *elapsed_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return rc;
     }
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return EPIC_ERROR_DEVICE_MALLOC;
@@ -918,7 +1420,7 @@ int epic_hip_timed_sweeps_gpu(Harmonic *harmonic, unsigned int sweeps, unsigned 
     }
     if (rc != EPIC_SUCCESS) report(fn, "Failed to execute the 'update' kernel.");
     (void)hipEventRecord(e1, c->stream);
-    harmonic->d_u = c->buf[c->cur];
+    harmonic->d_u = current_u(c);
     if (rc == EPIC_SUCCESS) {
         if (checked) rc = read_delta(harmonic, c, fn);  // the most recent check sweep's delta
         if (hipEventSynchronize(e1) != hipSuccess) rc = EPIC_ERROR_DEVICE_SYNCHRONIZE;
@@ -975,6 +1477,10 @@ int epic_hip_compute_paths_2d_gpu(Harmonic *harmonic, unsigned int n_paths, cons
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
     if (!harmonic || !ready(harmonic, c) || c->n != 2 || n_paths == 0 || !starts || !k || !rc_out || !paths) {
         report(fn, "Invalid data.");
+        return EPIC_ERROR_INVALID_DATA;
+    }
+    if (c->multi()) {  // the field lives on several devices: read it back and walk it with harmonic_compute_path_2d_cpu
+        report(fn, "Invalid data (not available in multi-device mode: use harmonic_get_potential_values_gpu and the CPU walk).");
         return EPIC_ERROR_INVALID_DATA;
     }
     // the host walk stops at size() < 2u * maxLength values (unsigned product, harmonic_path_cpu.cpp:185)
@@ -1088,7 +1594,43 @@ int epic_hip_get_layout(Harmonic *harmonic, unsigned int *pitch, size_t *u_bytes
     if (pitch) *pitch = (unsigned)c->pitch;
     if (u_bytes) *u_bytes = c->u_bytes();
     if (mask_bytes) *mask_bytes = c->mask_bytes();
+    if (c->multi()) {  // per-device state, ghost rows included, summed
+        size_t ub = 0, mb = 0;
+        for (const auto &sl : c->slabs) {
+            ub += (size_t)sl.rows * c->pitch * sizeof(float);
+            mb += sizeof(uint32_t) * epic_hip::mask_words_2d(sl.rows, c->pitch);
+        }
+        if (u_bytes) *u_bytes = ub;
+        if (mask_bytes) *mask_bytes = mb;
+    }
     return EPIC_SUCCESS;
+}
+
+// Which device holds which rows (multi-device mode: one entry per slab; otherwise one entry, the whole grid on the current
+// device).  Returns the number of slabs; fills at most `cap` entries of each non-null array.
+int epic_hip_device_layout(Harmonic *harmonic, int cap, int *devices, unsigned int *row_begin, unsigned int *row_end,
+                           unsigned int *ghost_rows)
+{
+    Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
+    if (!c || c->pitch == 0) return 0;
+    if (!c->multi()) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (cap > 0) {
+            if (devices) devices[0] = dev;
+            if (row_begin) row_begin[0] = 0;
+            if (row_end) row_end[0] = (unsigned)c->rows;
+            if (ghost_rows) ghost_rows[0] = 0;
+        }
+        return 1;
+    }
+    for (int k = 0; k < (int)c->slabs.size() && k < cap; k++) {
+        if (devices) devices[k] = c->slabs[k].dev;
+        if (row_begin) row_begin[k] = (unsigned)c->slabs[k].lo;
+        if (row_end) row_end[k] = (unsigned)c->slabs[k].hi;
+        if (ghost_rows) ghost_rows[k] = (unsigned)c->halo;
+    }
+    return (int)c->slabs.size();
 }
 
 size_t epic_hip_mask_words_2d(unsigned int rows, unsigned int pitch) { return epic_hip::mask_words_2d((int)rows, (int)pitch); }

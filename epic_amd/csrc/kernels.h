@@ -52,8 +52,11 @@ hipError_t launch_eval_math(const float *in, float *out, size_t n, int which, hi
 hipError_t launch_pack_mask_2d(const uint32_t *locked, int rows, int cols, int pitch, int ghost_top,
                                int ghost_bottom, uint32_t *maskw, hipStream_t stream);
 hipError_t launch_fill(float *p, size_t n, float v, hipStream_t stream);
+// row0 / grid_rows / pin_*: slab form -- the buffer holds global rows [row0, row0 + rows) of a grid of grid_rows rows
+// (0 = the buffer is the grid) and its outermost rows are pinned ghost rows.
 hipError_t launch_set_cells_2d(float *u, uint32_t *maskw, int rows, int cols, int pitch, unsigned k,
-                               const unsigned *v, const unsigned *types, hipStream_t stream);
+                               const unsigned *v, const unsigned *types, hipStream_t stream, int row0 = 0, int grid_rows = 0,
+                               int pin_top = 0, int pin_bottom = 0);
 
 // ---- streamlines on the resident field (path_2d.hip): one lane per start point ----------------
 // d_pts: n_paths x 2 * max_points floats; d_k: points per path (0 on failure); d_rc: EPIC_* code per path.

@@ -524,19 +524,25 @@ __global__ void fill_kernel(float *p, size_t n, float v)
 
 // Sparse edits (harmonic_utilities_gpu.cu:38-63): one thread per edit, into the CURRENT buffer and the
 // lane masks.  Border cells stay locked in the mask whatever the edit says (the sweep never updates them).
+// Slab form (multi-device): the buffer holds global rows [row0, row0 + rows) of a grid of grid_rows rows; edits outside
+// are somebody else's, the border test is the global one, and the outermost ghost rows stay pinned.
 __global__ void set_cells_2d_kernel(float *u, uint32_t *maskw, int rows, int cols, int pitch, unsigned k,
-                                    const unsigned *v, const unsigned *types)
+                                    const unsigned *v, const unsigned *types, int row0, int grid_rows, int pin_top,
+                                    int pin_bottom)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= k) return;
-    const unsigned x = v[2 * i], y = v[2 * i + 1];
-    if (y >= (unsigned)rows || x >= (unsigned)cols) return;
+    const unsigned x = v[2 * i], gy = v[2 * i + 1];
+    if (gy >= (unsigned)grid_rows || x >= (unsigned)cols) return;
+    const int y = (int)gy - row0;
+    if (y < 0 || y >= rows) return;
     const unsigned t = types[i];
     if (t > 2u) return;
     const float val = (t == 0u) ? 0.0f : -1e6f;
-    const bool lock = (t != 2u) || x == 0 || y == 0 || x == (unsigned)cols - 1 || y == (unsigned)rows - 1;
+    const bool lock = (t != 2u) || x == 0 || gy == 0 || x == (unsigned)cols - 1 || gy == (unsigned)grid_rows - 1 ||
+                      (pin_top && y == 0) || (pin_bottom && y == rows - 1);
     u[(size_t)y * pitch + x] = val;
-    uint32_t *w = maskw + mask_word_2d(y, x, (unsigned)pitch);
+    uint32_t *w = maskw + mask_word_2d((unsigned)y, x, (unsigned)pitch);
     const uint32_t bit = 1u << mask_bit_2d(x);
     if (lock) atomicOr(w, bit);
     else atomicAnd(w, ~bit);
@@ -700,11 +706,13 @@ hipError_t launch_fill(float *p, size_t n, float v, hipStream_t stream)
 }
 
 hipError_t launch_set_cells_2d(float *u, uint32_t *maskw, int rows, int cols, int pitch, unsigned k,
-                               const unsigned *v, const unsigned *types, hipStream_t stream)
+                               const unsigned *v, const unsigned *types, hipStream_t stream, int row0, int grid_rows,
+                               int pin_top, int pin_bottom)
 {
     if (k == 0) return hipSuccess;
+    if (grid_rows <= 0) grid_rows = rows;
     hipLaunchKernelGGL(set_cells_2d_kernel, dim3((k + 255) / 256), dim3(256), 0, stream, u, maskw, rows, cols, pitch, k,
-                       v, types);
+                       v, types, row0, grid_rows, pin_top, pin_bottom);
     return hipGetLastError();
 }
 

@@ -45,8 +45,13 @@ int epic_hip_timed_sweeps_gpu(EpicHarmonicT *harmonic, unsigned int sweeps, unsi
 /* Tuning knob: rows marched by one wave in the 2-D kernel (0 = automatic).  Also EPIC_HIP_ROWS_PER_TASK. */
 int epic_hip_set_rows_per_task(EpicHarmonicT *harmonic, unsigned int rows_per_task);
 
-/* Arithmetic of the sweep kernels (also EPIC_HIP_MATH=precise|df32|fast in the environment at initialisation):
- *   0 precise (default)  exp/log bit-identical to the host libm's expf/logf, evaluated in f64 -- the parity mode;
+/* Arithmetic of the sweep kernels (also EPIC_HIP_MATH=precise|tol|df32|fast in the environment at initialisation):
+ *   0 precise (default)  exp/log bit-identical to the host libm's expf/logf, evaluated in f64 -- the bit-exact parity mode;
+ *   4 tol                one exp-class split e^u = q 2^n per CELL (packed f32 polynomial), shared by the cells it is a
+ *                        neighbour of, one f64 log per cell; every rounding stage of the reference kept.  2-D and 3-D,
+ *                        Jacobi and red-black.  Jacobi stops by the reference's own test; converged fields within
+ *                        1e-5 max(1, |u|) of the reference's on its seeded grids, basic.png and maze.png, 1.6e-5 on the
+ *                        ill-conditioned umass.png.  ~1.3x faster per sweep than precise (the benchmarked mode);
  *   3 df32               packed-f32 double-float exp/log, <= 0.53 ulp, unbiased; ~1.3x faster; fixed sweep counts agree
  *                        with precise to a few ulp, but the reference's absolute max|du| < eps test may never fire on
  *                        ill-conditioned maps (the two checkerboard sub-sequences of Jacobi settle one ulp apart);
@@ -95,6 +100,20 @@ int epic_hip_activity_stats2(EpicHarmonicT *harmonic, unsigned long long *active
 
 /* Test hook: d_out[i] = which ? ln(d_in[i]) : exp(d_in[i]) with the precise device routines. */
 int epic_hip_eval_math(const float *d_in, float *d_out, size_t n, int which, void *stream);
+
+/* ---- several GPUs behind the unchanged ABI ------------------------------------------------------------------------
+ * EPIC_HIP_DEVICES=0,1,2,3 in the environment when a Harmonic's device state is created makes every harmonic_*_gpu entry
+ * point work on ONE 2-D grid cut into one row slab per listed device, in this process: harmonic_complete_gpu(&h, 1024) --
+ * the ROS plugin's only call, /root/reference/src/epic_nav_core_plugin.cpp:256 -- then uses the whole node.  The reference
+ * has nothing like it (libepic/src/harmonic/harmonic_gpu.cu:168-201 drives one device).  A device may be listed more than
+ * once ("0,0,0,0": four slabs on one GPU).  EPIC_HIP_HALO=G (default 8): ghost rows per interior side, traded every G
+ * iterations with hipMemcpyPeerAsync; results are bit-identical to the single-device path for every list and every G.
+ * 3-D grids, grids with fewer than 4 rows per listed device and an unusable list fall back to one device.  Activity
+ * tracking is off and the device streamline walk unavailable in this mode.
+ * epic_hip_device_layout: which device holds which rows -- returns the number of slabs (1 in single-device mode) and
+ * fills at most `cap` entries of each non-NULL array (owned rows [row_begin, row_end); ghost rows per interior side). */
+int epic_hip_device_layout(EpicHarmonicT *harmonic, int cap, int *devices, unsigned int *row_begin, unsigned int *row_end,
+                           unsigned int *ghost_rows);
 
 /* Geometry of the device-resident state: pitch in floats, bytes of one u buffer, bytes of the packed mask. */
 int epic_hip_get_layout(EpicHarmonicT *harmonic, unsigned int *pitch, size_t *u_bytes, size_t *mask_bytes);

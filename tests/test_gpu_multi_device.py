@@ -1,0 +1,200 @@
+"""Several devices behind the unchanged C-ABI (EPIC_HIP_DEVICES, include/epic_hip.h): one 2-D grid
+cut into row slabs, one per listed device, inside libepic.so -- so that the ROS plugin's harmonic_complete_gpu(&h, 1024)
+(/root/reference/src/epic_nav_core_plugin.cpp:256) uses a whole node without a line changed.
+
+A 1-GPU box cannot give every slab its own device, but the list may name a device more than once: "0,0,0,0" runs four
+slabs, with their ghost rows, second streams, events, halo copies and per-slab delta words, on the one GPU.  The bar is
+the single-device one: the tests of tests/test_gpu_parity.py / test_gpu_tol.py are run again, unchanged, under that
+environment -- bit-identical to the checker and to the reference's goldens for every slab count and every halo depth.
+BASELINE configs[3] (32768^2, 4 and 8 slabs) runs at full size: seam rows and the window around the goal against the
+single-device result and the checker."""
+import ctypes as ct
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as O
+import test_gpu_parity as P
+import test_gpu_tol as T
+from epic_amd import epic_harmonic as eh
+from epic_amd.harmonic import Harmonic
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+
+E = eh._epic
+NT = 1024
+UP = ct.POINTER(ct.c_uint)
+
+
+ALL_LISTS = [("0,0", "8"), ("0,0,0,0", "3"), ("0,0,0", "1"), ("0,0,0,0,0,0,0,0", "8")]
+ALL_IDS = ["2slabs_halo8", "4slabs_halo3", "3slabs_halo1", "8slabs_halo8"]
+
+
+@pytest.fixture(params=ALL_LISTS[1::2], ids=ALL_IDS[1::2])
+def devices(request):
+    """Most tests run with 4 slabs / 3 ghost rows and 8 slabs / 8 ghost rows; test_fixed_sweeps_equal_the_checker takes
+    every list (2 and 3 slabs, the one-row halo of the north star's wording included)."""
+    os.environ["EPIC_HIP_DEVICES"], os.environ["EPIC_HIP_HALO"] = request.param
+    yield request.param[0].count(",") + 1
+    del os.environ["EPIC_HIP_DEVICES"], os.environ["EPIC_HIP_HALO"]
+
+
+@pytest.fixture(params=ALL_LISTS, ids=ALL_IDS)
+def every_list(request):
+    os.environ["EPIC_HIP_DEVICES"], os.environ["EPIC_HIP_HALO"] = request.param
+    yield request.param[0].count(",") + 1
+    del os.environ["EPIC_HIP_DEVICES"], os.environ["EPIC_HIP_HALO"]
+
+
+def slabs_of(h):
+    dev = (ct.c_int * 64)()
+    lo, hi, g = (ct.c_uint * 64)(), (ct.c_uint * 64)(), (ct.c_uint * 64)()
+    n = E.epic_hip_device_layout(h, 64, dev, lo, hi, g)
+    return n, [(dev[i], lo[i], hi[i], g[i]) for i in range(min(n, 64))]
+
+
+def test_layout_follows_the_device_list(devices):
+    m = [403, 300]
+    u0, locked = P.synthetic_grid(m, 5, 0.05)
+    h = P.make(m, u0, locked)
+    P.gpu_init(h)
+    n, slabs = slabs_of(h)
+    assert n == devices and slabs[0][1] == 0 and slabs[-1][2] == m[0]
+    assert all(a[2] == b[1] for a, b in zip(slabs, slabs[1:])) and all(s[0] == 0 for s in slabs)
+    assert all(0 <= (a[2] - a[1]) - (b[2] - b[1]) <= 1 for a, b in zip(slabs, slabs[1:]))   # near-equal, larger first
+    P.gpu_fini(h)
+    # too few rows for the list, or a 3-D grid: one device
+    for m2 in ([7, 300], [6, 10, 70]):
+        u0, locked = P.synthetic_grid(m2, 5, 0.05)
+        h = P.make(m2, u0, locked)
+        P.gpu_init(h)
+        assert slabs_of(h)[0] == 1
+        P.gpu_fini(h)
+
+
+@pytest.mark.parametrize("m,seed,dens", [g for g in P.GRIDS_2D if g[0][0] >= 64])
+def test_fixed_sweeps_equal_the_checker(every_list, m, seed, dens):
+    P.test_fixed_sweeps_2d_vs_oracle_jacobi(m, seed, dens)
+
+
+@pytest.mark.parametrize("m,rpt", [([66000, 300], 0), ([1200, 9000], 64), ([200, 700], 16)])
+def test_extreme_aspect_ratios(devices, m, rpt):
+    P.test_extreme_aspect_ratios(m, rpt)
+
+
+def test_navigation_node_flow_with_live_edits(devices):
+    """update(k) batches, set_cells edits (some on and next to the slab seams), mid-solve readback, update_model."""
+    P.test_navigation_node_flow_set_cells_and_mid_solve_readback()
+    m = [120, 300]
+    u0, locked = P.synthetic_grid(m, 9, 0.05)
+    h = P.make(m, u0, locked)
+    P.gpu_init(h)
+    n, slabs = slabs_of(h)
+    p = O.Problem(m, u0, locked)
+    lib = O.oracle()
+    assert E.epic_hip_update_n_gpu(h, 11, 0) == 0
+    lib.oracle_jacobi_run(ct.byref(p.h), 11)
+    edits, types = [], []
+    for (_, lo, hi, _g) in slabs[1:]:        # a goal on the last row of the slab above, an obstacle on the first row of this one
+        edits += [(37, lo - 1), (150, lo), (151, lo + 1)]
+        types += [0, 1, 2]
+    v = np.array(edits, dtype=np.uint32)
+    t = np.array(types, dtype=np.uint32)
+    args = (len(t), v.ctypes.data_as(UP), t.ctypes.data_as(UP))
+    assert E.harmonic_utilities_set_cells_2d_gpu(h, NT, *args) == 0
+    assert lib.oracle_set_cells_2d(ct.byref(p.h), *args) == 0
+    assert E.epic_hip_update_n_gpu(h, 23, 1) in (0, 1)
+    lib.oracle_jacobi_run(ct.byref(p.h), 23)
+    assert E.harmonic_get_potential_values_gpu(h) == 0
+    P.gpu_fini(h)
+    assert np.array_equal(h.u_array().ravel(), p.u) and h.delta == p.h.delta
+
+
+def test_lifecycle_and_validation(devices, capfd):
+    P.test_execute_gpu_validation_and_lifecycle(capfd)
+
+
+@pytest.mark.parametrize("name", ["g2d_32", "g2d_64", "g2d_70x66_dense"])
+def test_complete_gpu_goldens(devices, goldens, name):
+    P.test_complete_gpu_vs_reference_golden(goldens, name)
+
+
+@pytest.mark.parametrize("name", ["basic", "umass"])
+def test_maps_converged(devices, goldens, name, record_property):
+    P.test_maps_converged_vs_reference_golden(goldens, name, record_property)
+
+
+@pytest.mark.parametrize("name", ["g2d_64", "g2d_70x66_dense"])
+def test_redblack_is_the_reference_iteration(devices, goldens, name):
+    P.test_redblack_half_sweeps_equal_reference_golden(goldens, name)
+
+
+def test_redblack_map_is_the_reference_result(devices, goldens):
+    os.environ["EPIC_HIP_SCHEME"] = "redblack"
+    try:
+        P.test_redblack_maps_are_the_reference_result(goldens, "basic", None)
+    finally:
+        del os.environ["EPIC_HIP_SCHEME"]
+
+
+@pytest.mark.parametrize("m,seed,dens,rpt", [g for g in T.GRIDS if g[0] in ([211, 530], [257, 513])])
+def test_tol_iterations_equal_the_checker(devices, m, seed, dens, rpt):
+    T.test_tol_iterations_equal_the_checker_bit_for_bit(m, seed, dens, rpt, eh.SCHEME_JACOBI)
+
+
+def test_full_size_8192_window_property(devices):
+    P.test_full_size_8192_window_property()
+
+
+@pytest.mark.parametrize("devlist", ["0,0,0,0", "0,0,0,0,0,0,0,0"], ids=["4slabs", "8slabs"])
+def test_config4_32768_squared_on_slabs(devlist):
+    """BASELINE configs[3]: 32768 x 32768, 4- and 8-way slab decomposition, at full size.  K = 2 halo + 3 sweeps (two
+    exchanges and a check in between): the rows on both sides of every seam and the window around the goal must equal the
+    single-device run of the same library bit for bit, the window also the checker's run on the window alone; nothing
+    outside the goal's reach may have moved."""
+    n, halo = 32768, 8
+    K, W = 2 * halo + 3, 64
+    m = [n, n]
+    u0, locked = O.oracle_synthetic(m)
+    # a second goal right on the first seam, so that values cross it: the centre goal is far from every seam but one
+    nslab = devlist.count(",") + 1
+    seam = n // nslab
+    c = n // 2
+    idx = (seam - 1) * n + 1000
+    u0[idx] = 0.0
+    locked[idx] = 1
+
+    def run(env):
+        if env:
+            os.environ["EPIC_HIP_DEVICES"], os.environ["EPIC_HIP_HALO"] = env, str(halo)
+        try:
+            h = P.make(m, u0, locked)
+            P.gpu_init(h)
+            slabs = slabs_of(h)
+            assert E.epic_hip_set_activity_tracking(h, 0) == 0
+            assert E.epic_hip_update_n_gpu(h, halo + 1, 1) in (0, 1)      # a check sweep on the sweep after an exchange
+            d1 = float(h.delta)
+            assert E.epic_hip_update_n_gpu(h, K - halo - 1, 1) in (0, 1)
+            assert E.harmonic_get_potential_values_gpu(h) == 0
+            P.gpu_fini(h)
+            return h.u_array().reshape(n, n), d1, float(h.delta), slabs
+        finally:
+            if env:
+                del os.environ["EPIC_HIP_DEVICES"], os.environ["EPIC_HIP_HALO"]
+
+    got, d1, d2, (ns, slabs) = run(devlist)
+    assert ns == nslab and [s[1] for s in slabs] == [k * seam for k in range(nslab)]
+    bands = [slice(max(0, s[1] - 2 * K), s[1] + 2 * K) for s in slabs[1:]] + [slice(c - W, c + W)]
+    kept = [got[b].copy() for b in bands]
+    moved = int((got != u0.reshape(n, n)).sum())
+    del got
+    ref, r1, r2, _ = run(None)
+    assert (d1, d2) == (r1, r2)
+    for b, k in zip(bands, kept):
+        assert np.array_equal(ref[b], k), "rows %s differ from the single-device result" % (b,)
+    assert moved == int((ref != u0.reshape(n, n)).sum()) and 0 < moved <= 2 * (2 * K + 1) ** 2
+    win = (slice(c - W, c + W), slice(c - W, c + W))
+    p = O.Problem([2 * W, 2 * W], u0.reshape(n, n)[win].copy(), locked.reshape(n, n)[win].copy())
+    O.oracle().oracle_jacobi_run(ct.byref(p.h), K)
+    assert np.array_equal(ref[win].ravel(), p.u)
