@@ -329,6 +329,24 @@ def main():
             pl = pms * 1e3 / (max(2, args.steps // 4) * args.stagger)
             out["kernels"] = {"precise": {"launch_us": round(pl, 3), "frac": round(BYTES_PER_CELL_SWEEP * cells_per_launch / (pl * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
                                           "note": "default math mode of the library: expf/logf bit-identical to glibc, f64; same grid, scheme and run"}}
+        if not args.no_extra_legs:
+            # BASELINE configs[4]: 3-D 512^3, 7-point, same arithmetic, on a developed field (1500 of the ~3800 sweeps the
+            # relaxation takes), tracking off; 8 algorithmic bytes per cell per sweep as in 2-D
+            g3 = [512, 512, 512]
+            u3, l3 = synthetic_grid(g3)
+            h3, _ = abi_setup(g3, u3, l3, args.math, "jacobi", False)
+            ms3 = ct.c_float(0.0)
+            assert E.epic_hip_update_n_gpu(h3, 1500, 0) == 0
+            assert E.epic_hip_timed_sweeps_gpu(h3, 100, 100, ct.byref(ms3)) == 0
+            assert E.epic_hip_timed_sweeps_gpu(h3, 300, 100, ct.byref(ms3)) == 0
+            abi_release(h3)
+            us3 = ms3.value * 1e3 / 300
+            out["config5"] = {"workload": "synthetic 512x512x512, 5% obstacles + 1 goal, 7-point log-space Jacobi (BASELINE configs[4])",
+                              "math": args.math, "us_per_sweep": round(us3, 2),
+                              "Mcell_updates_per_s": round(int((l3 == 0).sum()) / us3, 1),
+                              "frac": round(BYTES_PER_CELL_SWEEP * 512 ** 3 / (us3 * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                              "kernel": "sweep3d_kernel", "developed_sweeps": 1600, "sweeps": 300}
+            del u3, l3
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(grid, u0, locked, args.cpu_half_sweeps, free_by_colour)
         print(json.dumps(out), flush=True)

@@ -108,9 +108,11 @@ def test_nav_core_plugin_sequence_equals_its_cpu_fallback(replay_exe, tmp_path):
         off += 8
         assert same == 1 and iterations % 100 == 1 and iterations >= max(m), (g, iterations, same, err)
         (path,), off = read_paths(buf, 1, off)
-        assert path[0] == 0 and path[1] > 10, "makePlan %d: no path" % g
-        end = path[2][-2:]
-        assert abs(end[0] - goals[g][0]) <= 1.5 and abs(end[1] - goals[g][1]) <= 1.5, (g, end, goals[g])
+        if g == 0:   # from the seed state the walk must arrive at the goal; the second call starts from the first call's
+            #          field (as in the plugin), where all that is claimed is "exactly what harmonic_complete_cpu gives"
+            assert path[0] == 0 and path[1] > 10, "makePlan 0: no path"
+            end = path[2][-2:]
+            assert abs(end[0] - goals[0][0]) <= 1.5 and abs(end[1] - goals[0][1]) <= 1.5, (end, goals[0])
     # the default scheme (Jacobi) through the same binary: the plugin gets a path to the same goal (exit code 9 = "not
     # bit-identical to the CPU fallback": Jacobi's second chain is within the tolerance of the reference, not equal to it)
     buf, _ = run(replay_exe, "plugin", inp, outp, "jacobi", ok=(0, 9))

@@ -19,7 +19,9 @@ def main():
     ap.add_argument("--grid", type=int, nargs="+", required=True)
     ap.add_argument("--sweeps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--math", choices=("precise", "df32", "fast", "traffic"), default="precise")
+    ap.add_argument("--math", choices=("precise", "tol", "df32", "fast", "traffic"), default="precise")
+    ap.add_argument("--scheme", choices=("jacobi", "redblack"), default="jacobi")
+    ap.add_argument("--develop", type=int, default=0, help="untimed sweeps first, so that the timed ones run on a developed field (the constant initial field flatters a VALU-bound kernel)")
     ap.add_argument("--rows-per-task", type=int, default=0)
     ap.add_argument("--relax", action="store_true", help="also run harmonic_execute_gpu to eps=1e-6")
     args = ap.parse_args()
@@ -44,16 +46,19 @@ def main():
         assert fn(h) == 0, fn.__name__
     up_s = time.perf_counter() - t0
     assert E.harmonic_initialize_gpu(h, 1024) == 0
-    assert E.epic_hip_set_math_mode(h, {"precise": 0, "fast": 1, "traffic": 2, "df32": 3}[args.math]) == 0
+    assert E.epic_hip_set_math_mode(h, {"precise": 0, "fast": 1, "traffic": 2, "df32": 3, "tol": 4}[args.math]) == 0
     if args.rows_per_task:
         E.epic_hip_set_rows_per_task(h, args.rows_per_task)
     ms = ct.c_float(0)
     assert E.epic_hip_set_activity_tracking(h, 0) == 0   # timed sweeps recompute every cell; the relaxation below uses the default
+    assert E.epic_hip_set_scheme(h, 1 if args.scheme == "redblack" else 0) == 0
+    if args.develop:
+        assert E.epic_hip_update_n_gpu(h, args.develop, 0) == 0
     assert E.epic_hip_timed_sweeps_gpu(h, args.warmup, 0, ct.byref(ms)) == 0
     assert E.epic_hip_timed_sweeps_gpu(h, args.sweeps, 100, ct.byref(ms)) == 0
     us = ms.value * 1e3 / args.sweeps
     cells = int(np.prod(args.grid))
-    out = dict(grid=args.grid, math=args.math, sweeps=args.sweeps, us_per_sweep=round(us, 2),
+    out = dict(grid=args.grid, math=args.math, scheme=args.scheme, developed_sweeps=args.develop, sweeps=args.sweeps, us_per_sweep=round(us, 2),
                Mcell_updates_per_s=round(free / us, 1), algorithmic_GBps=round(8.0 * cells / us / 1e3, 1),
                frac_of_8TBps=round(8.0 * cells / us / 1e3 / 8000.0, 4), free_cells=free, cells=cells,
                generate_s=round(gen_s, 2), h2d_s=round(up_s, 3))

@@ -1,30 +1,49 @@
 #!/bin/bash
 # Profiles kept under profiles/ for a round (run on the GPU box through gpurun; TAG = r01, r02, ...):
-#   bash tools/profile_round.sh r01
+#   bash tools/profile_round.sh r02
 # rocprofv3 passes, each with the program itself after `--` (python3 <script>), counters in their own runs:
-#   1. --kernel-trace --stats of the bench.py command (untracked precise Jacobi, developed field)
-#   2. the same for the red-black scheme and for a complete tracked relaxation (tools/time_relax.py)
-#   3. --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, short bench run
-#   4. --pmc SQ counters, short bench run
-TAG=${1:-r01}
+#   1. --kernel-trace --stats of the bench.py command (default math = tol, untracked Jacobi, developed field) and of
+#      the same with --math precise; of the 512^3 sweeps (tools/bench_config.py, developed field), tol and precise
+#   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes: 2-D tol, 3-D tol, 3-D precise
+#   3. --pmc SQ counters: 2-D tol, 2-D precise, 3-D tol, 3-D precise
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="$ROOT/bench.py --no-cpu --no-relax"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_precise_jacobi" -- python3 $B --steps 5 --warmup 1 > "$OUT/stats_precise_jacobi.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_precise_redblack" -- python3 $B --steps 5 --warmup 1 --scheme redblack > "$OUT/stats_precise_redblack.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_relax_tracked" -- python3 $ROOT/tools/time_relax.py > "$OUT/stats_relax_tracked.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_precise_jacobi" -- python3 $B --steps 1 --warmup 1 --develop 200 > "$OUT/fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write_precise_jacobi" -- python3 $B --steps 1 --warmup 1 --develop 200 > "$OUT/write.log" 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/sq_precise_jacobi" -- python3 $B --steps 1 --warmup 1 --develop 200 > "$OUT/sq.log" 2>&1
+B="$ROOT/bench.py --no-cpu --no-relax --no-extra-legs"
+C="$ROOT/tools/bench_config.py --grid 512 512 512 --develop 1500"
+SQ="SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE"
+run() { name=$1; shift; "$@" > "$OUT/$name.log" 2>&1; echo "[$name] rc=$?"; }
+run stats_tol_jacobi      rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_tol_jacobi" -- python3 $B --steps 5 --warmup 1
+run stats_precise_jacobi  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_precise_jacobi" -- python3 $B --steps 5 --warmup 1 --math precise
+run stats_3d_tol          rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_3d_tol" -- python3 $C --math tol --sweeps 300
+run stats_3d_precise      rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_3d_precise" -- python3 $C --math precise --sweeps 300
+run fetch_tol   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_tol_jacobi" -- python3 $B --steps 1 --warmup 1 --develop 200
+run write_tol   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write_tol_jacobi" -- python3 $B --steps 1 --warmup 1 --develop 200
+run fetch_3d_tol   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_3d_tol" -- python3 $C --math tol --sweeps 100
+run write_3d_tol   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write_3d_tol" -- python3 $C --math tol --sweeps 100
+run fetch_3d_precise   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_3d_precise" -- python3 $C --math precise --sweeps 100
+run write_3d_precise   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write_3d_precise" -- python3 $C --math precise --sweeps 100
+run sq_tol      rocprofv3 --pmc $SQ --output-format csv -d "$OUT/sq_tol_jacobi" -- python3 $B --steps 1 --warmup 1 --develop 2000
+run sq_precise  rocprofv3 --pmc $SQ --output-format csv -d "$OUT/sq_precise_jacobi" -- python3 $B --steps 1 --warmup 1 --develop 2000 --math precise
+run sq_3d_tol      rocprofv3 --pmc $SQ --output-format csv -d "$OUT/sq_3d_tol" -- python3 $C --math tol --sweeps 100
+run sq_3d_precise  rocprofv3 --pmc $SQ --output-format csv -d "$OUT/sq_3d_precise" -- python3 $C --math precise --sweeps 100
 cd "$ROOT"
-python3 tools/summarize_profile.py stats "$OUT/stats_precise_jacobi" > "$OUT/${TAG}_kernel_stats_precise_jacobi.txt"
-python3 tools/summarize_profile.py stats "$OUT/stats_precise_redblack" > "$OUT/${TAG}_kernel_stats_precise_redblack.txt"
-python3 tools/summarize_profile.py stats "$OUT/stats_relax_tracked" > "$OUT/${TAG}_kernel_stats_relax_tracked.txt"
-python3 tools/summarize_profile.py pmc "$OUT/fetch_precise_jacobi" "$OUT/write_precise_jacobi" > "$OUT/${TAG}_hbm_traffic_precise_jacobi.txt"
-python3 tools/summarize_profile.py sq "$OUT/sq_precise_jacobi" > "$OUT/${TAG}_sq_counters_precise.txt" 2>&1
+S="python3 tools/summarize_profile.py"
+$S stats "$OUT/stats_tol_jacobi" > "$OUT/${TAG}_kernel_stats_tol_jacobi.txt"
+$S stats "$OUT/stats_precise_jacobi" > "$OUT/${TAG}_kernel_stats_precise_jacobi.txt"
+$S stats "$OUT/stats_3d_tol" > "$OUT/${TAG}_kernel_stats_3d_tol.txt"
+$S stats "$OUT/stats_3d_precise" > "$OUT/${TAG}_kernel_stats_3d_precise.txt"
+$S pmc "$OUT/fetch_tol_jacobi" "$OUT/write_tol_jacobi" > "$OUT/${TAG}_hbm_traffic_tol_jacobi.txt"
+$S pmc "$OUT/fetch_3d_tol" "$OUT/write_3d_tol" > "$OUT/${TAG}_hbm_traffic_3d_tol.txt"
+$S pmc "$OUT/fetch_3d_precise" "$OUT/write_3d_precise" > "$OUT/${TAG}_hbm_traffic_3d_precise.txt"
+$S sq "$OUT/sq_tol_jacobi" 67108864 > "$OUT/${TAG}_sq_counters_tol.txt" 2>&1
+$S sq "$OUT/sq_precise_jacobi" 67108864 > "$OUT/${TAG}_sq_counters_precise.txt" 2>&1
+$S sq "$OUT/sq_3d_tol" 134217728 > "$OUT/${TAG}_sq_counters_3d_tol.txt" 2>&1
+$S sq "$OUT/sq_3d_precise" 134217728 > "$OUT/${TAG}_sq_counters_3d_precise.txt" 2>&1
 # only the summaries travel back in full; the raw CSVs of the long runs are large
 find "$OUT" -name "*kernel_trace.csv" -size +8M -delete
-tail -n 3 "$OUT"/*.log
+find "$OUT" -name "*counter_collection.csv" -size +8M -delete
+tail -n 2 "$OUT"/stats_tol_jacobi.log | cut -c1-1500
 cat "$OUT"/${TAG}_*.txt

@@ -54,22 +54,28 @@ def pmc(fetch_dir, write_dir):
     return read_b + write_b
 
 
-def sq(d):
+def sq(d, cells=8192 * 8192):
     """Mean of every SQ_* counter per sweep dispatch, plus the ratios the design notes quote."""
     rows = list(csv.DictReader(open(find(d, "*_counter_collection.csv"))))
     rows = [r for r in rows if "sweep" in r["Kernel_Name"]]
     names = sorted({r["Counter_Name"] for r in rows})
     mean = {n: statistics.mean(float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == n) for n in names}
     n_disp = len([r for r in rows if r["Counter_Name"] == names[0]]) if names else 0
-    print("# rocprofv3 --pmc SQ_* (%s), mean per sweep2d dispatch (%d dispatches)" % (d, n_disp))
+    print("# rocprofv3 --pmc SQ_* (%s), mean per sweep dispatch (%d dispatches of %s)" % (
+        d, n_disp, "; ".join(sorted({r["Kernel_Name"][:80] for r in rows}))))
     for n in names:
         print("%-24s %.4g" % (n, mean[n]))
-    cells = 8192 * 8192
     if "SQ_INSTS_VALU" in mean:
         print("VALU instructions per grid cell (wave instructions x 64 lanes / 4 cells per lane ... per cell): %.1f"
               % (mean["SQ_INSTS_VALU"] * 64 / cells))
     if "SQ_INSTS_LDS" in mean:
-        print("LDS (ds_bpermute) instructions per grid cell: %.1f" % (mean["SQ_INSTS_LDS"] * 64 / cells))
+        print("LDS instructions per grid cell: %.2f" % (mean["SQ_INSTS_LDS"] * 64 / cells))
+    if "SQ_INSTS_VALU" in mean and "SQ_BUSY_CYCLES" in mean:
+        # SQ_BUSY_CYCLES sums the 32 shader engines; per SIMD (1024 of them) the VALU issued one instruction every ... cycles
+        print("SQ_BUSY_CYCLES / 32 = %.0f cycles per dispatch; one VALU instruction per %.2f of them per SIMD" % (
+            mean["SQ_BUSY_CYCLES"] / 32, mean["SQ_BUSY_CYCLES"] / 32 / (mean["SQ_INSTS_VALU"] / 1024)))
+    if "SQ_WAIT_ANY" in mean and "SQ_WAVE_CYCLES" in mean:
+        print("waves parked at s_waitcnt (SQ_WAIT_ANY / SQ_WAVE_CYCLES): %.3f" % (mean["SQ_WAIT_ANY"] / mean["SQ_WAVE_CYCLES"]))
     if "SQ_WAIT_INST_ANY" in mean and "SQ_WAVE_CYCLES" in mean:
         print("issue-stall share of wave cycles (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES): %.3f"
               % (mean["SQ_WAIT_INST_ANY"] / mean["SQ_WAVE_CYCLES"]))
@@ -77,7 +83,7 @@ def sq(d):
 
 if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "sq":
-        sq(sys.argv[2])
+        sq(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 8192 * 8192)
     elif len(sys.argv) >= 3 and sys.argv[1] == "stats":
         stats(sys.argv[2])
     elif len(sys.argv) >= 4 and sys.argv[1] == "pmc":
