@@ -51,6 +51,7 @@ struct Ctx {
     // Launch-bound grids replay the plain sweeps between two checks from a captured hipGraph; key = (count, starting
     // buffer, starting parity, math, scheme, rows_per_task) -- everything a captured launch sequence depends on.
     std::map<std::tuple<unsigned, int, int, int, int, int>, hipGraphExec_t> graphs;
+    bool graphs_broken = false;    // a capture / instantiate / launch failed once: batches run eagerly from then on
     // Activity tracking: every iteration lists the tiles its successor has to recompute; tiles whose inputs did
     // not change are never touched (bit-identical results, see kernels_2d.hip).  One device block `wake` holds 3 counter
     // sets (L words each, L = kWakeListCount), the queued marks of both directions (act_tiles words each) and both
@@ -394,28 +395,42 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
         return enqueue_plain_run(c, count, first);
     const auto key = std::make_tuple(count, c->cur + 2 * (c->track ? 1 + c->phase : 0), (int)(first & 1u), c->math,
                                      (int)c->redblack, auto_rows_per_task(c));
+    if (c->graphs_broken) return enqueue_plain_run(c, count, first);
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
-        const int cur0 = c->cur, phase0 = c->phase;
+        // Capture is an optimisation: whatever goes wrong in it (begin, a launch during capture, end, instantiate), the
+        // state is put back as it was, the error is cleared, the context stops trying and the batch runs eagerly.
+        const int cur0 = c->cur, phase0 = c->phase, force0 = c->force;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
-        if (e != hipSuccess) return e;
-        for (unsigned i = 0; i < count && e == hipSuccess; i++) e = enqueue_sweep(c, false, first + i);
-        hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
+        if (e == hipSuccess) {
+            for (unsigned i = 0; i < count && e == hipSuccess; i++) e = enqueue_sweep(c, false, first + i);
+            hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
+            if (e == hipSuccess) e = e2;
+        }
         c->cur = cur0;  // nothing has run yet
         c->phase = phase0;
-        if (e == hipSuccess) e = e2;
+        c->force = force0;
         if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         if (graph) (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) return e;
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            c->graphs_broken = true;
+            return enqueue_plain_run(c, count, first);
+        }
         if (c->graphs.size() >= 16) drop_graphs(c);
         it = c->graphs.emplace(key, exec).first;
     }
     hipError_t e = hipGraphLaunch(it->second, c->stream);
-    if (e == hipSuccess && !c->redblack && (count & 1u)) c->cur ^= 1;
-    if (e == hipSuccess && c->track) c->phase = (int)((c->phase + count) % 6);
-    return e;
+    if (e != hipSuccess) {  // nothing was enqueued: run the batch eagerly instead, and stop replaying
+        (void)hipGetLastError();
+        c->graphs_broken = true;
+        return enqueue_plain_run(c, count, first);
+    }
+    if (!c->redblack && (count & 1u)) c->cur ^= 1;
+    if (c->track) c->phase = (int)((c->phase + count) % 6);
+    return hipSuccess;
 }
 
 int multi_read_delta(Harmonic *h, Ctx *c, const char *fn);
