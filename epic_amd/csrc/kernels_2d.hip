@@ -16,7 +16,8 @@
 //    of the reference's +4 B/cell, and no VALU instruction besides the select itself.
 //  * Rows are addressed through buffer descriptors with the row / strip part of the address in an SGPR: loads and
 //    stores cost no VALU instruction either.  The kernel is bound by VALU issue, so every instruction that is not
-//    arithmetic of the update was moved to the scalar unit (68 VALU instructions per cell, 41 of them f64).
+//    arithmetic of the update was moved to the scalar unit (precise math: 70 VALU instructions per cell, 41 of them f64 /
+//    conversions; tol math: 43 -- profiles/r02_sq_counters_*.txt).
 //  * max |u_new - u_old| is reduced in registers, across the wave with shuffles, and leaves the wave as a
 //    single atomicMax on the float's bit pattern (valid order for non-negative floats).  No second kernel.
 //  * blockIdx is remapped so that each XCD sweeps a contiguous band of rows: vertically adjacent tasks share
@@ -25,10 +26,11 @@
 //  * Optional activity tracking: a sweep lists the tiles its successor has to recompute and the successor runs as
 //    persistent waves over those lists (Sweep2dArgs); results do not depend on it.
 //
-// Roofline: the memory side is HBM-bound (8 B per cell, 97 us per 8192^2 sweep with trivial arithmetic).  With the
+// Roofline: the memory side is HBM-bound (8 B per cell, 94-98 us per 8192^2 sweep with trivial arithmetic).  With the
 // fast math (v_exp_f32 / v_log_f32) the kernel stays there; with the default precise math (expf / logf bit-identical to
-// glibc, evaluated in f64) it is bound by VALU issue: 41 f64 / conversion instructions per cell plus 27 others at ~4
-// cycles per wave each.
+// glibc, evaluated in f64) it is bound by VALU issue: 41 f64 / conversion instructions per cell plus 29 others at ~4
+// cycles per wave each, 138-146 us; with the tol math (one split per cell shared by its neighbours, cell_update.h) both
+// pipes are nearly full: 107-109 us = 0.62 of 8 TB/s.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
