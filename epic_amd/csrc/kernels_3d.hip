@@ -25,7 +25,11 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kStripCols = 256;
-constexpr int kWavesPerBlock = 4;  // = consecutive planes per workgroup
+#ifndef EPIC_SWEEP3D_BLOCK_WAVES
+#define EPIC_SWEEP3D_BLOCK_WAVES 4
+#endif
+constexpr int kWavesPerBlock = EPIC_SWEEP3D_BLOCK_WAVES;  // = consecutive planes per workgroup
+static_assert(kWave * kWavesPerBlock >= kWakeLists, "one thread per work list resets the counters");
 constexpr int kRowsPerTask = 32;
 
 struct Sweep3dArgs {

@@ -67,7 +67,7 @@ struct WakeCursor {
 // Reset the counter set of the launch after next.  Call from every thread of the kernel (block 0 does the work).
 __device__ __forceinline__ void wake_reset_next(const WakeArgs &w)
 {
-    if (blockIdx.x == 0) w.count_zero[threadIdx.x * kWakeStride] = 0;  // kWakeLists == block size
+    if (blockIdx.x == 0 && threadIdx.x < kWakeLists) w.count_zero[threadIdx.x * kWakeStride] = 0;  // blocks have >= kWakeLists threads
 }
 
 // List-driven launch: find this wave's first element.  false = nothing to do for this wave.
