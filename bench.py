@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--stagger", type=int, default=100, help="sweeps per step (numIterationsToStaggerCheck)")
     ap.add_argument("--rows-per-task", type=int, default=0)
     ap.add_argument("--cpu-half-sweeps", type=int, default=40, help="bounded CPU sample (about 0.35 s each at 8192^2)")
-    ap.add_argument("--math", choices=("precise", "tol", "df32", "fast", "traffic"), default="tol",
+    ap.add_argument("--math", choices=("precise", "tol", "fast", "traffic"), default="tol",
                     help="precise = libm-equivalent exp/log (bit-exact parity mode, default); tol = one exp-class split per "
                          "cell shared by its neighbours (tolerance parity mode); fast = v_exp_f32/v_log_f32")
     ap.add_argument("--scheme", choices=("jacobi", "redblack"), default="jacobi",
@@ -176,7 +176,7 @@ def main():
 
     E = eh._epic
     n = args.size
-    MODES = {"precise": 0, "fast": 1, "traffic": 2, "df32": 3, "tol": 4}
+    MODES = {"precise": 0, "fast": 1, "traffic": 2, "tol": 4}
 
     def barrier():
         if world > 1:

@@ -50,7 +50,7 @@ __device__ __forceinline__ float max2(float a, float b) { return __builtin_fmaxf
 constexpr int kMathPrecise = 0;
 constexpr int kMathFast = 1;
 constexpr int kMathTraffic = 2;  // diagnostic: neighbours averaged with 3 adds -- same loads/stores, almost no ALU
-constexpr int kMathDf32 = 3;     // packed-f32 double-float exp/log (2-D kernel), see below
+// (3 was round 1's df32 mode: removed)
 constexpr int kMathTol = 4;      // one exp-class evaluation per cell (shared by its neighbours) + one f64 log: the tolerance mode, see below
 
 // ---- libm-equivalent expf / logf in f64 (glibc 2.35 algorithm, see header) --------------------------------
@@ -179,82 +179,16 @@ __device__ __forceinline__ double precise_ln_d(float sf, const MathTab &tab)  //
 }
 __device__ __forceinline__ float precise_ln(float sf, const MathTab &tab) { return (float)precise_ln_d(sf, tab); }
 
-// ---- kMathDf32: nearly-correctly-rounded exp/log in f32 "double-float" arithmetic, two cells per instruction ------
-// On gfx950 an f64 op, a conversion and a v_fma_f32 all issue at ~4.3 cycles per wave, but v_pk_fma_f32 /
-// v_pk_mul_f32 / v_pk_add_f32 do two lanes' worth in that time (profiles/r01_ubench_alu.txt).  This variant keeps the
-// reference's rounding sequence (f32 terms, f32 left-associated sum, f32 mx + ln s, f64 subtraction of ln 2n) but
-// evaluates e() and ln() with packed f32 only:
-//   e^d : n = round(d 32/ln2) by the 1.5*2^23 trick, r = d - n ln2/32 (two-term Cody-Waite), e^r - 1 by a quartic,
-//         2^(j/32) as Th + Tl from a 32-entry table, result = ldexp(Th + fma(Th, p, Tl), n >> 5)   -> <= 0.53 ulp
-//   ln s: s = 2^k z, z in [OFF, 2 OFF) cut into 32 sub-intervals with centre c; r = fma(z, 1/c, -1), log1p(r) by a
-//         quartic, ln c + k ln2 as Hi + Lo from a 128-entry table, result = Hi + (r + fma(r^2, q, Lo))  -> <= 0.51 ulp
-// Both are unbiased (mean error 1e-4 ulp) and agree with glibc's expf/logf on 99.8 % / 98.8 % of arguments, 1 ulp off
-// otherwise (tools/df32_study.c, which also relaxes the reference maps with exactly this arithmetic on the CPU).
+// ---- packed f32 (v_pk_fma_f32 / v_pk_add_f32: two lanes' worth per instruction at the issue cost of one f64 op) --------
 typedef float v2f __attribute__((ext_vector_type(2)));
-
-#include "df32_tables.inc"  // kDfExpTab, kDfLogTab, kDfL1, kDfL2 (generated by tools/gen_df32_tables.py)
-
-constexpr int kDfLdsFloats = 64 + 512;  // {Th, Tl} x 32, then {1/c, Hi, Lo, 0} x 128
-
-// Stage the df32 tables into LDS; call from every thread of the workgroup, then __syncthreads().
-__device__ __forceinline__ void df_tables_to_lds(float *lds)
-{
-    for (int t = threadIdx.x; t < kDfLdsFloats; t += blockDim.x) lds[t] = t < 64 ? kDfExpTab[t] : kDfLogTab[t - 64];
-}
-
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 // by-value helpers: __builtin_bit_cast applied directly to a vector ELEMENT expression (v.y) reads element 0
 __device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 __device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ v2f splat(float x) { return v2f{x, x}; }
-
-__device__ __forceinline__ v2f df_exp2(v2f d, const float *lds)
-{
-    d.x = max2(d.x, -104.0f);  // keeps n inside the 23-bit trick; e^-104 is 0 against a sum >= 1
-    d.y = max2(d.y, -104.0f);
-    const v2f magic = splat(12582912.0f);  // 1.5 * 2^23: the integer n = round(d c) appears in the low mantissa bits
-    const v2f zm = pk_fma(d, splat(46.16624130844683f), magic);
-    const v2f nf = zm - magic;
-    v2f r = pk_fma(nf, splat(-kDfL1), d);
-    r = pk_fma(nf, splat(-kDfL2), r);
-    v2f q = pk_fma(r, splat(1.0f / 24.0f), splat(1.0f / 6.0f));
-    q = pk_fma(r, q, splat(0.5f));
-    const v2f p = pk_fma(r * r, q, r);  // e^r - 1
-    const uint32_t b0 = f2u(zm.x), b1 = f2u(zm.y);
-    const float2 t0 = *reinterpret_cast<const float2 *>(lds + 2 * (b0 & 31u));
-    const float2 t1 = *reinterpret_cast<const float2 *>(lds + 2 * (b1 & 31u));
-    const v2f th = {t0.x, t1.x}, tl = {t0.y, t1.y};
-    const v2f y = th + pk_fma(th, p, tl);
-    // n >> 5 sits in mantissa bits 5..21 (two's complement inside the field, the 0x400000 of 1.5 is bit 22)
-    const int k0 = __builtin_amdgcn_sbfe(b0, 5, 17), k1 = __builtin_amdgcn_sbfe(b1, 5, 17);
-    return v2f{__builtin_ldexpf(y.x, k0), __builtin_ldexpf(y.y, k1)};
-}
-
-__device__ __forceinline__ v2f df_ln2(v2f s, const float *lds)
-{
-    const uint32_t i0 = f2u(s.x), i1 = f2u(s.y);
-    const uint32_t m0 = i0 - 0x3f330000u, m1 = i1 - 0x3f330000u;
-    const float4 e0 = *reinterpret_cast<const float4 *>(lds + 64 + 4 * (m0 >> 18));  // entry 32 k + i
-    const float4 e1 = *reinterpret_cast<const float4 *>(lds + 64 + 4 * (m1 >> 18));
-    const v2f z = {u2f(i0 - (m0 & 0xff800000u)), u2f(i1 - (m1 & 0xff800000u))};
-    const v2f r = pk_fma(z, v2f{e0.x, e1.x}, splat(-1.0f));
-    v2f q = pk_fma(r, splat(-0.25f), splat(1.0f / 3.0f));
-    q = pk_fma(r, q, splat(-0.5f));
-    v2f t = pk_fma(r * r, q, v2f{e0.z, e1.z});
-    t = t + r;
-    return v2f{e0.y, e1.y} + t;
-}
-
-// Two horizontally adjacent cells at once (components .x / .y); same sequence per component as cell_update_2d.
-__device__ __forceinline__ v2f df_pair_update_2d(v2f up, v2f dn, v2f lf, v2f rt, const float *lds)
-{
-    const v2f mx = {max2(max2(max2(up.x, dn.x), lf.x), rt.x), max2(max2(max2(up.y, dn.y), lf.y), rt.y)};
-    v2f s = df_exp2(up - mx, lds) + df_exp2(dn - mx, lds);
-    s = s + df_exp2(lf - mx, lds);
-    s = s + df_exp2(rt - mx, lds);
-    const v2f t = mx + df_ln2(s, lds);
-    return v2f{(float)((double)t.x - kLn4), (float)((double)t.y - kLn4)};
-}
+// (Round 1's `df32` mode -- packed double-float exp / log per neighbour, <= 0.53 ulp, 99.8 % agreement with libm -- lived
+// here; it was no faster than the reworked precise kernel, could not stop by the reference's test under Jacobi on umass,
+// and is superseded by the tol mode below.  Removed in round 2; DESIGN.md section 2 keeps what was learned from it.)
 
 // ---- kMathTol: one exp-class evaluation and one log per CELL instead of per NEIGHBOUR -------------------------------
 // The reference evaluates u' = mx + ln(sum_i e^(u_i - mx)) - ln 2n with 2n expf and one logf per cell
@@ -274,7 +208,7 @@ __device__ __forceinline__ v2f df_pair_update_2d(v2f up, v2f dn, v2f lf, v2f rt,
 // relative either way, zero mean).  The terms are never formed by subtracting the maximum first, so Jacobi's two
 // interleaved chains see the same term for the same neighbour value; on the reference's maps Jacobi, red-black and any
 // tiling end in ONE fixed point with max |du| = 0 exactly, which is what lets the reference's absolute termination test
-// fire under Jacobi (df32 above ends in two fixed points one ulp apart on umass).
+// fire under Jacobi (round 1's per-neighbour double-float mode ended in two fixed points one ulp apart on umass).
 // tools/tol_study.c is the same arithmetic on the CPU, operation for operation, and relaxes the reference's maps with
 // it; oracle/harmonic_oracle.c holds the checker's copy (oracle_tol_*), against which the kernels are bit-identical.
 // n is carried as the BIT PATTERN of zm = u log2 e + 1.5 * 2^23 (an integer-valued float whose low mantissa bits are n

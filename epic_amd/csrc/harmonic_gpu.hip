@@ -47,7 +47,7 @@ struct Ctx {
     float *h_delta = nullptr;      // pinned
     hipStream_t stream = nullptr;
     int rows_per_task = 0;         // 0 = automatic
-    int math = 0;                  // 0 = precise (default), 1 = fast, 2 = traffic, 3 = df32, 4 = tol; EPIC_HIP_MATH / epic_hip_set_math_mode
+    int math = 0;                  // 0 = precise (default), 1 = fast, 2 = traffic, 4 = tol; EPIC_HIP_MATH / epic_hip_set_math_mode
     // Launch-bound grids replay the plain sweeps between two checks from a captured hipGraph; key = (count, starting
     // buffer, starting parity, math, scheme, rows_per_task) -- everything a captured launch sequence depends on.
     std::map<std::tuple<unsigned, int, int, int, int, int>, hipGraphExec_t> graphs;
@@ -189,7 +189,6 @@ Ctx *get_ctx(Harmonic *h, bool create)
     if (e) c->rows_per_task = atoi(e);
     e = getenv("EPIC_HIP_MATH");
     if (e && strcmp(e, "fast") == 0) c->math = 1;
-    if (e && strcmp(e, "df32") == 0) c->math = 3;
     if (e && strcmp(e, "tol") == 0) c->math = 4;
     e = getenv("EPIC_HIP_SCHEME");
     if (e && strcmp(e, "redblack") == 0) c->redblack = true;
@@ -369,7 +368,7 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
 {
     static const bool no_fuse = getenv("EPIC_HIP_NO_FUSE") != nullptr;
     // (the fused pass has its own 248-column tiling and no work lists: it is used when tracking is off)
-    // (and the precise / fast / df32 arithmetic only: the tol math runs the in-place half-sweeps)
+    // (and the precise / fast arithmetic only: the tol math runs the in-place half-sweeps)
     const bool fuse = c->redblack && c->n == 2 && !no_fuse && !c->track && !c->multi() && c->math != 4 && (long long)c->rows * c->pitch >= (1ll << 22);
     unsigned i = 0;
     while (fuse && count - i >= 2) {
@@ -1458,7 +1457,7 @@ int epic_hip_set_rows_per_task(Harmonic *harmonic, unsigned int rows_per_task)
 int epic_hip_set_math_mode(Harmonic *harmonic, int mode)
 {
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
-    if (!c || mode < 0 || mode > 4) return EPIC_ERROR_INVALID_DATA;  // 2 = traffic-only diagnostic, 3 = df32 (2-D), 4 = tol
+    if (!c || mode < 0 || mode > 4 || mode == 3) return EPIC_ERROR_INVALID_DATA;  // 2 = traffic-only diagnostic (2-D), 4 = tol; 3 was round 1's df32
     c->math = mode;
     c->force = 2;
     return EPIC_SUCCESS;
@@ -1669,7 +1668,7 @@ int epic_hip_sweep_2d(const float *d_in, float *d_out, const uint32_t *d_maskw, 
         row_begin > row_end)
         return EPIC_ERROR_INVALID_DATA;
     if (rows_per_task == 0) rows_per_task = 32;
-    if (math_mode < 0 || math_mode > 4) return EPIC_ERROR_INVALID_DATA;
+    if (math_mode < 0 || math_mode > 4 || math_mode == 3) return EPIC_ERROR_INVALID_DATA;
     return epic_hip::launch_sweep_2d(d_in, d_out, d_maskw, (int)rows, (int)pitch, (int)row_begin, (int)row_end,
                                      (int)rows_per_task, math_mode, -1, d_delta_bits, (hipStream_t)stream) == hipSuccess
                ? EPIC_SUCCESS
@@ -1684,7 +1683,7 @@ int epic_hip_sweep_rb_2d(float *d_u, const uint32_t *d_maskw, unsigned int rows,
         (parity != 0 && parity != 1))
         return EPIC_ERROR_INVALID_DATA;
     if (rows_per_task == 0) rows_per_task = 32;
-    if (math_mode < 0 || math_mode > 4) return EPIC_ERROR_INVALID_DATA;
+    if (math_mode < 0 || math_mode > 4 || math_mode == 3) return EPIC_ERROR_INVALID_DATA;
     return epic_hip::launch_sweep_2d(d_u, d_u, d_maskw, (int)rows, (int)pitch, (int)row_begin, (int)row_end,
                                      (int)rows_per_task, math_mode, parity, d_delta_bits, (hipStream_t)stream) == hipSuccess
                ? EPIC_SUCCESS

@@ -101,11 +101,6 @@ template <bool CHECK, int MATH, bool RB, bool TRACK> struct SweepOcc {
 template <bool CHECK, int MATH, bool RB, bool TRACK>
 __global__ __launch_bounds__(kWave * kWavesPerBlock, (SweepOcc<CHECK, MATH, RB, TRACK>::kMinWaves)) EPIC_SWEEP_OCC void sweep2d_kernel(Sweep2dArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float ldsf[kDfLdsFloats];  // df32 tables (df32 math only)
-    if (MATH == kMathDf32) {
-        df_tables_to_lds(ldsf);
-        __syncthreads();
-    }
     __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];  // glibc's expf / logf tables (precise math only)
     // libm tables in LDS (precise math only): fetched here, written to LDS only after the first task's row loads are
     // under way, so that the fetch from constant memory hides behind them (the small ROS maps run one row per wave:
@@ -206,32 +201,16 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (SweepOcc<CHECK, MATH, RB, 
         } else if (RB) {
             o = c;
             if (((r + a.parity) & 1) == 0) {  // scalar: this row's active cells sit in the odd columns (.y, .w)
-                float ny, nw;
-                if (MATH == kMathDf32) {
-                    const v2f n = df_pair_update_2d(v2f{up.y, up.w}, v2f{dn.y, dn.w}, v2f{c.x, c.z}, v2f{c.z, rt}, ldsf);
-                    ny = n.x; nw = n.y;
-                } else {
-                    ny = cell_update_2d<MATH>(up.y, dn.y, c.x, c.z, lds);
-                    nw = cell_update_2d<MATH>(up.w, dn.w, c.z, rt, lds);
-                }
+                const float ny = cell_update_2d<MATH>(up.y, dn.y, c.x, c.z, lds);
+                const float nw = cell_update_2d<MATH>(up.w, dn.w, c.z, rt, lds);
                 o.y = sel(h.m1, c.y, ny);
                 o.w = sel(h.m3, c.w, nw);
             } else {                           // even columns (.x, .z)
-                float nx, nz;
-                if (MATH == kMathDf32) {
-                    const v2f n = df_pair_update_2d(v2f{up.x, up.z}, v2f{dn.x, dn.z}, v2f{lf, c.y}, v2f{c.y, c.w}, ldsf);
-                    nx = n.x; nz = n.y;
-                } else {
-                    nx = cell_update_2d<MATH>(up.x, dn.x, lf, c.y, lds);
-                    nz = cell_update_2d<MATH>(up.z, dn.z, c.y, c.w, lds);
-                }
+                const float nx = cell_update_2d<MATH>(up.x, dn.x, lf, c.y, lds);
+                const float nz = cell_update_2d<MATH>(up.z, dn.z, c.y, c.w, lds);
                 o.x = sel(h.m0, c.x, nx);
                 o.z = sel(h.m2, c.z, nz);
             }
-        } else if (MATH == kMathDf32) {  // two cells per packed instruction
-            const v2f a = df_pair_update_2d(v2f{up.x, up.y}, v2f{dn.x, dn.y}, v2f{lf, c.x}, v2f{c.y, c.z}, ldsf);
-            const v2f b = df_pair_update_2d(v2f{up.z, up.w}, v2f{dn.z, dn.w}, v2f{c.y, c.z}, v2f{c.w, rt}, ldsf);
-            o = make_float4(a.x, a.y, b.x, b.y);
         } else {
             o.x = cell_update_2d<MATH>(up.x, dn.x, lf, c.y, lds);
             o.y = cell_update_2d<MATH>(up.y, dn.y, c.x, c.z, lds);
@@ -378,14 +357,9 @@ constexpr int kFusedOut = 248;  // owned columns per wave
 template <int MATH>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Sweep2dArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float ldsf[kDfLdsFloats];
     __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];
     MathTab lds = {};
     if (MATH == kMathPrecise) lds = math_tables_load(math_lds);
-    if (MATH == kMathDf32) {
-        df_tables_to_lds(ldsf);
-        __syncthreads();
-    }
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int task = xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
@@ -437,26 +411,14 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
         const bool odd_cols = ((((r + it) & 1) == 0) != second);  // scalar
         if (odd_cols) {
             const float rt = wave_from_right(c.x, 0.0f);
-            float ny, nw;
-            if (MATH == kMathDf32) {
-                const v2f n = df_pair_update_2d(v2f{up.y, up.w}, v2f{dn.y, dn.w}, v2f{c.x, c.z}, v2f{c.z, rt}, ldsf);
-                ny = n.x; nw = n.y;
-            } else {
-                ny = cell_update_2d<MATH>(up.y, dn.y, c.x, c.z, lds);
-                nw = cell_update_2d<MATH>(up.w, dn.w, c.z, rt, lds);
-            }
+            const float ny = cell_update_2d<MATH>(up.y, dn.y, c.x, c.z, lds);
+            const float nw = cell_update_2d<MATH>(up.w, dn.w, c.z, rt, lds);
             o.y = sel(k.m1, c.y, ny);
             o.w = sel(k.m3, c.w, nw);
         } else {
             const float lf = wave_from_left(c.w, 0.0f);
-            float nx, nz;
-            if (MATH == kMathDf32) {
-                const v2f n = df_pair_update_2d(v2f{up.x, up.z}, v2f{dn.x, dn.z}, v2f{lf, c.y}, v2f{c.y, c.w}, ldsf);
-                nx = n.x; nz = n.y;
-            } else {
-                nx = cell_update_2d<MATH>(up.x, dn.x, lf, c.y, lds);
-                nz = cell_update_2d<MATH>(up.z, dn.z, c.y, c.w, lds);
-            }
+            const float nx = cell_update_2d<MATH>(up.x, dn.x, lf, c.y, lds);
+            const float nz = cell_update_2d<MATH>(up.z, dn.z, c.y, c.w, lds);
             o.x = sel(k.m0, c.x, nx);
             o.z = sel(k.m2, c.z, nz);
         }
@@ -553,11 +515,8 @@ __global__ void set_cells_2d_kernel(float *u, uint32_t *maskw, int rows, int col
 // libm-replica check: out[i] = which ? ln(in[i]) : exp(in[i]) with the PRECISE device routines (test hook).
 __global__ void eval_math_kernel(const float *in, float *out, size_t n, int which)
 {
-    __shared__ __attribute__((aligned(16))) float ldsf[kDfLdsFloats];
     __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];
     const MathTab lds = math_tables_load(math_lds);
-    df_tables_to_lds(ldsf);
-    __syncthreads();
     // all 64 lanes stay active (as in the sweeps, whose update assumes it), so the loop count is wave-uniform and
     // out-of-range lanes work on a clamped index and skip the store
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -566,13 +525,7 @@ __global__ void eval_math_kernel(const float *in, float *out, size_t n, int whic
     for (size_t t = 0; t < trips; t++) {
         const size_t i = first + t * stride;
         const float x = in[i < n ? i : n - 1];
-        float r;
-        if (which == 0) r = precise_exp(x, lds);
-        else if (which == 1) r = precise_ln(x, lds);
-        else if (which == 2) r = df_exp2(v2f{x, -0.25f}, ldsf).x;   // df32 pair routines, first component
-        else if (which == 3) r = df_ln2(v2f{x, 2.5f}, ldsf).x;
-        else if (which == 4) r = df_exp2(v2f{0.0f, x}, ldsf).y;         // second component, first one at the other extreme
-        else r = df_ln2(v2f{4.0f, x}, ldsf).y;
+        const float r = which == 0 ? precise_exp(x, lds) : precise_ln(x, lds);
         if (i < n) out[i] = r;
     }
 }
@@ -605,7 +558,6 @@ void launch_sweep_2d_math(int math, int nblocks, hipStream_t stream, const Sweep
     const dim3 grid(nblocks), block(kWave * kWavesPerBlock);
     if (math == kMathFast) hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathFast, RB, TRACK>), grid, block, 0, stream, a);
     else if (math == kMathTraffic) hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathTraffic, RB, TRACK>), grid, block, 0, stream, a);
-    else if (math == kMathDf32) hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathDf32, RB, TRACK>), grid, block, 0, stream, a);
     else if (math == kMathTol) hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathTol, RB, TRACK>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathPrecise, RB, TRACK>), grid, block, 0, stream, a);
 }
@@ -626,6 +578,7 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, i
     if (pitch <= 0 || (pitch % 256) != 0 || rows <= 0 || row_begin < 0 || row_end > rows || rows_per_task <= 0)
         return hipErrorInvalidValue;
     if ((parity >= 0) != (in == out)) return hipErrorInvalidValue;
+    if (math != kMathPrecise && math != kMathFast && math != kMathTraffic && math != kMathTol) return hipErrorInvalidValue;
     // the kernel addresses a task's rows with 32-bit byte offsets from a base 8 rows above it (rows_per_task + 14 rows)
     const long long max_rows = 0x7fffffffLL / ((long long)pitch * 4) - 16;
     if (max_rows < 1) return hipErrorInvalidValue;
@@ -665,6 +618,7 @@ hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw
                               int math, int parity, hipStream_t stream)
 {
     if (pitch <= 0 || (pitch % 256) != 0 || rows <= 0 || rows_per_task <= 0 || in == out) return hipErrorInvalidValue;
+    if (math != kMathPrecise && math != kMathFast && math != kMathTraffic) return hipErrorInvalidValue;  // (tol: in-place half-sweeps)
     Sweep2dArgs a;
     a.in = in;
     a.out = out;
@@ -684,7 +638,6 @@ hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw
     const dim3 grid((a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
     if (math == kMathFast) hipLaunchKernelGGL((rb_fused2d_kernel<kMathFast>), grid, block, 0, stream, a);
     else if (math == kMathTraffic) hipLaunchKernelGGL((rb_fused2d_kernel<kMathTraffic>), grid, block, 0, stream, a);
-    else if (math == kMathDf32) hipLaunchKernelGGL((rb_fused2d_kernel<kMathDf32>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((rb_fused2d_kernel<kMathPrecise>), grid, block, 0, stream, a);
     return hipGetLastError();
 }

@@ -163,7 +163,6 @@ EPIC_ERROR_INVALID_CUDA_PARAM = 3
 EPIC_ERROR_DEVICE_MALLOC = 4
 MATH_PRECISE = 0
 MATH_FAST = 1
-MATH_DF32 = 3
 MATH_TOL = 4
 SCHEME_JACOBI = 0
 SCHEME_REDBLACK = 1

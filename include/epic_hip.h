@@ -45,18 +45,16 @@ int epic_hip_timed_sweeps_gpu(EpicHarmonicT *harmonic, unsigned int sweeps, unsi
 /* Tuning knob: rows marched by one wave in the 2-D kernel (0 = automatic).  Also EPIC_HIP_ROWS_PER_TASK. */
 int epic_hip_set_rows_per_task(EpicHarmonicT *harmonic, unsigned int rows_per_task);
 
-/* Arithmetic of the sweep kernels (also EPIC_HIP_MATH=precise|tol|df32|fast in the environment at initialisation):
+/* Arithmetic of the sweep kernels (also EPIC_HIP_MATH=precise|tol|fast in the environment at initialisation):
  *   0 precise (default)  exp/log bit-identical to the host libm's expf/logf, evaluated in f64 -- the bit-exact parity mode;
  *   4 tol                one exp-class split e^u = q 2^n per CELL (packed f32 polynomial), shared by the cells it is a
  *                        neighbour of, one f64 log per cell; every rounding stage of the reference kept.  2-D and 3-D,
  *                        Jacobi and red-black.  Jacobi stops by the reference's own test; converged fields within
  *                        1e-5 max(1, |u|) of the reference's on its seeded grids, basic.png and maze.png, 1.6e-5 on the
  *                        ill-conditioned umass.png.  ~1.3x faster per sweep than precise (the benchmarked mode);
- *   3 df32               packed-f32 double-float exp/log, <= 0.53 ulp, unbiased; ~1.3x faster; fixed sweep counts agree
- *                        with precise to a few ulp, but the reference's absolute max|du| < eps test may never fire on
- *                        ill-conditioned maps (the two checkerboard sub-sequences of Jacobi settle one ulp apart);
  *   1 fast               v_exp_f32 / v_log_f32: biased, ~1e-4 relative drift on ill-conditioned maps; no parity claim;
- *   2 traffic            diagnostic: same loads/stores, trivial arithmetic (2-D only). */
+ *   2 traffic            diagnostic: same loads/stores, trivial arithmetic (2-D only).
+ * (3 was round 1's df32 mode, removed: EPIC_ERROR_INVALID_DATA.) */
 int epic_hip_set_math_mode(EpicHarmonicT *harmonic, int mode);
 
 /* Iteration scheme of the 2-D solver: 0 = Jacobi ping-pong (default: one iteration recomputes every unlocked cell),
@@ -98,7 +96,7 @@ int epic_hip_activity_stats(EpicHarmonicT *harmonic, unsigned long long *active_
 int epic_hip_activity_stats2(EpicHarmonicT *harmonic, unsigned long long *active_tiles, unsigned long long *due_tiles,
                              unsigned long long *tiles);
 
-/* Test hook: d_out[i] = which ? ln(d_in[i]) : exp(d_in[i]) with the precise device routines. */
+/* Test hook: d_out[i] = which ? ln(d_in[i]) : exp(d_in[i]) with the precise device routines (which = 0 / 1). */
 int epic_hip_eval_math(const float *d_in, float *d_out, size_t n, int which, void *stream);
 
 /* ---- several GPUs behind the unchanged ABI ------------------------------------------------------------------------

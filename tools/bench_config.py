@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--grid", type=int, nargs="+", required=True)
     ap.add_argument("--sweeps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--math", choices=("precise", "tol", "df32", "fast", "traffic"), default="precise")
+    ap.add_argument("--math", choices=("precise", "tol", "fast", "traffic"), default="precise")
     ap.add_argument("--scheme", choices=("jacobi", "redblack"), default="jacobi")
     ap.add_argument("--develop", type=int, default=0, help="untimed sweeps first, so that the timed ones run on a developed field (the constant initial field flatters a VALU-bound kernel)")
     ap.add_argument("--rows-per-task", type=int, default=0)
@@ -46,7 +46,7 @@ def main():
         assert fn(h) == 0, fn.__name__
     up_s = time.perf_counter() - t0
     assert E.harmonic_initialize_gpu(h, 1024) == 0
-    assert E.epic_hip_set_math_mode(h, {"precise": 0, "fast": 1, "traffic": 2, "df32": 3, "tol": 4}[args.math]) == 0
+    assert E.epic_hip_set_math_mode(h, {"precise": 0, "fast": 1, "traffic": 2, "tol": 4}[args.math]) == 0
     if args.rows_per_task:
         E.epic_hip_set_rows_per_task(h, args.rows_per_task)
     ms = ct.c_float(0)

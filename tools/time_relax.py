@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time harmonic_execute_gpu on the synthetic N x N grid: tools/time_relax.py [--size 8192] [--scheme jacobi|redblack]
-[--track 0|1] [--rows-per-task R] [--math precise|df32].  Prints one JSON line (seconds, iterations, final active-tile
+[--track 0|1] [--rows-per-task R] [--math precise|tol].  Prints one JSON line (seconds, iterations, final active-tile
 share).  Tuning experiments: EPIC_HIP_LIST_WAVES is read from the environment by the library."""
 import argparse
 import ctypes as ct
@@ -36,7 +36,7 @@ for fn in (E.harmonic_initialize_dimension_size_gpu, E.harmonic_initialize_poten
     assert fn(h) == 0
 assert E.harmonic_initialize_gpu(h, 1024) == 0
 assert E.epic_hip_set_scheme(h, 1 if a.scheme == "redblack" else 0) == 0
-assert E.epic_hip_set_math_mode(h, {"precise": 0, "fast": 1, "df32": 3}[a.math]) == 0
+assert E.epic_hip_set_math_mode(h, {"precise": 0, "fast": 1, "tol": 4}[a.math]) == 0
 assert E.epic_hip_set_activity_tracking(h, a.track) == 0
 if a.rows_per_task:
     assert E.epic_hip_set_rows_per_task(h, a.rows_per_task) == 0
