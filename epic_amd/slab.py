@@ -73,7 +73,7 @@ class HipBackend:
         self.E = eh._epic
         if self.E.epic_hip_device_count() < 1:
             raise RuntimeError("epic_amd.slab: no HIP device -- the slab solver has no CPU path")
-        self.rows_per_task = int(rows_per_task) or 16
+        self.rows_per_task = int(rows_per_task) or (10 if math == "tol" else 16)   # the tol kernel's row loop runs in trips of 10
         modes = {"precise": 0, "fast": 1, "traffic": 2, "tol": 4}
         if math not in modes:
             raise ValueError("epic_amd.slab: unknown math mode %r (one of %s)" % (math, ", ".join(sorted(modes))))
