@@ -253,7 +253,12 @@ int auto_rows_per_task(const Ctx *c)
     // Small grids (the ROS maps are 0.1-1 Mcell) cannot fill the chip at all: there one row per wave is best
     // (310 x 940: 4.3 us per sweep at 1 row per task vs 11.4 us at 8, both measured).
     long long r = (long long)c->rows * nstrips / 32768;
-    if (c->math == 4 && r >= 8) return (int)std::min<long long>(60, std::max<long long>(10, (r + 2) / 10 * 10));  // tol: the row loop runs in trips of 10 (kernels_2d.hip)
+    // tol: the row loop runs in trips of 10 rows (kernels_2d.hip), anything else goes through its slower ragged loop.  One
+    // trip per task wherever that still gives every wave slot of the chip a task (256 CUs x 24 waves); measured, us per
+    // sweep at 1 / 2 / 4 / 8 / 10 / 20 rows per task (profiles/r02_rows_per_task_tol.txt): 4096^2 45 / 39 / 34 / 36 / 31 / 33,
+    // 6144 x 8192 112 / 98 / 92 / 90 / 77 / 77, 8192^2 147 / 128 / 122 / 117 / 99 / 110 (30, 40, 60: slower still);
+    // 2048^2 and below keep the rule for small grids (10.8 / 10.7 / 10.5 / 12.7 / 11.1 / 14.7 at 2048^2).
+    if (c->math == 4 && (long long)c->rows / 10 * nstrips >= 6144) return 10;
     if (r >= 8) r = r / 8 * 8;
     else if (r >= 4) r = 4;
     else if (r >= 2) r = 2;
@@ -1234,6 +1239,22 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
     // The reference's loop (harmonic_gpu.cu:266-290): a sweep with currentIteration % stagger == 0 is a check
     // sweep; a plain sweep resets "converged"; exit right after a converged check with currentIteration >= mMax.
     // The plain sweeps between two checks need no host decision, so they are enqueued back to back.
+    //
+    // Jacobi handover.  A Jacobi iteration is two interleaved red-black chains: the cells of one colour at even iterations
+    // and of the other colour at odd ones never meet the rest.  In f32 the two chains may stagnate one unit in the last
+    // place apart; every cell then flips between them for ever and max |du| never falls below eps, where the reference's
+    // red-black iteration from the same state stops (first seen on the nav_core plugin's SECOND makePlan, whose start is
+    // the first goal's converged field: tests/test_gpu_plugin_replay.py).  This loop's contract is "until the test fires",
+    // so at the first check with delta < 1 that is not below the previous check's delta it continues with the reference's
+    // in-place half-sweeps (what EPIC_HIP_SCHEME=redblack runs from the start), which end as the reference ends.  delta < 1
+    // keeps the rule away from the phase in which the front still moves (delta ~1e6 for many checks in a row); a handover
+    // that comes early costs time, never correctness.  oracle_jacobi_complete / oracle_tol_complete state the same rule.
+    struct Handover {
+        Ctx *c;
+        bool done = false;
+        float last_check = -1.0f;  // no check yet
+        ~Handover() { if (done) { c->redblack = false; c->force = 2; } }
+    } handover{c};   // (the context outlives this function: it still holds the field and the mask)
     const unsigned stagger = harmonic->numIterationsToStaggerCheck;
     result = EPIC_SUCCESS;
     while (result != EPIC_SUCCESS_AND_CONVERGED || harmonic->currentIteration < mMax) {
@@ -1243,6 +1264,13 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
                 report(fn, "Failed to perform the Jacobi update and check step.");
                 return result;
             }
+            if (!c->redblack && result == EPIC_SUCCESS && harmonic->delta < 1.0f && handover.last_check >= 0.0f &&
+                harmonic->delta >= handover.last_check) {
+                c->redblack = true;
+                c->force = 2;
+                handover.done = true;
+            }
+            handover.last_check = harmonic->delta;
         } else {
             // every plain iteration returns SUCCESS (which clears a previous CONVERGED), so the ones up to the next
             // check need no host decision in between: enqueue them as one batch

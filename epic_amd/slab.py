@@ -362,14 +362,27 @@ class SlabSolver:
         return e0.elapsed_time(e1)
 
     def solve(self, max_sweeps=None):
-        """Relax until a check sweep finds delta < epsilon with iteration >= max(grid) (the reference's exit rule)."""
+        """Relax until a check sweep finds delta < epsilon with iteration >= max(grid) (the reference's exit rule).
+        Jacobi hands over to the reference's red-black half-sweeps at the first check with delta < 1 that is not below the
+        previous check's delta, exactly as harmonic_execute_gpu does (epic_amd/csrc/harmonic_gpu.hip, "Jacobi handover":
+        Jacobi's two colour chains can stagnate one ulp apart and never meet the absolute test).  delta is the all-reduced
+        value, so every rank takes the decision at the same iteration."""
         self.iteration = 0
         floor = max(self.grid)
         result = False
-        while not result or self.iteration < floor:
-            check = self.iteration % self.stagger == 0
-            self.sweep(check)
-            result = (self.reduce_delta() < self.epsilon) if check else False
-            if max_sweeps is not None and self.iteration >= max_sweeps:
-                break
+        last_check, handed_over = -1.0, False
+        try:
+            while not result or self.iteration < floor:
+                check = self.iteration % self.stagger == 0
+                self.sweep(check)
+                result = (self.reduce_delta() < self.epsilon) if check else False
+                if check:
+                    if not self.redblack and not result and self.delta < 1.0 and 0.0 <= last_check <= self.delta:
+                        self.redblack = handed_over = True
+                    last_check = self.delta
+                if max_sweeps is not None and self.iteration >= max_sweeps:
+                    break
+        finally:
+            if handed_over:
+                self.redblack = False
         return self.iteration

@@ -260,7 +260,16 @@ int oracle_jacobi_run(OracleHarmonic *h, unsigned int sweeps)
 }
 
 /* Jacobi driven by the reference's loop rule (harmonic_cpu.cpp:158-173): delta is
- * looked at only on sweeps with currentIteration % stagger == 0 (before the increment). */
+ * looked at only on sweeps with currentIteration % stagger == 0 (before the increment).
+ *
+ * Handover (the library's harmonic_execute_gpu does the same, epic_amd/csrc/harmonic_gpu.hip): a Jacobi iteration is two
+ * interleaved red-black chains (the cells of one colour at even iterations and of the other at odd ones never meet the
+ * rest), and in f32 the two may stagnate a unit in the last place apart -- then every cell flips between them for ever
+ * and max |du| never falls below eps (first seen on the nav_core plugin's second makePlan, tests/test_gpu_plugin_replay.py).
+ * So: at the first check with delta < 1 that is not below the previous check's delta, the iteration continues as the
+ * reference's red-black half-sweeps in place, which stop as the reference stops.  ORACLE_JACOBI_HANDOVER_DELTA is that 1:
+ * far below the ~1e6 of a front still moving, far above any f32 flicker of a field the solver can hold. */
+#define ORACLE_JACOBI_HANDOVER_DELTA 1.0f
 int oracle_jacobi_complete(OracleHarmonic *h)
 {
     if (h == NULL || h->m == NULL || h->u == NULL || h->locked == NULL || h->epsilon <= 0.0 ||
@@ -273,19 +282,37 @@ int oracle_jacobi_complete(OracleHarmonic *h)
     if (!b) return ORACLE_ERROR_INVALID_DATA;
     h->currentIteration = 0;
     h->delta = h->epsilon + 1.0;
-    int converged = 0;
+    int converged = 0, handed_over = 0;
+    float last_check = -1.0f;   /* no check yet */
     while (!converged || h->currentIteration < mMax) {
         int check = (h->currentIteration % h->numIterationsToStaggerCheck) == 0;
+        if (handed_over) {
+            if (h->n == 2) g_updates += rb_update_2d(h, check);
+            else g_updates += rb_update_3d(h, check);
+            h->currentIteration++;
+            converged = check && h->delta < h->epsilon;
+            continue;
+        }
         float d;
         if (h->n == 2) jacobi_sweep_2d(h, a, b, &d);
         else jacobi_sweep_3d(h, a, b, &d);
         float *t = a; a = b; b = t;
         h->currentIteration++;
-        if (check) { h->delta = d; converged = d < h->epsilon; }
-        else converged = 0;
+        if (check) {
+            h->delta = d;
+            converged = d < h->epsilon;
+            if (!converged && d < ORACLE_JACOBI_HANDOVER_DELTA && last_check >= 0.0f && d >= last_check) {
+                if (a != h->u) { memcpy(h->u, a, cells * sizeof(float)); free(a); a = h->u; b = NULL; }
+                else { free(b); b = NULL; }
+                handed_over = 1;
+            }
+            last_check = d;
+        } else converged = 0;
     }
-    if (a != h->u) { memcpy(h->u, a, cells * sizeof(float)); free(a); }
-    else free(b);
+    if (!handed_over) {
+        if (a != h->u) { memcpy(h->u, a, cells * sizeof(float)); free(a); }
+        else free(b);
+    }
     return ORACLE_SUCCESS;
 }
 

@@ -146,15 +146,18 @@ static size_t tol_cells(const TolHarmonic *h)
 /* One iteration over `in`: Jacobi (colour < 0: every unlocked interior cell, in -> out, out pre-filled with in) or the
  * reference's red-black colour rule in place (in == out): 2-D (x0 + x1 + iteration) odd, 3-D (x0 + x1 + x2 + iteration)
  * even (harmonic_cpu.cpp:46-51, :89-102).  q / zb: scratch of one float / word per cell.  Returns max |du|. */
+#define TOL_OMP_MIN_CELLS ((size_t)1 << 17)
 static float tol_iterate(const TolHarmonic *h, const float *in, float *out, int colour_iteration, float *q, uint32_t *zb)
 {
     const size_t cells = tol_cells(h);
     float d = 0.0f;
-#pragma omp parallel for schedule(static)
+    /* (small grids run on one thread: on a box with many more hardware threads than this process may use, a team's
+     *  fork and barrier cost more than 12 000 cells do, and the drivers below iterate thousands of times) */
+#pragma omp parallel for schedule(static) if (cells >= TOL_OMP_MIN_CELLS)
     for (size_t i = 0; i < cells; i++) tol_split(in[i], &q[i], &zb[i]);
     if (h->n == 2) {
         const unsigned int m0 = h->m[0], m1 = h->m[1];
-#pragma omp parallel for schedule(static) reduction(max : d)
+#pragma omp parallel for schedule(static) reduction(max : d) if (cells >= TOL_OMP_MIN_CELLS)
         for (unsigned int x0 = 1; x0 < m0 - 1; x0++)
             for (unsigned int x1 = 1; x1 + 1 < m1; x1++) {
                 const size_t c = (size_t)x0 * m1 + x1;
@@ -167,7 +170,7 @@ static float tol_iterate(const TolHarmonic *h, const float *in, float *out, int 
     } else {
         const unsigned int m0 = h->m[0], m1 = h->m[1], m2 = h->m[2];
         const size_t s0 = (size_t)m1 * m2, s1 = m2;
-#pragma omp parallel for schedule(static) reduction(max : d)
+#pragma omp parallel for schedule(static) reduction(max : d) if (cells >= TOL_OMP_MIN_CELLS)
         for (unsigned int x0 = 1; x0 < m0 - 1; x0++)
             for (unsigned int x1 = 1; x1 + 1 < m1; x1++)
                 for (unsigned int x2 = 1; x2 + 1 < m2; x2++) {
@@ -209,7 +212,9 @@ int oracle_tol_run(TolHarmonic *h, unsigned int iterations, int scheme)
 }
 
 /* The reference's driver loop (harmonic_cpu.cpp:136-178) around the tol iteration: a check when
- * currentIteration % stagger == 0, exit right after a converged check with currentIteration >= max(m). */
+ * currentIteration % stagger == 0, exit right after a converged check with currentIteration >= max(m).
+ * Jacobi (scheme 0) hands over to red-black half-sweeps at the first check with delta < 1 that is not below the previous
+ * check's delta, as harmonic_execute_gpu does (why: oracle/harmonic_oracle.c, oracle_jacobi_complete). */
 int oracle_tol_complete(TolHarmonic *h, int scheme)
 {
     if (h == NULL || h->m == NULL || h->u == NULL || h->locked == NULL || h->epsilon <= 0.0f ||
@@ -225,6 +230,7 @@ int oracle_tol_complete(TolHarmonic *h, int scheme)
     h->currentIteration = 0;
     h->delta = h->epsilon + 1.0f;
     int converged = 0;
+    float last_check = -1.0f;
     while (!converged || h->currentIteration < mMax) {
         const int check = (h->currentIteration % h->numIterationsToStaggerCheck) == 0;
         float d;
@@ -236,8 +242,12 @@ int oracle_tol_complete(TolHarmonic *h, int scheme)
             d = tol_iterate(h, a, a, (int)(h->currentIteration & 1u), q, zb);
         }
         h->currentIteration++;
-        if (check) { h->delta = d; converged = d < h->epsilon; }
-        else converged = 0;
+        if (check) {
+            h->delta = d;
+            converged = d < h->epsilon;
+            if (scheme == 0 && !converged && d < 1.0f && last_check >= 0.0f && d >= last_check) scheme = 1;   /* handover */
+            last_check = d;
+        } else converged = 0;
         if (h->currentIteration > 4000000u) break;   /* a mode that does not settle must not hang the test run */
     }
     if (a != h->u) { memcpy(h->u, a, cells * sizeof(float)); free(a); }

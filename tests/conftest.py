@@ -4,6 +4,10 @@ import sys
 
 import pytest
 
+# The checkers' OpenMP teams (oracle/) default to one thread per hardware thread of the HOST; a GPU box gives this process
+# a 16-CPU share of a much larger machine, where such a team spends its time in barriers.  Set before libgomp is loaded.
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

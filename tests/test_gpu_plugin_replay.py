@@ -113,9 +113,13 @@ def test_nav_core_plugin_sequence_equals_its_cpu_fallback(replay_exe, tmp_path):
         if path[0] == 0:
             assert path[1] > 10 and np.isfinite(path[2]).all()
             assert abs(path[2][0] - starts[g][0]) < 1e-6 and abs(path[2][1] - starts[g][1]) < 1e-6
-    # the default scheme (Jacobi) through the same binary: the plugin gets a path to the same goal (exit code 9 = "not
-    # bit-identical to the CPU fallback": Jacobi's second chain is within the tolerance of the reference, not equal to it)
+    # The default scheme (Jacobi) through the same binary.  The second makePlan is the case a plain Jacobi iteration never
+    # finishes (its two chains stagnate one ulp apart: tests/test_gpu_jacobi_handover.py); harmonic_execute_gpu hands over
+    # to the reference's half-sweeps there, so both calls return.  Exit code 9 = "not bit-identical to the CPU fallback"
+    # is allowed here: the iteration counts differ by construction.
     buf, _ = run(replay_exe, "plugin", inp, outp, "jacobi", ok=(0, 9))
-    iterations, same = struct.unpack_from("<II", buf, 0)
-    (path,), _ = read_paths(buf, 1, 8)
-    assert iterations % 100 == 1 and path[0] in (0, 12)
+    off = 0
+    for g in range(2):
+        iterations, same = struct.unpack_from("<II", buf, off)
+        (path,), off = read_paths(buf, 1, off + 8)
+        assert iterations % 100 == 1 and max(m) <= iterations < 20000 and path[0] in (0, 12), (g, iterations)

@@ -219,3 +219,25 @@ def test_redblack_slab_solve_is_the_reference_result(goldens, name, world, tmp_p
     assert all(int(q["iteration"]) == info["iterations"] for q in parts)
     assert all(float(q["delta"]) == info["delta"] for q in parts)
     assert np.array_equal(field.ravel(), g[name + "/converged"])
+
+
+@pytest.mark.parametrize("world,halo", [(2, 8), (3, 3)])
+def test_jacobi_solve_hands_over_where_plain_jacobi_never_ends(world, halo, tmp_path):
+    """The nav_core plugin's second makePlan (tests/jacobi_handover_case.py): Jacobi's two colour chains stagnate one ulp
+    apart there.  The slab driver takes the same decision as harmonic_execute_gpu and the checker -- on the all-reduced
+    delta, so on every rank at the same iteration -- and ends in the checker's field after the checker's iteration count."""
+    from jacobi_handover_case import GRID, two_goal_sequence, set_goal
+    lib = O.oracle()
+    u, locked, goals = two_goal_sequence()
+    set_goal(u, locked, *goals[0])
+    first = O.Problem(GRID, u, locked)
+    assert lib.oracle_complete(ct.byref(first.h)) == 0
+    u = first.u.reshape(GRID).copy()
+    set_goal(u, locked, *goals[1])
+    problem = dict(u0=u.ravel().copy(), locked=locked.ravel().copy(), stagger=100, epsilon=1e-6)
+    field, parts = _run(world, GRID, 0, 0, "solve", tmp_path, halo, "jacobi", problem)
+    p = O.Problem(GRID, u, locked)
+    assert lib.oracle_jacobi_complete(ct.byref(p.h)) == 0
+    assert all(int(q["iteration"]) == int(p.h.currentIteration) for q in parts)
+    assert all(float(q["delta"]) == float(p.h.delta) < 1e-6 for q in parts)
+    assert np.array_equal(field.ravel(), p.u)
