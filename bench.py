@@ -244,14 +244,23 @@ def main():
                    E.harmonic_uninitialize_potential_values_gpu, E.harmonic_uninitialize_locked_gpu):
             fn(h)
 
-    def roofline(cells_per_launch, launch_us, math, scheme, single_device_full_grid):
-        achieved = BYTES_PER_CELL_SWEEP * cells_per_launch / (launch_us * 1e-6) / 1e9
-        traffic = measured_traffic(n, math, scheme) if single_device_full_grid else None
+    def roofline(cells_per_launch, launch_us, math, scheme, single_device_full_grid, per_pass=1):
+        """cells_per_launch: grid cells one launch of the dominant kernel sweeps; per_pass: iterations it advances (2 for
+        the fused passes: the algorithmic bytes of a launch are those of the iterations it performs, SURVEY.md section
+        8(d): 8 B per cell per iteration)."""
+        achieved = BYTES_PER_CELL_SWEEP * cells_per_launch * per_pass / (launch_us * 1e-6) / 1e9
+        fused = per_pass == 2
+        traffic = measured_traffic(n, math, scheme + ("_fused" if fused else "")) if single_device_full_grid else None
+        kernel = ("jacobi_fused2d_kernel" if scheme == "jacobi" else "rb_fused2d_kernel") if fused else "sweep2d_kernel"
         return {
-            "bound": "hbm", "kernel": "sweep2d_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "launch_us": round(launch_us, 3),
-            "bytes_per_launch": int(BYTES_PER_CELL_SWEEP * cells_per_launch),
-            "note": "8 B x grid cells per launch / mean launch-to-launch device time (HIP events on the kernel's stream)"
+            "iterations_per_launch": per_pass,
+            "bytes_per_launch": int(BYTES_PER_CELL_SWEEP * cells_per_launch * per_pass),
+            "note": "8 B x grid cells x iterations per launch / mean launch-to-launch device time (HIP events on the kernel's "
+                    "stream, over a batch of plain iterations = launches of this kernel only)"
+                    + ("; the fused pass performs two iterations per launch while moving the field through HBM once: traffic "
+                       "is about half of the algorithmic bytes" if fused else "")
                     + ("; traffic = PMC FETCH_SIZE x2 + WRITE_SIZE per launch of this command, recorded in profiles/hbm_traffic.json"
                        if traffic is not None else "; traffic: no PMC measurement of this configuration on file"),
         }
@@ -281,8 +290,24 @@ def main():
 
         h, upload_s = abi_setup(grid, u0, locked, args.math, args.scheme, args.track)
         wall, dev_ms = abi_timed(h, args.steps, args.warmup)
-        launch_us = dev_ms * 1e3 / sweeps
-        cells_per_launch = n * n if args.scheme == "jacobi" else n * n // 2
+        step_us_per_sweep = dev_ms * 1e3 / sweeps
+        # the dominant kernel on its own: a batch of plain iterations (no check) is launches of that kernel only -- the
+        # fused pass where the library fuses (two iterations per launch), the single sweep otherwise
+        per_pass = max(1, int(E.epic_hip_iterations_per_pass(h)))
+        batch = 2 * (args.stagger // 2)
+        kms, ms1 = 0.0, ct.c_float(0.0)
+        for _ in range(max(2, args.steps)):
+            assert E.epic_hip_timed_sweeps_gpu(h, batch, 0, ct.byref(ms1)) == 0
+            kms += ms1.value
+        launch_us = kms * 1e3 / (max(2, args.steps) * batch // per_pass)
+        cells_per_launch = n * n if args.scheme == "jacobi" else n * n // 2   # cells one ITERATION recomputes
+        single_us = None
+        if per_pass == 2:   # the single sweep of the same arithmetic, same run: what the fusion buys
+            os.environ["EPIC_HIP_NO_FUSE"] = "1"
+            assert E.epic_hip_timed_sweeps_gpu(h, batch, 0, ct.byref(ms1)) == 0
+            assert E.epic_hip_timed_sweeps_gpu(h, batch, 0, ct.byref(ms1)) == 0
+            del os.environ["EPIC_HIP_NO_FUSE"]
+            single_us = ms1.value * 1e3 / batch
         out.update({
             "value": round(updates_in(args.scheme, sweeps, develop + args.warmup * args.stagger) / wall / 1e6, 1),
             "ms_per_step": round(wall * 1e3 / args.steps, 4),
@@ -293,8 +318,14 @@ def main():
                 "math": args.math, "scheme": args.scheme, "activity_tracking": bool(args.track), "free_cells": free_cells,
                 "parallelism": "1 GPU", "h2d_seconds": round(upload_s, 3),
             },
-            "roofline": roofline(cells_per_launch, launch_us, args.math, args.scheme, True),
+            "roofline": roofline(cells_per_launch, launch_us, args.math, args.scheme, True, per_pass),
+            "step_us_per_iteration": round(step_us_per_sweep, 3),
         })
+        if single_us is not None:
+            out.setdefault("kernels", {})["single_sweep"] = {
+                "launch_us": round(single_us, 3),
+                "frac": round(BYTES_PER_CELL_SWEEP * cells_per_launch / (single_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                "note": "sweep2d_kernel, one iteration per launch (EPIC_HIP_NO_FUSE=1), same arithmetic, same field, same run"}
         assert E.harmonic_uninitialize_gpu(h) == 0
         if not args.no_relax:
             # the complete relaxation, exactly as the plugin runs it (harmonic_execute_gpu), from the initial state: with the
@@ -327,8 +358,8 @@ def main():
             pw, pms = abi_timed(hp, max(2, args.steps // 4), 1)
             abi_release(hp)
             pl = pms * 1e3 / (max(2, args.steps // 4) * args.stagger)
-            out["kernels"] = {"precise": {"launch_us": round(pl, 3), "frac": round(BYTES_PER_CELL_SWEEP * cells_per_launch / (pl * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
-                                          "note": "default math mode of the library: expf/logf bit-identical to glibc, f64; same grid, scheme and run"}}
+            out.setdefault("kernels", {})["precise"] = {"launch_us": round(pl, 3), "frac": round(BYTES_PER_CELL_SWEEP * cells_per_launch / (pl * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                                          "note": "default math mode of the library: expf/logf bit-identical to glibc, f64; same grid, scheme and run"}
         if not args.no_extra_legs:
             # BASELINE configs[4]: 3-D 512^3, 7-point, same arithmetic, on a developed field (1500 of the ~3800 sweeps the
             # relaxation takes), tracking off; 8 algorithmic bytes per cell per sweep as in 2-D

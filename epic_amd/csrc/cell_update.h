@@ -25,6 +25,7 @@
 //
 // Compile with -ffp-contract=off so no step is fused behind our back (explicit fma() where wanted).
 #pragma once
+#include <utility>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -234,6 +235,24 @@ __device__ __forceinline__ Split2 tol_split2(v2f u)
     p = pk_fma(f, p, splat(0x1.ebfbep-3f));
     p = pk_fma(f, p, splat(0x1.62e43p-1f));
     s.q = pk_fma(f, p, splat(1.0f));
+    return s;
+}
+// one cell, unpacked (v_fma_f32: the same IEEE operations as the packed form, so the same bits)
+struct Split1 { float q, zm; };
+__device__ __forceinline__ Split1 tol_split1(float u)
+{
+    Split1 s;
+    s.zm = __builtin_fmaf(u, kTolLog2eHi, kTolMagic);
+    const float nf = s.zm - kTolMagic;
+    float f = __builtin_fmaf(u, kTolLog2eHi, -nf);
+    f = __builtin_fmaf(u, kTolLog2eLo, f);
+    float p = __builtin_fmaf(f, 0x1.e5ba06p-17f, 0x1.44227cp-13f);
+    p = __builtin_fmaf(f, p, 0x1.5da0f4p-10f);
+    p = __builtin_fmaf(f, p, 0x1.3b2a4ap-7f);
+    p = __builtin_fmaf(f, p, 0x1.c6b072p-5f);
+    p = __builtin_fmaf(f, p, 0x1.ebfbep-3f);
+    p = __builtin_fmaf(f, p, 0x1.62e43p-1f);
+    s.q = __builtin_fmaf(f, p, 1.0f);
     return s;
 }
 // a row of four cells: q and the bit patterns of zm
@@ -483,6 +502,34 @@ __device__ __forceinline__ float wave_from_right(float v, float edge)
     return r;
 #endif
 }
+
+// Three registers' values of lane K (left*) and of lane 32 + K (right*), broadcast to all lanes: six ds_bpermute_b32 (the
+// LDS crossbar; no LDS memory, no VALU issue), the lane selected by the instruction's OFFSET field on top of an address
+// register holding 0 in every lane (`zero`).  Written out because the builtin either becomes v_readlane_b32 + v_mov_b32 (when the
+// compiler can see that the address is uniform: two VALU instructions per value) or keeps one address register per lane
+// number (when it cannot: twenty registers in the ten-row trip of the tol sweep, which then spills).  The compiler does
+// not count LDS operations issued from inline assembly, so the block ends with its own wait.
+template <int K>
+__device__ __forceinline__ void edge_from_lanes(int zero, float a, float b, float c, float &la, float &ra, float &lb, float &rb,
+                                                float &lc, float &rc)
+{
+    static_assert(K >= 0 && K < 32, "lanes K and 32 + K");
+    asm("ds_bpermute_b32 %0, %6, %7 offset:%10\n\t"
+        "ds_bpermute_b32 %1, %6, %7 offset:%11\n\t"
+        "ds_bpermute_b32 %2, %6, %8 offset:%10\n\t"
+        "ds_bpermute_b32 %3, %6, %8 offset:%11\n\t"
+        "ds_bpermute_b32 %4, %6, %9 offset:%10\n\t"
+        "ds_bpermute_b32 %5, %6, %9 offset:%11\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(la), "=&v"(ra), "=&v"(lb), "=&v"(rb), "=&v"(lc), "=&v"(rc)
+        : "v"(zero), "v"(a), "v"(b), "v"(c), "n"(4 * K), "n"(4 * (32 + K)));
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant expression in the body
+template <class F, int... J>
+__device__ __forceinline__ void unrolled_seq(F &f, std::integer_sequence<int, J...>) { (f(std::integral_constant<int, J>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void unrolled(F &f) { unrolled_seq(f, std::make_integer_sequence<int, N>{}); }
 
 // max over the 64 lanes of a non-negative float, result valid in every lane.
 __device__ __forceinline__ float wave_max(float v)

@@ -50,7 +50,8 @@ struct Ctx {
     int math = 0;                  // 0 = precise (default), 1 = fast, 2 = traffic, 4 = tol; EPIC_HIP_MATH / epic_hip_set_math_mode
     // Launch-bound grids replay the plain sweeps between two checks from a captured hipGraph; key = (count, starting
     // buffer, starting parity, math, scheme, rows_per_task) -- everything a captured launch sequence depends on.
-    std::map<std::tuple<unsigned, int, int, int, int, int>, hipGraphExec_t> graphs;
+    struct Replay { hipGraphExec_t exec; int cur_flip; };  // cur_flip: whether the sequence ends in the other buffer
+    std::map<std::tuple<unsigned, int, int, int, int, int>, Replay> graphs;
     bool graphs_broken = false;    // a capture / instantiate / launch failed once: batches run eagerly from then on
     // Activity tracking: every iteration lists the tiles its successor has to recompute; tiles whose inputs did
     // not change are never touched (bit-identical results, see kernels_2d.hip).  One device block `wake` holds 3 counter
@@ -258,7 +259,8 @@ int auto_rows_per_task(const Ctx *c)
     // sweep at 1 / 2 / 4 / 8 / 10 / 20 rows per task (profiles/r02_rows_per_task_tol.txt): 4096^2 45 / 39 / 34 / 36 / 31 / 33,
     // 6144 x 8192 112 / 98 / 92 / 90 / 77 / 77, 8192^2 147 / 128 / 122 / 117 / 99 / 110 (30, 40, 60: slower still);
     // 2048^2 and below keep the rule for small grids (10.8 / 10.7 / 10.5 / 12.7 / 11.1 / 14.7 at 2048^2).
-    if (c->math == 4 && (long long)c->rows / 10 * nstrips >= 6144) return 10;
+    constexpr int trip = epic_hip::kTolTripRows;  // 10
+    if (c->math == 4 && (long long)c->rows / trip * nstrips >= 6144) return trip;
     if (r >= 8) r = r / 8 * 8;
     else if (r >= 4) r = 4;
     else if (r >= 2) r = 2;
@@ -351,7 +353,7 @@ hipError_t enqueue_sweep(Ctx *c, bool check, unsigned iteration)
 
 void drop_graphs(Ctx *c)
 {
-    for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.second);
+    for (auto &g : c->graphs) (void)hipGraphExecDestroy(g.second.exec);
     c->graphs.clear();
 }
 
@@ -369,6 +371,28 @@ int fused_rows_per_task(const Ctx *c)
     return (int)std::min<long long>(64, std::max<long long>(16, r));
 }
 
+// Whether two consecutive plain Jacobi iterations run as one fused pass in the context's current configuration.
+// EPIC_HIP_FUSE_MIN_CELLS: grids below it keep the single sweeps (default 4 Mcell: below, a sweep is launch-bound and the
+// fused pass's extra rows cost more than the second launch; read per batch, not cached -- the tests switch it).
+bool fuses_jacobi(const Ctx *c)
+{
+    if (getenv("EPIC_HIP_NO_FUSE") != nullptr) return false;
+    const char *e = getenv("EPIC_HIP_FUSE_MIN_CELLS");
+    const long long min_cells = e ? atoll(e) : (1ll << 22);
+    return !c->redblack && c->n == 2 && !c->track && !c->multi() && c->math == 4 && (long long)c->rows * c->pitch >= min_cells;
+}
+
+// Rows per task of the fused Jacobi pass: a task recomputes the first iteration of one row above and one below its
+// chunk, so longer is cheaper, while the launch should still deal every wave slot several tasks (4 waves per SIMD).
+int jacobi_fused_rows_per_task(const Ctx *c)
+{
+    const char *e = getenv("EPIC_HIP_FUSED_ROWS");  // experiment / test knob
+    if (e && atoi(e) > 0) return atoi(e);
+    const long long nstrips = (c->pitch + 247) / 248;
+    const long long r = (long long)c->rows * nstrips / 16384;   // >= 4 tasks per wave slot (256 CUs x 16 waves)
+    return (int)std::min<long long>(48, std::max<long long>(8, r));   // (4096^2: 8 rows 29.4 us per iteration, 4 rows 30.9)
+}
+
 hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
 {
     static const bool no_fuse = getenv("EPIC_HIP_NO_FUSE") != nullptr;
@@ -376,6 +400,17 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
     // (and the precise / fast arithmetic only: the tol math runs the in-place half-sweeps)
     const bool fuse = c->redblack && c->n == 2 && !no_fuse && !c->track && !c->multi() && c->math != 4 && (long long)c->rows * c->pitch >= (1ll << 22);
     unsigned i = 0;
+    // Jacobi, tol math, 2-D: two consecutive plain iterations run as one pass as well (kernels_2d.hip,
+    // jacobi_fused2d_kernel: 4 B of HBM traffic per cell-update instead of 8, bit-identical to two sweeps).
+    // EPIC_HIP_FUSE_MIN_CELLS: grids below it keep the single sweeps (default 4 Mcell; the tests set 0).
+    const bool fuse_jacobi = !no_fuse && fuses_jacobi(c);
+    while (fuse_jacobi && count - i >= 2) {
+        hipError_t e = epic_hip::launch_jacobi_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch,
+                                                        jacobi_fused_rows_per_task(c), c->math, c->stream);
+        if (e != hipSuccess) return e;
+        c->cur ^= 1;
+        i += 2;
+    }
     while (fuse && count - i >= 2) {
         hipError_t e = epic_hip::launch_rb_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch,
                                                     fused_rows_per_task(c), c->math, (int)((first + i) & 1u), c->stream);
@@ -393,7 +428,7 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
 hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
 {
     const bool small = (long long)c->rows * c->pitch <= (1ll << 22);
-    static const bool no_graph = getenv("EPIC_HIP_NO_GRAPH") != nullptr;
+    const bool no_graph = getenv("EPIC_HIP_NO_GRAPH") != nullptr;  // (read per batch: the tests switch it)
     // a captured sequence bakes in the work-list buffers and list mode: run eagerly until the forced iterations are over
     if (!small || count < 8 || no_graph || c->multi() || (c->track && (c->force > 0 || c->act_tiles == 0)))
         return enqueue_plain_run(c, count, first);
@@ -409,10 +444,11 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
         hipGraphExec_t exec = nullptr;
         hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
-            for (unsigned i = 0; i < count && e == hipSuccess; i++) e = enqueue_sweep(c, false, first + i);
+            e = enqueue_plain_run(c, count, first);  // (fused passes included)
             hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
             if (e == hipSuccess) e = e2;
         }
+        const int cur_flip = c->cur ^ cur0;  // (a fused pass advances two iterations and changes buffers once)
         c->cur = cur0;  // nothing has run yet
         c->phase = phase0;
         c->force = force0;
@@ -424,15 +460,15 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
             return enqueue_plain_run(c, count, first);
         }
         if (c->graphs.size() >= 16) drop_graphs(c);
-        it = c->graphs.emplace(key, exec).first;
+        it = c->graphs.emplace(key, Ctx::Replay{exec, cur_flip}).first;
     }
-    hipError_t e = hipGraphLaunch(it->second, c->stream);
+    hipError_t e = hipGraphLaunch(it->second.exec, c->stream);
     if (e != hipSuccess) {  // nothing was enqueued: run the batch eagerly instead, and stop replaying
         (void)hipGetLastError();
         c->graphs_broken = true;
         return enqueue_plain_run(c, count, first);
     }
-    if (!c->redblack && (count & 1u)) c->cur ^= 1;
+    c->cur ^= it->second.cur_flip;
     if (c->track) c->phase = (int)((c->phase + count) % 6);
     return hipSuccess;
 }
@@ -1471,6 +1507,17 @@ int epic_hip_timed_sweeps_gpu(Harmonic *harmonic, unsigned int sweeps, unsigned 
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return rc;
+}
+
+int epic_hip_iterations_per_pass(Harmonic *harmonic)
+{
+    Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
+    if (!c) return 0;
+    if (fuses_jacobi(c)) return 2;
+    static const bool no_fuse = getenv("EPIC_HIP_NO_FUSE") != nullptr;
+    const bool rb_fused = c->redblack && c->n == 2 && !no_fuse && !c->track && !c->multi() && c->math != 4 &&
+                          (long long)c->rows * c->pitch >= (1ll << 22);
+    return rb_fused ? 2 : 1;
 }
 
 int epic_hip_set_rows_per_task(Harmonic *harmonic, unsigned int rows_per_task)

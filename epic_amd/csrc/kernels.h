@@ -48,6 +48,9 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, i
 // two red-black iterations fused into one in -> out pass (first colour = parity); see kernels_2d.hip
 hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
                               int math, int parity, hipStream_t stream);
+// Two Jacobi iterations in one pass (tol math only): in = u_k, out = u_{k+2}; in != out.
+hipError_t launch_jacobi_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
+                                  int math, hipStream_t stream);
 hipError_t launch_eval_math(const float *in, float *out, size_t n, int which, hipStream_t stream);
 hipError_t launch_pack_mask_2d(const uint32_t *locked, int rows, int cols, int pitch, int ghost_top,
                                int ghost_bottom, uint32_t *maskw, hipStream_t stream);
@@ -64,6 +67,14 @@ hipError_t launch_follow_paths_2d(const float *u, const uint32_t *maskw, int row
                                   const float *d_starts, float step, float cd, unsigned max_points, float *d_pts,
                                   unsigned *d_k, int *d_rc, hipStream_t stream);
 
+// tol math, 2-D: rows are loaded kTolRowsAhead steps ahead of their use through a ring of kTolRowsAhead + 3 register sets; the
+// pipelined loop runs in trips of kTolTripRows rows (the rings close after lcm(ring, 2) steps), and the host picks rows per
+// task in multiples of it (harmonic_gpu.hip: auto_rows_per_task).
+#ifndef EPIC_TOL_AHEAD  // build knob (A/B)
+#define EPIC_TOL_AHEAD 2
+#endif
+constexpr int kTolRowsAhead = EPIC_TOL_AHEAD;
+constexpr int kTolTripRows = (kTolRowsAhead + 3) % 2 == 0 ? kTolRowsAhead + 3 : 2 * (kTolRowsAhead + 3);
 // rows are padded to whole wave-strips (256 floats = 1 KiB): every lane of every wave is in bounds, always
 inline int pitch_for_cols(int cols) { return (cols + 255) / 256 * 256; }
 // 2-D mask layout (device-private): LANE MASKS.  For every row and every 256-column strip four 64-bit words, word j

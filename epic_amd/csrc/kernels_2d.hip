@@ -31,6 +31,7 @@
 // glibc, evaluated in f64) it is bound by VALU issue: 41 f64 / conversion instructions per cell plus 29 others at ~4
 // cycles per wave each, 138-146 us; with the tol math (one split per cell shared by its neighbours, cell_update.h) both
 // pipes are nearly full: 107-109 us = 0.62 of 8 TB/s.
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -96,7 +97,7 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nblk)
 // alone the five-row ring takes 83.  The tracked and the red-black check variants would spill: they keep what they get.
 // No sweep kernel may use scratch: tools/isa_hazards.py checks it.)
 template <bool CHECK, int MATH, bool RB, bool TRACK> struct SweepOcc {
-    static constexpr int kMinWaves = (MATH == kMathTol && !TRACK && !(RB && CHECK)) ? 6 : 1;
+    static constexpr int kMinWaves = (MATH == kMathTol && !TRACK && !(RB && CHECK)) ? (CHECK ? 5 : 6) : 1;  // the check sweep (1 in 100) needs 3 registers more
 };
 template <bool CHECK, int MATH, bool RB, bool TRACK>
 __global__ __launch_bounds__(kWave * kWavesPerBlock, (SweepOcc<CHECK, MATH, RB, TRACK>::kMinWaves)) EPIC_SWEEP_OCC void sweep2d_kernel(Sweep2dArgs a)
@@ -163,6 +164,19 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (SweepOcc<CHECK, MATH, RB, 
         cu64 *mk = (cu64 *)a.maskw + ((size_t)r * a.nstrips + strip) * 4;
         return RowSide{row[hcol_l], row[hcol_r], mk[0], mk[1], mk[2], mk[3]};
     };
+    // tol math: the splits of the row's two strip-edge cells, needed in lane 0 (left) and lane 63 (right) only.  The plain
+    // loops split the two wave-uniform values as one packed pair in every lane (edge_split); the trips of the pipelined
+    // loop split the edge cells of all their rows at once, one cell per lane (below).
+    struct EdgeSplit { float ql, qr, zl, zr; };
+    auto edge_split = [&](const RowSide &h) -> EdgeSplit {
+        const Split2 hs = tol_split2(v2f{h.l, h.r});
+        return EdgeSplit{hs.q.x, hs.q.y, hs.zm.x, hs.zm.y};
+    };
+    auto masks = [&](int r) -> RowSide {  // a RowSide without the edge values (the caller fills them in)
+        r = min(max(r, 0), rlast);
+        cu64 *mk = (cu64 *)a.maskw + ((size_t)r * a.nstrips + strip) * 4;
+        return RowSide{0.0f, 0.0f, mk[0], mk[1], mk[2], mk[3]};
+    };
 
     // March direction.  Vertically adjacent tasks share two halo rows; if every task marched downwards, task k would
     // read them at its end and task k+1 at its start, a whole task apart in time, and the XCD's 4 MiB L2 would have
@@ -178,16 +192,15 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (SweepOcc<CHECK, MATH, RB, 
     lmask chg_any = 0, chg_x = 0, chg_w = 0, chg_top = 0, chg_bot = 0;
     // One row: up / c / dn are rows r-1, r, r+1 of u_in, h the two strip-edge values of row r.
     // (tol math: su / sc / sd are the splits of the three rows, computed once per row as it enters the window)
+    // (tol math: he = the splits of the two strip-edge cells of the row, see EdgeSplit below)
     auto row_step = [&](int r, const float4 &up, const float4 &c, const float4 &dn, const RowSide &h, const Split4 &su,
-                        const Split4 &sc, const Split4 &sd) {
+                        const Split4 &sc, const Split4 &sd, const EdgeSplit &he) {
         const float lf = wave_from_left(c.w, h.l);   // u[r][col-1]
         const float rt = wave_from_right(c.x, h.r);  // u[r][col+4]
         float4 o;
         if (TOL) {
-            // the two strip-edge cells of the row: wave-uniform values, split as one packed pair
-            const Split2 hs = tol_split2(v2f{h.l, h.r});
-            const float ql = wave_from_left(sc.qw, hs.q.x), qr = wave_from_right(sc.qx, hs.q.y);
-            const uint32_t nl = f2u(wave_from_left(u2f(sc.nw), hs.zm.x)), nr = f2u(wave_from_right(u2f(sc.nx), hs.zm.y));
+            const float ql = wave_from_left(sc.qw, he.ql), qr = wave_from_right(sc.qx, he.qr);
+            const uint32_t nl = f2u(wave_from_left(u2f(sc.nw), he.zl)), nr = f2u(wave_from_right(u2f(sc.nx), he.zr));
             o = c;
             const bool odd_cols = !RB || ((r + a.parity) & 1) == 0, even_cols = !RB || !odd_cols;  // scalar
             if (even_cols) {
@@ -249,41 +262,68 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (SweepOcc<CHECK, MATH, RB, 
     // small grids -- go through a plain loop.
     auto row_at = [&](int i) { return rfirst + dir * i; };  // i-th row of the march
     auto split = [&](const float4 &q) { return TOL ? tol_split4(q) : Split4{}; };
-    if constexpr (TOL) {
+    // (the traffic-only diagnostic build marches like the tol kernel, so that it times THAT kernel's loads and stores)
+    constexpr bool DEEP = TOL || MATH == kMathTraffic;
+    if constexpr (DEEP) {
         // The tol arithmetic leaves the kernel close to the memory roofline, where what counts is the number of bytes in
         // flight: rows are loaded TWO steps ahead (two 1 KiB loads per wave outstanding instead of one; one step ahead
         // the chip ran at 4.9 TB/s with 6 waves per SIMD, 110 us per 8192^2 sweep).  Five rows rotate through five register
         // sets -- the arrays below are indexed by constants once the inner loop is unrolled, so nothing is moved --, the
         // splits ride the same ring (a row is split when it enters the window as the row below), the row sides alternate
         // between two sets of SGPRs as before; 10 = lcm(5, 2) steps per trip.
-        constexpr int kRing = 5, kTrip = 10;
+        constexpr int kAhead = kTolRowsAhead, kRing = kAhead + 3, kTrip = kTolTripRows;
+        static_assert(kTrip % kRing == 0 && kTrip % 2 == 0, "the rings close after a trip");
         float4 q[kRing];
         Split4 s[kRing];
         RowSide h[2];
-        q[0] = ld(row_at(-1)); q[1] = ld(row_at(0)); q[2] = ld(row_at(1)); q[3] = ld(row_at(2));
-        h[0] = side(row_at(0));
+#pragma unroll
+        for (int k = 0; k < kAhead + 2; ++k) q[k] = ld(row_at(k - 1));
+        h[0] = TOL ? masks(row_at(0)) : side(row_at(0));
         if (tables_pending) {  // wave-uniform, once per wave
             math_tables_commit(tab_regs, math_lds);
             tables_pending = false;
         }
         const int ntrip = nrows / kTrip * kTrip;
         if (ntrip > 0) {
+            // The strip-edge cells of a trip's ten rows -- u[r][col0 - 1] and u[r][col0 + 256], which belong to the
+            // neighbouring strips -- are loaded and split ONCE per trip, one cell per lane: lane k holds the left edge cell
+            // of the trip's k-th row, lane 32 + k the right one (one dword load per lane, issued a trip ahead; one
+            // unpacked split per trip instead of a packed one per row in every lane: 11 VALU instructions per row less).
+            // A row takes its two cells' u, q and zm from those lanes with ds_bpermute_b32 (all lanes read one lane; the
+            // LDS crossbar, no VALU), as the `edge` operands of the wave shifts.
+            const int hk = min(lane & 31, kTrip - 1);
+            const int hcol = lane < 32 ? hcol_l : hcol_r;
+            auto edge_ld = [&](int i0) -> float {  // rows of the march only: r0 <= r < r1, so r - rlo >= 0
+                const int r = rfirst + dir * (i0 + hk);
+                return u2f(__builtin_amdgcn_raw_buffer_load_b32(rin, (unsigned)((r - rlo) * a.pitch + hcol) * 4u, 0, 0));
+            };
+            int lane_zero;  // address operand of edge_from_lanes (cell_update.h); opaque so that it stays one VGPR
+            asm("v_mov_b32 %0, 0" : "=v"(lane_zero));
+            float ev_next = edge_ld(0);
             s[0] = split(q[0]); s[1] = split(q[1]);
             for (int i = 0; i < ntrip; i += kTrip) {
-#pragma unroll
-                for (int j = 0; j < kTrip; ++j) {
-                    q[(j + 4) % kRing] = ld(row_at(i + j + 3));
-                    h[(j + 1) & 1] = side(row_at(i + j + 1));
+                const float ev = ev_next;
+                const Split1 es = tol_split1(ev);
+                if (i + kTrip < ntrip) ev_next = edge_ld(i + kTrip);
+                auto trip_row = [&](auto jc) {  // j as a constant: the lane numbers are immediates of edge_from_lanes
+                    constexpr int j = decltype(jc)::value;
+                    q[(j + 2 + kAhead) % kRing] = ld(row_at(i + j + 1 + kAhead));
+                    h[(j + 1) & 1] = TOL ? masks(row_at(i + j + 1)) : side(row_at(i + j + 1));
                     s[(j + 2) % kRing] = split(q[(j + 2) % kRing]);
-                    row_step(row_at(i + j), q[j % kRing], q[(j + 1) % kRing], q[(j + 2) % kRing], h[j & 1], s[j % kRing],
-                             s[(j + 1) % kRing], s[(j + 2) % kRing]);
-                }
+                    RowSide hj = h[j & 1];
+                    EdgeSplit he = {};
+                    if constexpr (TOL) edge_from_lanes<j>(lane_zero, ev, es.q, es.zm, hj.l, hj.r, he.ql, he.qr, he.zl, he.zr);
+                    row_step(row_at(i + j), q[j % kRing], q[(j + 1) % kRing], q[(j + 2) % kRing], hj, s[j % kRing],
+                             s[(j + 1) % kRing], s[(j + 2) % kRing], he);
+                };
+                unrolled<kTrip>(trip_row);
             }
         }
         for (int i = ntrip; i < nrows; ++i) {  // ragged rest, and the short tasks of the small grids
             const int r = row_at(i);
             const float4 ru = ld(r - dir), rc = ld(r), rd = ld(r + dir);
-            row_step(r, ru, rc, rd, side(r), split(ru), split(rc), split(rd));
+            const RowSide hr = side(r);
+            row_step(r, ru, rc, rd, hr, split(ru), split(rc), split(rd), TOL ? edge_split(hr) : EdgeSplit{});
         }
     } else {
     const int nfull = nrows & ~3;
@@ -294,24 +334,25 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (SweepOcc<CHECK, MATH, RB, 
         tables_pending = false;
     }
     const Split4 none = {};
+    const EdgeSplit no_edge = {};
     if (nfull > 0) {
         for (int i = 0; i < nfull; i += 4) {
             q3 = ld(row_at(i + 2)); sb = side(row_at(i + 1));
-            row_step(row_at(i), q0, q1, q2, sa, none, none, none);
+            row_step(row_at(i), q0, q1, q2, sa, none, none, none, no_edge);
             q0 = ld(row_at(i + 3)); sa = side(row_at(i + 2));
-            row_step(row_at(i + 1), q1, q2, q3, sb, none, none, none);
+            row_step(row_at(i + 1), q1, q2, q3, sb, none, none, none, no_edge);
             q1 = ld(row_at(i + 4)); sb = side(row_at(i + 3));
-            row_step(row_at(i + 2), q2, q3, q0, sa, none, none, none);
+            row_step(row_at(i + 2), q2, q3, q0, sa, none, none, none, no_edge);
             q2 = ld(row_at(i + 5)); sa = side(row_at(i + 4));
-            row_step(row_at(i + 3), q3, q0, q1, sb, none, none, none);
+            row_step(row_at(i + 3), q3, q0, q1, sb, none, none, none, no_edge);
         }
     }
-    if (nfull == 0 && nrows > 0) row_step(row_at(0), q0, q1, q2, sa, none, none, none);  // the one-row tasks of the small grids land here
+    if (nfull == 0 && nrows > 0) row_step(row_at(0), q0, q1, q2, sa, none, none, none, no_edge);  // the one-row tasks of the small grids land here
     for (int i = nfull == 0 ? 1 : nfull; i < nrows; ++i) {
         const int r = row_at(i);
-        row_step(r, ld(r - dir), ld(r), ld(r + dir), side(r), none, none, none);
+        row_step(r, ld(r - dir), ld(r), ld(r + dir), side(r), none, none, none, no_edge);
     }
-    }  // !TOL
+    }  // !DEEP
 
     if (TRACK) {
         // wake the tiles that read what this task changed: itself, and the neighbour across each edge that changed
@@ -451,6 +492,124 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
     for (; r < r1; ++r) {  // at most two rows
         step(r, ma, mb, mc, oa, ob, oc);
         ma = mb; mb = mc; oa = ob; ob = oc;
+    }
+}
+
+// ---- fused Jacobi sweep, tol math: TWO iterations in one pass over the data -----------------------------------------
+// The single tol sweep runs at ~0.9 of what its own loads and stores cost with no arithmetic at all (the traffic-only
+// build), and those at ~0.93 of a flat copy: 8 B of HBM traffic per cell-update is the bill, whatever the VALU does.  This
+// kernel pays it once for two iterations: while a wave marches down its strip it computes iteration k+1 of row r+1 from
+// rows r .. r+2 of u_k (level A, kept in registers only), then iteration k+2 of row r from rows r-1 .. r+1 of level A
+// (level B), and stores row r.  4 B per cell-update; the price is arithmetic done twice where tasks meet:
+//   * columns: a wave loads 256 columns and owns the 248 in lanes 1..62 (as rb_fused2d_kernel); the inner cell of each
+//     halo lane is a correct level-A value (its own neighbours are all inside the 256), everything further out is unused;
+//   * rows: a task computes level A for the row above and the row below its chunk as well (rows r0-1 .. r1 of level A
+//     from rows r0-2 .. r1+1 of u_k).
+// Every cell value is produced by the same tol_update_2d on the same inputs as in two single sweeps, so the result is
+// bit-identical to them (tests/test_gpu_tol.py compares odd and even iteration counts with the checker).  Ping-pong
+// (in != out) as always for Jacobi.  Rings: u_k rows over six register sets (loaded two steps ahead), their splits, the
+// level-A rows and THEIR splits over three each, the lane masks of three rows in SGPRs; six steps per trip, every step
+// behind a scalar test of its row number so that a task may have any number of rows.
+#ifndef EPIC_FUSED_MIN_WAVES  // build knob (A/B)
+#define EPIC_FUSED_MIN_WAVES 4
+#endif
+template <int MATH>
+__global__ __launch_bounds__(kWave * kWavesPerBlock, EPIC_FUSED_MIN_WAVES) void jacobi_fused2d_kernel(Sweep2dArgs a)
+{
+    static_assert(MATH == kMathTol, "the fused Jacobi pass exists for the tol math");
+    __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];
+    const MathTab lds = math_tables_load(math_lds);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int task = xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
+    if (task >= a.ntasks) return;
+    const int strip = task % a.nstrips;
+    const int chunk = task / a.nstrips;
+    const int r0 = a.row_begin + chunk * a.rows_per_task;
+    const int r1 = min(r0 + a.rows_per_task, a.row_end);
+    const int col = strip * kFusedOut - kColsPerLane + lane * kColsPerLane;  // lane 0 = left halo lane
+    const int lcol = min(max(col, 0), a.pitch - kColsPerLane);
+    const bool owner = lane >= 1 && lane <= kWave - 2 && col < a.pitch;
+    const int rlast = a.rows - 1;
+    const size_t pitch = (size_t)a.pitch;
+    typedef unsigned vu4 __attribute__((ext_vector_type(4)));
+
+    const int rlo = max(r0 - 2, 0);  // rows r0 - 2 .. r1 + 4 are touched (clamped to the grid)
+    const __amdgpu_buffer_rsrc_t rin = raw_buffer(a.in + (size_t)rlo * pitch), rout = raw_buffer(a.out + (size_t)rlo * pitch);
+    const unsigned lane_off = (unsigned)lcol * 4u;
+    auto row_off = [&](int r) -> unsigned { return (unsigned)((r - rlo) * a.pitch) * 4u; };  // r already clamped
+    auto ld = [&](int r) -> float4 {
+        r = min(max(r, 0), rlast);
+        const vu4 q = __builtin_amdgcn_raw_buffer_load_b128(rin, lane_off, row_off(r), 0);
+        return make_float4(u2f(q.x), u2f(q.y), u2f(q.z), u2f(q.w));
+    };
+    // lane masks of a row for this kernel's lane -> column mapping: as in rb_fused2d_kernel
+    typedef const __attribute__((address_space(4))) uint64_t cu64;
+    struct RowMask { lmask m0, m1, m2, m3; };
+    const int nstd = a.pitch >> 8;
+    const int g0 = strip * (kFusedOut / kColsPerLane) - 1;
+    const int sw = max(g0, 0) >> 6, sh = max(g0, 0) & 63, sw1 = min(sw + 1, nstd - 1);
+    auto row_mask = [&](int r) -> RowMask {
+        r = min(max(r, 0), rlast);
+        cu64 *lo = (cu64 *)a.maskw + ((size_t)r * nstd + sw) * 4, *hi = (cu64 *)a.maskw + ((size_t)r * nstd + sw1) * 4;
+        auto cut = [&](int j) -> lmask {
+            lmask m = lo[j];
+            if (sh) m = (m >> sh) | (hi[j] << (64 - sh));
+            return g0 < 0 ? m << 1 : m;
+        };
+        return RowMask{cut(0), cut(1), cut(2), cut(3)};
+    };
+    // One iteration of one row from its three rows and their splits.  The outer cells of the halo lanes have no neighbour
+    // on one side: the shift gives them zero bits there (bound_ctrl: one instruction, no edge operand to set up) -- their
+    // results are never stored and never read by an owned cell.
+    auto shl = [](float v) { return u2f(__builtin_amdgcn_mov_dpp(f2u(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true)); };  // from the left
+    auto shr = [](float v) { return u2f(__builtin_amdgcn_mov_dpp(f2u(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true)); };  // from the right
+    auto level = [&](const float4 &up, const float4 &c, const float4 &dn, const Split4 &su, const Split4 &sc, const Split4 &sd,
+                     const RowMask &k) -> float4 {
+        const float lf = shl(c.w), rt = shr(c.x);
+        const float ql = shl(sc.qw), qr = shr(sc.qx);
+        const uint32_t nl = f2u(shl(u2f(sc.nw))), nr = f2u(shr(u2f(sc.nx)));
+        float4 o;
+        o.x = sel(k.m0, c.x, tol_update_2d(up.x, dn.x, lf, c.y, su.qx, su.nx, sd.qx, sd.nx, ql, nl, sc.qy, sc.ny, lds));
+        o.y = sel(k.m1, c.y, tol_update_2d(up.y, dn.y, c.x, c.z, su.qy, su.ny, sd.qy, sd.ny, sc.qx, sc.nx, sc.qz, sc.nz, lds));
+        o.z = sel(k.m2, c.z, tol_update_2d(up.z, dn.z, c.y, c.w, su.qz, su.nz, sd.qz, sd.nz, sc.qy, sc.ny, sc.qw, sc.nw, lds));
+        o.w = sel(k.m3, c.w, tol_update_2d(up.w, dn.w, c.z, rt, su.qw, su.nw, sd.qw, sd.nw, sc.qz, sc.nz, qr, nr, lds));
+        return o;
+    };
+
+    // Ring slots (row numbers relative to r0, trips start at multiples of 6):  u_k row x -> u[(x + 2) % 6],
+    // its split -> su[(x + 2) % 3],  level-A row x and its split -> m / sm[(x + 1) % 3],  masks of row x -> k[(x + 1) % 3].
+    constexpr int kTrip = 6;
+    float4 u[6], m[3];
+    Split4 su[3], sm[3];
+    RowMask k[3];
+#pragma unroll
+    for (int x = 0; x < 6; ++x) u[x] = ld(r0 - 2 + x);
+    k[0] = row_mask(r0 - 1); k[1] = row_mask(r0); k[2] = row_mask(r0 + 1);
+    su[0] = tol_split4(u[0]); su[1] = tol_split4(u[1]); su[2] = tol_split4(u[2]);
+    m[0] = level(u[0], u[1], u[2], su[0], su[1], su[2], k[0]);   // level A of row r0 - 1
+    sm[0] = tol_split4(m[0]);
+    su[0] = tol_split4(u[3]);                                    // the split of row r0 - 2 is done with
+    m[1] = level(u[1], u[2], u[3], su[1], su[2], su[0], k[1]);   // level A of row r0
+    sm[1] = tol_split4(m[1]);
+    const int nrows = r1 - r0;
+    for (int i = 0; i < nrows; i += kTrip) {
+        auto step = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if (i + j < nrows) {  // scalar
+                const int r = r0 + i + j;
+                u[j % 6] = ld(r + 4);                                            // slot of row r - 2
+                su[(j + 1) % 3] = tol_split4(u[(j + 4) % 6]);                    // row r + 2 (slot of row r - 1's split)
+                m[(j + 2) % 3] = level(u[(j + 2) % 6], u[(j + 3) % 6], u[(j + 4) % 6], su[(j + 2) % 3], su[j % 3],
+                                       su[(j + 1) % 3], k[(j + 2) % 3]);         // level A of row r + 1
+                sm[(j + 2) % 3] = tol_split4(m[(j + 2) % 3]);
+                const float4 x = level(m[j % 3], m[(j + 1) % 3], m[(j + 2) % 3], sm[j % 3], sm[(j + 1) % 3], sm[(j + 2) % 3],
+                                       k[(j + 1) % 3]);                          // level B of row r
+                k[j % 3] = row_mask(r + 2);                                      // slot of row r - 1's masks
+                if (owner) store_row(rout, x.x, x.y, x.z, x.w, lane_off, row_off(r));
+            }
+        };
+        unrolled<kTrip>(step);
     }
 }
 
@@ -639,6 +798,32 @@ hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw
     if (math == kMathFast) hipLaunchKernelGGL((rb_fused2d_kernel<kMathFast>), grid, block, 0, stream, a);
     else if (math == kMathTraffic) hipLaunchKernelGGL((rb_fused2d_kernel<kMathTraffic>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((rb_fused2d_kernel<kMathPrecise>), grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_jacobi_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
+                                  int math, hipStream_t stream)
+{
+    if (pitch <= 0 || (pitch % 256) != 0 || rows <= 0 || rows_per_task <= 0 || in == out) return hipErrorInvalidValue;
+    if (math != kMathTol) return hipErrorInvalidValue;
+    Sweep2dArgs a;
+    a.in = in;
+    a.out = out;
+    a.maskw = maskw;
+    a.delta_bits = nullptr;
+    a.rows = rows;
+    a.pitch = pitch;
+    a.row_begin = 0;
+    a.row_end = rows;
+    a.rows_per_task = rows_per_task;
+    a.nstrips = (pitch + kFusedOut - 1) / kFusedOut;
+    a.ntasks = a.nstrips * ((rows + rows_per_task - 1) / rows_per_task);
+    a.parity = 0;
+    a.flags = sweep_flags();
+    a.nchunks = 0;
+    a.wake = wake_args(nullptr, 0);
+    const dim3 grid((a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
+    hipLaunchKernelGGL((jacobi_fused2d_kernel<kMathTol>), grid, block, 0, stream, a);
     return hipGetLastError();
 }
 

@@ -106,6 +106,34 @@ def test_tol_iterations_equal_the_checker_bit_for_bit(m, seed, dens, rpt, scheme
             assert gdelta == wdelta
 
 
+FUSED_GRIDS = [([16, 16], 1, 0.05), ([23, 37], 4, 0.10), ([3, 3], 6, 0.0), ([3, 70], 6, 0.0), ([70, 3], 6, 0.0),
+               ([8, 300], 7, 0.05), ([70, 66], 8, 0.30), ([257, 513], 9, 0.05), ([64, 1030], 10, 0.05), ([96, 249], 6, 0.05),
+               ([211, 530], 12, 0.06), ([1200, 3000], 5, 0.05)]
+
+
+@pytest.mark.parametrize("m,seed,dens", FUSED_GRIDS)
+@pytest.mark.parametrize("rows", [0, 1, 5, 6, 7, 24])
+def test_tol_fused_double_sweeps_equal_the_checker_bit_for_bit(m, seed, dens, rows, monkeypatch):
+    """Plain Jacobi iterations in pairs run as ONE pass (jacobi_fused2d_kernel: level A in registers, 248 owned columns
+    per wave, tasks of any number of rows); forced here on small grids and with task heights around the six-row trip.
+    k = 2, 3 (pair + single), 8, 41 (20 pairs + the check sweep), 100 and 101 plain iterations, through the captured
+    graph (small grids) and eagerly."""
+    monkeypatch.setenv("EPIC_HIP_FUSE_MIN_CELLS", "0")
+    if rows:
+        monkeypatch.setenv("EPIC_HIP_FUSED_ROWS", str(rows))
+    u0, locked = with_extra_goals(m, seed, dens)
+    for k in (2, 3, 8, 41, 101):
+        want, wdelta = checker_iterations(m, u0, locked, k, eh.SCHEME_JACOBI)
+        for graph in (True, False):
+            if graph:
+                monkeypatch.delenv("EPIC_HIP_NO_GRAPH", raising=False)
+            else:
+                monkeypatch.setenv("EPIC_HIP_NO_GRAPH", "1")
+            got, gdelta = gpu_iterations(m, u0, locked, k, eh.SCHEME_JACOBI, 0)
+            assert np.array_equal(got, want), f"{m} after {k} iterations, fused rows {rows}, graph {graph}"
+            assert gdelta == wdelta
+
+
 @pytest.mark.parametrize("m,rpt", [([66000, 300], 0), ([6, 80000], 0), ([1200, 9000], 60), ([40000, 520], 5), ([33, 257], 4)])
 def test_tol_extreme_aspect_ratios(m, rpt):
     u0, locked = synthetic_grid(m, 17, 0.05)

@@ -2,7 +2,8 @@
 # Profiles kept under profiles/ for a round (run on the GPU box through gpurun; TAG = r01, r02, ...):
 #   bash tools/profile_round.sh r02
 # rocprofv3 passes, each with the program itself after `--` (python3 <script>), counters in their own runs:
-#   1. --kernel-trace --stats of the bench.py command (default math = tol, untracked Jacobi, developed field) and of
+#   1. --kernel-trace --stats of the bench.py command (default math = tol, untracked Jacobi, developed field: pairs of
+#      iterations as jacobi_fused2d_kernel, the check and the odd iteration as sweep2d_kernel) and of
 #      the same with --math precise; of the 512^3 sweeps (tools/bench_config.py, developed field), tol and precise
 #   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes: 2-D tol, 3-D tol, 3-D precise
 #   3. --pmc SQ counters: 2-D tol, 2-D precise, 3-D tol, 3-D precise
@@ -35,10 +36,12 @@ $S stats "$OUT/stats_tol_jacobi" > "$OUT/${TAG}_kernel_stats_tol_jacobi.txt"
 $S stats "$OUT/stats_precise_jacobi" > "$OUT/${TAG}_kernel_stats_precise_jacobi.txt"
 $S stats "$OUT/stats_3d_tol" > "$OUT/${TAG}_kernel_stats_3d_tol.txt"
 $S stats "$OUT/stats_3d_precise" > "$OUT/${TAG}_kernel_stats_3d_precise.txt"
-$S pmc "$OUT/fetch_tol_jacobi" "$OUT/write_tol_jacobi" > "$OUT/${TAG}_hbm_traffic_tol_jacobi.txt"
+PROFILE_KERNEL=jacobi_fused2d $S pmc "$OUT/fetch_tol_jacobi" "$OUT/write_tol_jacobi" > "$OUT/${TAG}_hbm_traffic_tol_jacobi_fused.txt"
+PROFILE_KERNEL=sweep2d $S pmc "$OUT/fetch_tol_jacobi" "$OUT/write_tol_jacobi" > "$OUT/${TAG}_hbm_traffic_tol_jacobi.txt"
 $S pmc "$OUT/fetch_3d_tol" "$OUT/write_3d_tol" > "$OUT/${TAG}_hbm_traffic_3d_tol.txt"
 $S pmc "$OUT/fetch_3d_precise" "$OUT/write_3d_precise" > "$OUT/${TAG}_hbm_traffic_3d_precise.txt"
-$S sq "$OUT/sq_tol_jacobi" 67108864 > "$OUT/${TAG}_sq_counters_tol.txt" 2>&1
+PROFILE_KERNEL=jacobi_fused2d $S sq "$OUT/sq_tol_jacobi" 134217728 > "$OUT/${TAG}_sq_counters_tol_fused.txt" 2>&1
+PROFILE_KERNEL=sweep2d $S sq "$OUT/sq_tol_jacobi" 67108864 > "$OUT/${TAG}_sq_counters_tol.txt" 2>&1
 $S sq "$OUT/sq_precise_jacobi" 67108864 > "$OUT/${TAG}_sq_counters_precise.txt" 2>&1
 $S sq "$OUT/sq_3d_tol" 134217728 > "$OUT/${TAG}_sq_counters_3d_tol.txt" 2>&1
 $S sq "$OUT/sq_3d_precise" 134217728 > "$OUT/${TAG}_sq_counters_3d_precise.txt" 2>&1

@@ -75,6 +75,24 @@ int main()
     for (int blocks : {2048, 8192, 65536})
         { char nm[64]; snprintf(nm, 64, "flat copy, %d blocks", blocks);
           report(nm, time_it([&] { hipLaunchKernelGGL(flat_copy, dim3(blocks), dim3(256), 0, 0, (const float4 *)a, (float4 *)b, bytes / 16); })); }
+    {   // ping-pong (a -> b, b -> a, ...), as consecutive sweeps do: every launch reads what the previous one wrote
+        int flip = 0;
+        for (int blocks : {65536}) {
+            report("flat copy ping-pong, 65536 blocks", time_it([&] { const float4 *src = (const float4 *)(flip ? b : a); float4 *dst = (float4 *)(flip ? a : b); flip ^= 1;
+                hipLaunchKernelGGL(flat_copy, dim3(blocks), dim3(256), 0, 0, src, dst, bytes / 16); }));
+        }
+        const int ns = N / 256;
+        for (int rpt : {8, 16, 64}) {
+            const int ntasks = ns * ((N + rpt - 1) / rpt), nblk = (ntasks + 3) / 4;
+            char nm[96];
+            snprintf(nm, 96, "strip rpt=%d 3-row + halo + mask nt ping-pong", rpt);
+            report(nm, time_it([&] { const float *src = flip ? b : a; float *dst = flip ? a : b; flip ^= 1;
+                hipLaunchKernelGGL((strip<4, true>), dim3(nblk), dim3(256), 0, 0, src, dst, m, rpt, ns, ntasks); }));
+            snprintf(nm, 96, "strip rpt=%d 3-row stencil nt ping-pong", rpt);
+            report(nm, time_it([&] { const float *src = flip ? b : a; float *dst = flip ? a : b; flip ^= 1;
+                hipLaunchKernelGGL((strip<2, true>), dim3(nblk), dim3(256), 0, 0, src, dst, m, rpt, ns, ntasks); }));
+        }
+    }
     const int nstrips = N / 256;
     for (int rpt : {8, 16, 64, 256}) {
         const int ntasks = nstrips * ((N + rpt - 1) / rpt), nblk = (ntasks + 3) / 4;

@@ -3,6 +3,9 @@
 
   python tools/summarize_profile.py stats  <dir-with-*_kernel_stats.csv>  > profiles/rNN_kernel_stats_<tag>.txt
   python tools/summarize_profile.py pmc    <fetch-dir> <write-dir>        > profiles/rNN_hbm_traffic_<tag>.txt
+  python tools/summarize_profile.py sq     <dir> <cell-updates per dispatch>
+pmc and sq look at the dispatches whose kernel name contains PROFILE_KERNEL (environment; default "sweep": the sweep2d /
+sweep3d kernels; "jacobi_fused2d" for the fused double sweep, whose dispatch performs two updates per grid cell).
 
 PMC handling follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are collected in separate
 passes; both are reported by rocprofv3 in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced
@@ -13,6 +16,8 @@ import glob
 import os
 import statistics
 import sys
+
+KERNEL = os.environ.get("PROFILE_KERNEL", "sweep")
 
 
 def find(d, pat):
@@ -33,8 +38,8 @@ def stats(d):
 
 def pmc_values(d, counter):
     rows = list(csv.DictReader(open(find(d, "*_counter_collection.csv"))))
-    vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == counter and "sweep" in r["Kernel_Name"]]
-    names = sorted({r["Kernel_Name"] for r in rows if "sweep" in r["Kernel_Name"]})
+    vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == counter and KERNEL in r["Kernel_Name"]]
+    names = sorted({r["Kernel_Name"] for r in rows if KERNEL in r["Kernel_Name"]})
     return vals, names
 
 
@@ -57,7 +62,7 @@ def pmc(fetch_dir, write_dir):
 def sq(d, cells=8192 * 8192):
     """Mean of every SQ_* counter per sweep dispatch, plus the ratios the design notes quote."""
     rows = list(csv.DictReader(open(find(d, "*_counter_collection.csv"))))
-    rows = [r for r in rows if "sweep" in r["Kernel_Name"]]
+    rows = [r for r in rows if KERNEL in r["Kernel_Name"]]
     names = sorted({r["Counter_Name"] for r in rows})
     mean = {n: statistics.mean(float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == n) for n in names}
     n_disp = len([r for r in rows if r["Counter_Name"] == names[0]]) if names else 0
