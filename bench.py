@@ -409,7 +409,8 @@ def main():
             dist.all_reduce(f)
             free = int(f[0])
         rows_local = solver.hi - solver.lo
-        res = dict(wall=wall, dev_ms=dev_ms, free=free, halo=solver.halo, rows_local=rows_local)
+        res = dict(wall=wall, dev_ms=dev_ms, free=free, halo=solver.halo, rows_local=rows_local,
+                   pairs=bool(getattr(solver.backend, "pairs", False)))
         del solver
         torch.cuda.empty_cache()
         return res
@@ -434,9 +435,15 @@ def main():
             "parallelism": "row slabs x%d (one process per GPU), %d halo rows exchanged every %d sweeps: %s"
                            % (world, r["halo"], r["halo"], transport),
         },
-        # the dominant kernel is one rank's sweep of its slab (rows_local x n cells per launch, ghost rows not counted)
+        # the dominant kernel is one rank's sweep of its slab (rows_local x n cells per iteration, ghost rows not counted);
+        # launch_us here is device time per ITERATION of the whole step (pairs of iterations run as one fused pass where
+        # neither a check nor an exchange falls, the others singly, plus the exchanges)
         "roofline": roofline(r["rows_local"] * n, launch_us, args.math, "jacobi", False),
     })
+    out["roofline"]["kernel"] = ("jacobi_fused2d_kernel (pairs of iterations) + sweep2d_kernel (checks, exchange iterations)"
+                                 if r["pairs"] else "sweep2d_kernel")
+    out["roofline"]["note"] = ("8 B x this rank's owned cells per iteration / mean device time per iteration over the timed steps "
+                               "(HIP events on the compute stream; includes ghost rows, halo exchange waits and check iterations)")
     if world > 1:
         seen = [None] * world
         dist.all_gather_object(seen, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device": local,

@@ -1750,6 +1750,18 @@ int epic_hip_sweep_2d(const float *d_in, float *d_out, const uint32_t *d_maskw, 
                : EPIC_ERROR_KERNEL_EXECUTION;
 }
 
+int epic_hip_sweep2_2d(const float *d_in, float *d_out, const uint32_t *d_maskw, unsigned int rows, unsigned int pitch,
+                       unsigned int rows_per_task, int math_mode, void *stream)
+{
+    if (!d_in || !d_out || !d_maskw || d_in == d_out || rows < 3 || pitch % 256 != 0 || pitch == 0) return EPIC_ERROR_INVALID_DATA;
+    if (math_mode != 4) return EPIC_ERROR_INVALID_DATA;  // the fused pass exists for the tol arithmetic
+    if (rows_per_task == 0) rows_per_task = 24;
+    return epic_hip::launch_jacobi_fused_2d(d_in, d_out, d_maskw, (int)rows, (int)pitch, (int)rows_per_task, math_mode,
+                                            (hipStream_t)stream) == hipSuccess
+               ? EPIC_SUCCESS
+               : EPIC_ERROR_KERNEL_EXECUTION;
+}
+
 int epic_hip_sweep_rb_2d(float *d_u, const uint32_t *d_maskw, unsigned int rows, unsigned int pitch, unsigned int row_begin,
                          unsigned int row_end, unsigned int rows_per_task, int math_mode, int parity,
                          uint32_t *d_delta_bits, void *stream)

@@ -140,6 +140,7 @@ _SIGNATURES = {
                               ct.c_void_p),
     "epic_hip_sweep_2d": (ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_uint,
                           ct.c_uint, ct.c_int, ct.c_void_p, ct.c_void_p),
+    "epic_hip_sweep2_2d": (ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_int, ct.c_void_p),
     "epic_hip_sweep_rb_2d": (ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_int,
                              ct.c_int, ct.c_void_p, ct.c_void_p),
 }

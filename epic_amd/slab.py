@@ -20,8 +20,10 @@ gloo backend (tests/test_slab_gloo.py passes the checker's row sweep).  There is
 backend needs the HIP library and a GPU.
 """
 import ctypes as ct
+import os
 
 import numpy as np
+
 import torch
 import torch.distributed as dist
 
@@ -74,6 +76,7 @@ class HipBackend:
         if self.E.epic_hip_device_count() < 1:
             raise RuntimeError("epic_amd.slab: no HIP device -- the slab solver has no CPU path")
         self.rows_per_task = int(rows_per_task) or (10 if math == "tol" else 16)   # the tol kernel's row loop runs in trips of 10
+        self.rows_per_pair = int(os.environ.get("EPIC_HIP_FUSED_ROWS", "0")) or 24          # task height of the fused double sweep
         modes = {"precise": 0, "fast": 1, "traffic": 2, "tol": 4}
         if math not in modes:
             raise ValueError("epic_amd.slab: unknown math mode %r (one of %s)" % (math, ", ".join(sorted(modes))))
@@ -100,6 +103,18 @@ class HipBackend:
                                       torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             raise RuntimeError("epic_hip_sweep_2d failed: %d" % rc)
+
+    @property
+    def pairs(self):
+        """Whether sweep2() exists for this arithmetic (the fused double sweep: tol math)."""
+        return self.math == 4 and os.environ.get("EPIC_HIP_NO_FUSE") is None
+
+    def sweep2(self, src, dst, maskw, rows, pitch):
+        """Two Jacobi sweeps of all local rows in one pass (src -> dst), bit-identical to two sweep() calls."""
+        rc = self.E.epic_hip_sweep2_2d(src.data_ptr(), dst.data_ptr(), maskw.data_ptr(), rows, pitch, self.rows_per_pair,
+                                       self.math, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("epic_hip_sweep2_2d failed: %d" % rc)
 
     def sweep_rb(self, u, maskw, rows, pitch, row_begin, row_end, parity, delta_bits):
         """One in-place red-black half-sweep of local rows [row_begin, row_end): cells with (row + col + parity) odd."""
@@ -331,6 +346,29 @@ class SlabSolver:
             self.cur ^= 1
         self.iteration += 1
 
+    def can_pair(self):
+        """Two plain Jacobi iterations as ONE pass (backend.sweep2: the fused double sweep of the tol math, 4 B of HBM
+        traffic per cell-update instead of 8): possible when neither of them ends with an exchange -- a pass leaves two
+        more ghost rows stale."""
+        return (not self.redblack and getattr(self.backend, "pairs", False)
+                and (self.world == 1 or self.since + 2 < self.halo))
+
+    def sweep_pair(self):
+        self.backend.sweep2(self.buf[self.cur], self.buf[self.cur ^ 1], self.maskw, self.rows, self.pitch)
+        self.since += 2
+        self.cur ^= 1
+        self.iteration += 2
+
+    def advance(self, budget):
+        """The next iteration -- or the next two as one pass where that is possible and neither is a check iteration --
+        of at most `budget`; returns (iterations done, whether the last one was a check)."""
+        check = self.iteration % self.stagger == 0
+        if not check and budget >= 2 and (self.iteration + 1) % self.stagger != 0 and self.can_pair():
+            self.sweep_pair()
+            return 2, False
+        self.sweep(check)
+        return 1, check
+
     def reduce_delta(self):
         """Global max |du| of the last check sweep (one MAX all-reduce of one float)."""
         t = self.delta_bits.view(torch.float32).clone()
@@ -345,9 +383,10 @@ class SlabSolver:
         """One pass of the reference's driver loop over `stagger` iterations (harmonic_gpu.cu:266-290): a check
         sweep when iteration % stagger == 0, plain sweeps otherwise.  Returns True if the check sweep converged."""
         converged = False
-        for _ in range(self.stagger):
-            check = self.iteration % self.stagger == 0
-            self.sweep(check)
+        left = self.stagger
+        while left > 0:
+            done, check = self.advance(left)
+            left -= done
             if check:
                 converged = self.reduce_delta() < self.epsilon
         return converged
@@ -373,8 +412,8 @@ class SlabSolver:
         last_check, handed_over = -1.0, False
         try:
             while not result or self.iteration < floor:
-                check = self.iteration % self.stagger == 0
-                self.sweep(check)
+                # (an iteration count that must not be passed -- max_sweeps -- bounds a pair as well)
+                _, check = self.advance(2 if max_sweeps is None else max_sweeps - self.iteration)
                 result = (self.reduce_delta() < self.epsilon) if check else False
                 if check:
                     if not self.redblack and not result and self.delta < 1.0 and 0.0 <= last_check <= self.delta:

@@ -135,6 +135,11 @@ int epic_hip_pack_mask_2d(const uint32_t *d_locked, unsigned int rows, unsigned 
 int epic_hip_sweep_2d(const float *d_in, float *d_out, const uint32_t *d_maskw, unsigned int rows,
                       unsigned int pitch, unsigned int row_begin, unsigned int row_end, unsigned int rows_per_task,
                       int math_mode, uint32_t *d_delta_bits, void *stream);
+/* TWO Jacobi sweeps of the whole local grid in one pass (tol math only: math_mode 4): d_out receives what two calls of
+ * epic_hip_sweep_2d over rows [0, rows) -- d_in -> tmp -> d_out -- would leave there, bit for bit, with the field moved
+ * through HBM once.  No delta (check iterations run singly).  In a slab, two more ghost rows go stale. */
+int epic_hip_sweep2_2d(const float *d_in, float *d_out, const uint32_t *d_maskw, unsigned int rows, unsigned int pitch,
+                       unsigned int rows_per_task, int math_mode, void *stream);
 /* The same for the reference's red-black scheme: one in-place half-sweep of rows [row_begin, row_end) of d_u, updating
  * the unlocked cells with (local row + column + parity) odd (libepic/src/harmonic/harmonic_cpu.cpp:46-51 with
  * parity = currentIteration; a slab whose local row 0 is global row `top` passes (currentIteration + top) & 1). */

@@ -121,3 +121,48 @@ def test_redblack_slab_solve_of_a_reference_map_is_the_reference_result(goldens,
     assert all(int(q["iterations"]) == run["iterations"] and float(q["delta"]) == run["delta"] for q in parts)
     field = np.concatenate([p["u"] for p in parts], axis=0)
     assert np.array_equal(field.ravel(), goldens["maps"][name + "/converged_1e-06"])
+
+
+def _tol_worker(rank, world, port, grid, seed, sweeps, halo, out_dir):
+    """The tol arithmetic on slabs through the driver's own loop: fused double sweeps (epic_hip_sweep2_2d) between
+    exchanges and checks, single sweeps on them."""
+    import torch
+    import torch.distributed as dist
+
+    from epic_amd.slab import SlabSolver
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s = SlabSolver(grid, rank, world, device=torch.device("cuda:0"), stagger=10, math="tol", halo=halo)
+        assert s.backend.pairs
+        s.load_synthetic(seed=seed, density=0.06)
+        done, pairs = 0, 0
+        while done < sweeps:
+            k, check = s.advance(sweeps - done)
+            done += k
+            pairs += k == 2
+            if check:
+                s.reduce_delta()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), u=s.owned(), delta=s.delta, pairs=pairs)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,halo", [(1, 8), (2, 8), (3, 4)])
+def test_tol_slabs_with_fused_double_sweeps_equal_the_checker(world, halo, tmp_path):
+    grid, seed, sweeps = [211, 530], 12, 37
+    mp.spawn(_tol_worker, args=(world, _free_port(), grid, seed, sweeps, halo, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    field = np.concatenate([p["u"] for p in parts], axis=0)
+    u0, locked = synthetic_grid(grid, seed, 0.06)
+    lib = O.oracle()
+    p = O.Problem(grid, u0, locked)
+    assert lib.oracle_tol_run(ct.byref(p.h), 31, 0) == 0           # the last check is iteration 30
+    want_delta = float(p.h.delta)
+    assert lib.oracle_tol_run(ct.byref(p.h), sweeps - 31, 0) == 0
+    assert np.array_equal(field.ravel(), p.u)
+    assert all(float(q["delta"]) == want_delta for q in parts)
+    assert all(int(q["pairs"]) >= 8 for q in parts)                 # the passes did run as pairs
