@@ -584,7 +584,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, EPIC_FUSED_MIN_WAVES) void 
     Split4 su[3], sm[3];
     RowMask k[3];
 #pragma unroll
-    for (int x = 0; x < 6; ++x) u[x] = ld(r0 - 2 + x);
+    for (int x = 0; x < 6; ++x) u[x] = ld(min(r0 - 2 + x, r1 + 1));
     k[0] = row_mask(r0 - 1); k[1] = row_mask(r0); k[2] = row_mask(r0 + 1);
     su[0] = tol_split4(u[0]); su[1] = tol_split4(u[1]); su[2] = tol_split4(u[2]);
     m[0] = level(u[0], u[1], u[2], su[0], su[1], su[2], k[0]);   // level A of row r0 - 1
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, EPIC_FUSED_MIN_WAVES) void 
             constexpr int j = decltype(jc)::value;
             if (i + j < nrows) {  // scalar
                 const int r = r0 + i + j;
-                u[j % 6] = ld(r + 4);                                            // slot of row r - 2
+                u[j % 6] = ld(min(r + 4, r1 + 1));   // slot of row r - 2; past r1 + 1 (nothing needs those rows) the last row again: a cache hit
                 su[(j + 1) % 3] = tol_split4(u[(j + 4) % 6]);                    // row r + 2 (slot of row r - 1's split)
                 m[(j + 2) % 3] = level(u[(j + 2) % 6], u[(j + 3) % 6], u[(j + 4) % 6], su[(j + 2) % 3], su[j % 3],
                                        su[(j + 1) % 3], k[(j + 2) % 3]);         // level A of row r + 1
