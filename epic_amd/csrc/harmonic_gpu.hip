@@ -379,8 +379,11 @@ bool fuses_jacobi(const Ctx *c)
     if (getenv("EPIC_HIP_NO_FUSE") != nullptr) return false;
     const char *e = getenv("EPIC_HIP_FUSE_MIN_CELLS");
     const long long min_cells = e ? atoll(e) : (1ll << 22);
-    return !c->redblack && c->n == 2 && !c->track && !c->multi() && c->math == 4 && (long long)c->rows * c->pitch >= min_cells;
+    return !c->redblack && c->n == 2 && !c->track && c->math == 4 && (long long)c->rows * c->pitch >= min_cells;
 }
+// ... and whether the NEXT two can: on several devices a pass leaves two more ghost rows stale, so neither of its two
+// iterations may be one that ends with an exchange.
+bool next_two_fuse(const Ctx *c) { return !c->multi() || c->since + 2 < c->halo; }
 
 // Rows per task of the fused Jacobi pass: a task recomputes the first iteration of one row above and one below its
 // chunk, so longer is cheaper, while the launch should still deal every wave slot several tasks (4 waves per SIMD).
@@ -389,9 +392,12 @@ int jacobi_fused_rows_per_task(const Ctx *c)
     const char *e = getenv("EPIC_HIP_FUSED_ROWS");  // experiment / test knob
     if (e && atoi(e) > 0) return atoi(e);
     const long long nstrips = (c->pitch + 247) / 248;
-    const long long r = (long long)c->rows * nstrips / 16384;   // >= 4 tasks per wave slot (256 CUs x 16 waves): 17 rows at 8192^2 (12 .. 24 time the same, 34 and 48 are 1-3 % slower)
+    const long long rows = c->multi() ? c->rows / (long long)c->slabs.size() : c->rows;   // per device
+    const long long r = rows * nstrips / 16384;   // >= 4 tasks per wave slot (256 CUs x 16 waves): 17 rows at 8192^2 (12 .. 24 time the same, 34 and 48 are 1-3 % slower)
     return (int)std::min<long long>(48, std::max<long long>(8, r));   // (4096^2: 8 rows 29.4 us per iteration, 4 rows 30.9)
 }
+
+hipError_t multi_sweep_pair(Ctx *c);
 
 hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
 {
@@ -403,13 +409,22 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
     // Jacobi, tol math, 2-D: two consecutive plain iterations run as one pass as well (kernels_2d.hip,
     // jacobi_fused2d_kernel: 4 B of HBM traffic per cell-update instead of 8, bit-identical to two sweeps).
     // EPIC_HIP_FUSE_MIN_CELLS: grids below it keep the single sweeps (default 4 Mcell; the tests set 0).
-    const bool fuse_jacobi = !no_fuse && fuses_jacobi(c);
-    while (fuse_jacobi && count - i >= 2) {
-        hipError_t e = epic_hip::launch_jacobi_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch,
-                                                        jacobi_fused_rows_per_task(c), c->math, c->stream);
-        if (e != hipSuccess) return e;
-        c->cur ^= 1;
-        i += 2;
+    if (!no_fuse && fuses_jacobi(c)) {
+        while (i < count) {
+            if (count - i >= 2 && next_two_fuse(c)) {
+                hipError_t e = c->multi() ? multi_sweep_pair(c)
+                                          : epic_hip::launch_jacobi_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows,
+                                                                             c->pitch, jacobi_fused_rows_per_task(c), c->math, c->stream);
+                if (e != hipSuccess) return e;
+                if (!c->multi()) c->cur ^= 1;
+                i += 2;
+            } else {
+                hipError_t e = enqueue_sweep(c, false, first + i);
+                if (e != hipSuccess) return e;
+                i++;
+            }
+        }
+        return hipSuccess;
     }
     while (fuse && count - i >= 2) {
         hipError_t e = epic_hip::launch_rb_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch,
@@ -818,6 +833,23 @@ hipError_t multi_sweep(Ctx *c, bool check, unsigned iteration)
         c->since++;
     }
     if (!c->redblack) c->cur ^= 1;
+    return hipSuccess;
+}
+
+// Two plain Jacobi iterations of every slab as one fused pass (tol math; jacobi_fused2d_kernel), no exchange: the caller
+// has checked next_two_fuse().  Ghost rows are swept like owned rows, two more of them are stale afterwards.
+hipError_t multi_sweep_pair(Ctx *c)
+{
+    DeviceGuard g;
+    const int rpt = jacobi_fused_rows_per_task(c);
+    for (auto &sl : c->slabs) {
+        hipError_t e = hipSetDevice(sl.dev);
+        if (e == hipSuccess)
+            e = epic_hip::launch_jacobi_fused_2d(sl.buf[c->cur], sl.buf[c->cur ^ 1], sl.maskw, sl.rows, c->pitch, rpt, c->math, sl.stream);
+        if (e != hipSuccess) return e;
+    }
+    c->since += 2;
+    c->cur ^= 1;
     return hipSuccess;
 }
 
@@ -1462,11 +1494,18 @@ int epic_hip_timed_sweeps_gpu(Harmonic *harmonic, unsigned int sweeps, unsigned 
         unsigned done = 0;
         while (done < sweeps && rc == EPIC_SUCCESS) {
             const unsigned it = harmonic->currentIteration;
-            const bool check = check_every && it % check_every == 0;
-            if (enqueue_sweep(c, check, it) != hipSuccess) rc = EPIC_ERROR_KERNEL_EXECUTION;
-            checked = checked || check;
-            harmonic->currentIteration++;
-            done++;
+            if (check_every && it % check_every == 0) {
+                if (enqueue_sweep(c, true, it) != hipSuccess) rc = EPIC_ERROR_KERNEL_EXECUTION;
+                checked = true;
+                harmonic->currentIteration++;
+                done++;
+            } else {
+                unsigned run = sweeps - done;
+                if (check_every) run = std::min(run, check_every - it % check_every);
+                if (enqueue_plain_run(c, run, it) != hipSuccess) rc = EPIC_ERROR_KERNEL_EXECUTION;
+                harmonic->currentIteration += run;
+                done += run;
+            }
         }
         if (rc != EPIC_SUCCESS) report(fn, "Failed to execute the 'update' kernel.");
         harmonic->d_u = current_u(c);

@@ -143,6 +143,14 @@ def test_tol_iterations_equal_the_checker(devices, m, seed, dens, rpt):
     T.test_tol_iterations_equal_the_checker_bit_for_bit(m, seed, dens, rpt, eh.SCHEME_JACOBI)
 
 
+@pytest.mark.parametrize("m,seed,dens", [g for g in T.FUSED_GRIDS if g[0] in ([211, 530], [257, 513], [1200, 3000])])
+@pytest.mark.parametrize("rows", [0, 7])
+def test_tol_fused_pairs_on_slabs_equal_the_checker(every_list, m, seed, dens, rows, monkeypatch):
+    """Pairs of plain iterations as one fused pass per slab wherever neither iteration ends with an exchange (a pass leaves
+    two more ghost rows stale): every device list, ghost depths 1 (never a pair), 3, 8."""
+    T.test_tol_fused_double_sweeps_equal_the_checker_bit_for_bit(m, seed, dens, rows, monkeypatch)
+
+
 def test_full_size_8192_window_property(devices):
     P.test_full_size_8192_window_property()
 
