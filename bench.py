@@ -57,7 +57,10 @@ def parse():
                          "cell shared by its neighbours (tolerance parity mode); fast = v_exp_f32/v_log_f32")
     ap.add_argument("--scheme", choices=("jacobi", "redblack"), default="jacobi",
                     help="jacobi = ping-pong sweep of every cell (default); redblack = the reference's in-place half-sweeps")
-    ap.add_argument("--halo", type=int, default=8, help="N > 1: ghost rows per side = sweeps between two halo exchanges")
+    ap.add_argument("--halo", type=int, default=0,
+                    help="N > 1: ghost rows per side = sweeps between two halo exchanges (0 = by slab height: 8 from 4096 rows per "
+                         "GPU up, 16 from 2048, 32 below -- an exchange costs a fixed few tens of microseconds, a sweep of a short "
+                         "slab only ~15, and 2 x halo extra rows per slab are cheap)")
     ap.add_argument("--slab", action="store_true", help="use the slab-decomposition driver even on one GPU")
     ap.add_argument("--strong", action="store_true", help="(default for N > 1; kept for older command lines)")
     ap.add_argument("--weak", action="store_true",
@@ -389,8 +392,10 @@ def main():
     from epic_amd.slab import SlabSolver
 
     def slab_run(grid, steps, warmup):
+        rows_each = grid[0] // world
+        halo = args.halo or (8 if rows_each >= 4096 else 16 if rows_each >= 2048 else 32)
         solver = SlabSolver(grid, rank, world, device=torch.device("cuda", local), stagger=args.stagger,
-                            rows_per_task=args.rows_per_task, math=args.math, halo=args.halo)
+                            rows_per_task=args.rows_per_task, math=args.math, halo=halo)
         free = solver.load_synthetic()
         for _ in range(develop):
             solver.sweep(False)

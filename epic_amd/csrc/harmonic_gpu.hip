@@ -90,7 +90,8 @@ struct Ctx {
     };
     std::vector<Slab> slabs;
     std::vector<int> devices;      // EPIC_HIP_DEVICES as given (validated); fewer than 2 entries: single-device mode
-    int halo = 8, since = 0;       // ghost rows per interior side (EPIC_HIP_HALO); iterations since the last exchange
+    int halo = 8, since = 0;       // ghost rows per interior side in use; iterations since the last exchange
+    int halo_env = 0;              // EPIC_HIP_HALO (0 = not given: chosen by slab height in multi_plan)
     bool multi() const { return !slabs.empty(); }
     size_t u_bytes() const { return (size_t)rows * pitch * sizeof(float); }
     size_t mask_bytes() const
@@ -196,7 +197,7 @@ Ctx *get_ctx(Harmonic *h, bool create)
     e = getenv("EPIC_HIP_TRACK");
     if (e && (strcmp(e, "0") == 0 || strcmp(e, "1") == 0)) c->track_mode = atoi(e);
     e = getenv("EPIC_HIP_HALO");
-    if (e && atoi(e) >= 1) c->halo = atoi(e);
+    if (e && atoi(e) >= 1) c->halo_env = atoi(e);
     e = getenv("EPIC_HIP_DEVICES");
     if (e && *e) {  // "0,1,2,3"; a device may be named more than once ("0,0,0,0": four slabs on one GPU)
         int ndev = 0;
@@ -385,16 +386,13 @@ bool fuses_jacobi(const Ctx *c)
 // iterations may be one that ends with an exchange.
 bool next_two_fuse(const Ctx *c) { return !c->multi() || c->since + 2 < c->halo; }
 
-// Rows per task of the fused Jacobi pass: a task recomputes the first iteration of one row above and one below its
-// chunk, so longer is cheaper, while the launch should still deal every wave slot several tasks (4 waves per SIMD).
+// Rows per task of the fused Jacobi pass (kernels.h: jacobi_fused_auto_rows), per device in multi-device mode.
 int jacobi_fused_rows_per_task(const Ctx *c)
 {
     const char *e = getenv("EPIC_HIP_FUSED_ROWS");  // experiment / test knob
     if (e && atoi(e) > 0) return atoi(e);
-    const long long nstrips = (c->pitch + 247) / 248;
-    const long long rows = c->multi() ? c->rows / (long long)c->slabs.size() : c->rows;   // per device
-    const long long r = rows * nstrips / 16384;   // >= 4 tasks per wave slot (256 CUs x 16 waves): 17 rows at 8192^2 (12 .. 24 time the same, 34 and 48 are 1-3 % slower)
-    return (int)std::min<long long>(48, std::max<long long>(8, r));   // (4096^2: 8 rows 29.4 us per iteration, 4 rows 30.9)
+    const long long rows = c->multi() ? c->rows / (long long)c->slabs.size() : c->rows;
+    return epic_hip::jacobi_fused_auto_rows((int)rows, c->pitch);
 }
 
 hipError_t multi_sweep_pair(Ctx *c);
@@ -643,7 +641,10 @@ bool multi_plan(Ctx *c)
     if (!c->slabs.empty()) multi_destroy(c);
     DeviceGuard g;
     const int base = c->rows / want, rem = c->rows % want;
-    const int halo = std::max(1, std::min(c->halo, base / 2));
+    // ghost depth G = iterations between two exchanges: an exchange costs a fixed few tens of microseconds while a sweep of
+    // a short slab takes ~15, and 2 G extra rows per slab are cheap -- 8 from 4096 rows per device up, 16 from 2048, 32 below
+    const int want_halo = c->halo_env > 0 ? c->halo_env : base >= 4096 ? 8 : base >= 2048 ? 16 : 32;
+    const int halo = std::max(1, std::min(want_halo, base / 2));
     int lo = 0;
     c->slabs.resize(want);
     for (int k = 0; k < want; k++) {
@@ -1794,7 +1795,7 @@ int epic_hip_sweep2_2d(const float *d_in, float *d_out, const uint32_t *d_maskw,
 {
     if (!d_in || !d_out || !d_maskw || d_in == d_out || rows < 3 || pitch % 256 != 0 || pitch == 0) return EPIC_ERROR_INVALID_DATA;
     if (math_mode != 4) return EPIC_ERROR_INVALID_DATA;  // the fused pass exists for the tol arithmetic
-    if (rows_per_task == 0) rows_per_task = 24;
+    if (rows_per_task == 0) rows_per_task = (unsigned)epic_hip::jacobi_fused_auto_rows((int)rows, (int)pitch);
     return epic_hip::launch_jacobi_fused_2d(d_in, d_out, d_maskw, (int)rows, (int)pitch, (int)rows_per_task, math_mode,
                                             (hipStream_t)stream) == hipSuccess
                ? EPIC_SUCCESS

@@ -75,6 +75,17 @@ hipError_t launch_follow_paths_2d(const float *u, const uint32_t *maskw, int row
 #endif
 constexpr int kTolRowsAhead = EPIC_TOL_AHEAD;
 constexpr int kTolTripRows = (kTolRowsAhead + 3) % 2 == 0 ? kTolRowsAhead + 3 : 2 * (kTolRowsAhead + 3);
+// Rows per task of the fused double sweep (jacobi_fused2d_kernel) for a grid -- or a slab -- of `rows` rows: a task
+// recomputes the first iteration of one row above and one below its chunk, so taller is cheaper, while the launch should
+// deal every wave slot (256 CUs x 16 waves) about four tasks.  Measured, us per iteration at 4 / 8 / 12 / 16 / 24 / 32
+// rows: 1024 x 8192 16.8 / 17.6 / 16.0 / 19.8 / 22.0 / 27.7; 2048 x 8192 30.1 / 28.2 / 28.0 / 30.3 / 28.8 / 36.2;
+// 4096 x 8192 56.3 / 50.0 / 50.0 / 49.6 / 50.6 / 55.8; 8192^2: 12 .. 24 time the same, 34 and 48 are 1-3 % slower.
+inline int jacobi_fused_auto_rows(int rows, int pitch)
+{
+    const long long nstrips = (pitch + 247) / 248;
+    const long long r = (long long)rows * nstrips / 16384;
+    return (int)(r < 12 ? 12 : r > 48 ? 48 : r);
+}
 // rows are padded to whole wave-strips (256 floats = 1 KiB): every lane of every wave is in bounds, always
 inline int pitch_for_cols(int cols) { return (cols + 255) / 256 * 256; }
 // 2-D mask layout (device-private): LANE MASKS.  For every row and every 256-column strip four 64-bit words, word j

@@ -76,7 +76,7 @@ class HipBackend:
         if self.E.epic_hip_device_count() < 1:
             raise RuntimeError("epic_amd.slab: no HIP device -- the slab solver has no CPU path")
         self.rows_per_task = int(rows_per_task) or (10 if math == "tol" else 16)   # the tol kernel's row loop runs in trips of 10
-        self.rows_per_pair = int(os.environ.get("EPIC_HIP_FUSED_ROWS", "0")) or 24          # task height of the fused double sweep
+        self.rows_per_pair = int(os.environ.get("EPIC_HIP_FUSED_ROWS", "0"))   # task height of the fused double sweep; 0 = the library's rule for the slab's size
         modes = {"precise": 0, "fast": 1, "traffic": 2, "tol": 4}
         if math not in modes:
             raise ValueError("epic_amd.slab: unknown math mode %r (one of %s)" % (math, ", ".join(sorted(modes))))

@@ -111,7 +111,8 @@ int epic_hip_eval_math(const float *d_in, float *d_out, size_t n, int which, voi
  * point work on ONE 2-D grid cut into one row slab per listed device, in this process: harmonic_complete_gpu(&h, 1024) --
  * the ROS plugin's only call, /root/reference/src/epic_nav_core_plugin.cpp:256 -- then uses the whole node.  The reference
  * has nothing like it (libepic/src/harmonic/harmonic_gpu.cu:168-201 drives one device).  A device may be listed more than
- * once ("0,0,0,0": four slabs on one GPU).  EPIC_HIP_HALO=G (default 8): ghost rows per interior side, traded every G
+ * once ("0,0,0,0": four slabs on one GPU).  EPIC_HIP_HALO=G (default by slab height: 8 from 4096 rows per device up, 16 from
+ * 2048, 32 below): ghost rows per interior side, traded every G
  * iterations with hipMemcpyPeerAsync; results are bit-identical to the single-device path for every list and every G.
  * 3-D grids, grids with fewer than 4 rows per listed device and an unusable list fall back to one device.  Activity
  * tracking is off and the device streamline walk unavailable in this mode.
@@ -137,7 +138,8 @@ int epic_hip_sweep_2d(const float *d_in, float *d_out, const uint32_t *d_maskw, 
                       int math_mode, uint32_t *d_delta_bits, void *stream);
 /* TWO Jacobi sweeps of the whole local grid in one pass (tol math only: math_mode 4): d_out receives what two calls of
  * epic_hip_sweep_2d over rows [0, rows) -- d_in -> tmp -> d_out -- would leave there, bit for bit, with the field moved
- * through HBM once.  No delta (check iterations run singly).  In a slab, two more ghost rows go stale. */
+ * through HBM once.  No delta (check iterations run singly).  In a slab, two more ghost rows go stale.
+ * rows_per_task = 0: the library's choice for this size. */
 int epic_hip_sweep2_2d(const float *d_in, float *d_out, const uint32_t *d_maskw, unsigned int rows, unsigned int pitch,
                        unsigned int rows_per_task, int math_mode, void *stream);
 /* The same for the reference's red-black scheme: one in-place half-sweep of rows [row_begin, row_end) of d_u, updating
