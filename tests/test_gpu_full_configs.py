@@ -160,3 +160,37 @@ def test_config4_32768_squared_window_property_one_gpu():
             lo, hi = max(c - W, r0) - r0, min(c + W, r0 + 2048) - r0
             same[lo:hi, c - W:c + W] = True
         assert same.all(), f"rows {r0}..{r0 + 2047}: a cell outside the goal's reach has moved"
+
+
+def test_config4_32768_squared_fused_tol_pairs_window_property():
+    """The same grid with the benchmarked arithmetic and kernel: tol math, activity tracking off, so that the 15 plain
+    iterations behind the check run as seven fused double sweeps (jacobi_fused2d_kernel: 133 strips of 248 columns, byte
+    offsets up to 4.3 GB) and one single sweep.  Window around the goal against the tol checker on the window alone,
+    everything else still at its seed."""
+    n, K, W = 32768, 16, 64
+    m = [n, n]
+    u0, locked = _synthetic_big(m)
+    c = n // 2
+    win = (slice(c - W, c + W), slice(c - W, c + W))
+    p = O.Problem([2 * W, 2 * W], u0.reshape(m)[win].copy(), locked.reshape(m)[win].copy())
+    assert O.oracle().oracle_tol_run(ct.byref(p.h), 1, 0) == 0       # the check is the first iteration
+    wdelta = float(p.h.delta)
+    assert O.oracle().oracle_tol_run(ct.byref(p.h), K - 1, 0) == 0
+    h = make(m, u0, locked)
+    gpu_init(h)
+    assert E.epic_hip_set_math_mode(h, eh.MATH_TOL) == 0 and E.epic_hip_set_activity_tracking(h, 0) == 0
+    assert E.epic_hip_iterations_per_pass(h) == 2
+    assert E.harmonic_update_and_check_gpu(h, NT) in (0, 1)
+    assert float(h.delta) == wdelta
+    assert E.epic_hip_update_n_gpu(h, K - 1, 0) == 0
+    assert E.harmonic_get_potential_values_gpu(h) == 0
+    gpu_fini(h)
+    got = h.u_array().reshape(m)
+    assert np.array_equal(got[win].ravel(), p.u)
+    u0 = u0.reshape(m)
+    for r0 in range(0, n, 2048):
+        same = got[r0:r0 + 2048] == u0[r0:r0 + 2048]
+        if r0 <= c < r0 + 2048 or r0 <= c - W < r0 + 2048 or r0 <= c + W - 1 < r0 + 2048:
+            lo, hi = max(c - W, r0) - r0, min(c + W, r0 + 2048) - r0
+            same[lo:hi, c - W:c + W] = True
+        assert same.all(), f"rows {r0}..{r0 + 2047}: a cell outside the goal's reach has moved"
