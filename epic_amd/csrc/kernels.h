@@ -75,16 +75,35 @@ hipError_t launch_follow_paths_2d(const float *u, const uint32_t *maskw, int row
 #endif
 constexpr int kTolRowsAhead = EPIC_TOL_AHEAD;
 constexpr int kTolTripRows = (kTolRowsAhead + 3) % 2 == 0 ? kTolRowsAhead + 3 : 2 * (kTolRowsAhead + 3);
-// Rows per task of the fused double sweep (jacobi_fused2d_kernel) for a grid -- or a slab -- of `rows` rows: a task
-// recomputes the first iteration of one row above and one below its chunk, so taller is cheaper, while the launch should
-// deal every wave slot (256 CUs x 16 waves) about four tasks.  Measured, us per iteration at 4 / 8 / 12 / 16 / 24 / 32
-// rows: 1024 x 8192 16.8 / 17.6 / 16.0 / 19.8 / 22.0 / 27.7; 2048 x 8192 30.1 / 28.2 / 28.0 / 30.3 / 28.8 / 36.2;
-// 4096 x 8192 56.3 / 50.0 / 50.0 / 49.6 / 50.6 / 55.8; 8192^2: 12 .. 24 time the same, 34 and 48 are 1-3 % slower.
+// Rows per task of the fused double sweep (jacobi_fused2d_kernel) for a grid -- or a slab -- of `rows` rows.  A task
+// recomputes the first iteration of one row above and one below its chunk, so taller is cheaper; the chip holds 4096 of
+// these waves at a time (256 CUs x 16), and a launch whose tasks fill a whole number of such rounds wastes no tail: the
+// height is chosen so that the tasks come to just under k x 4096 for the k = 2 .. 8 that fills its last round best
+// (8192^2: 23 rows, 357 x 34 tasks = 2.96 rounds -- 97.4-98.0 us per iteration against 100.0 at 17 rows = 4.001 rounds,
+// 101 at 18, 29, 36, same box).  Short grids (slabs): one round, at least 12 rows -- measured, us per iteration at 4 / 8 /
+// 12 / 16 / 24 / 32 rows: 1024 x 8192 16.8 / 17.6 / 16.0 / 19.8 / 22.0 / 27.7; 2048 x 8192 30.1 / 28.2 / 28.0 / 30.3 /
+// 28.8 / 36.2 (18: 27.7); 4096 x 8192 56.3 / 50.0 / 50.0 / 49.6 / 50.6 / 55.8 (18: 49.9).  Many rounds: 24.
 inline int jacobi_fused_auto_rows(int rows, int pitch)
 {
-    const long long nstrips = (pitch + 247) / 248;
-    const long long r = (long long)rows * nstrips / 16384;
-    return (int)(r < 12 ? 12 : r > 48 ? 48 : r);
+    const long long nstrips = (pitch + 247) / 248, slots = 4096;
+    int best = 0;
+    double best_fill = 0.0;
+    for (int k = 2; k <= 8; ++k) {
+        const long long chunks_max = k * slots / nstrips;
+        if (chunks_max < 1) continue;
+        const int r = (int)((rows + chunks_max - 1) / chunks_max);
+        if (r < 12 || r > 40) continue;
+        const long long tasks = ((rows + r - 1) / r) * nstrips;
+        const double fill = (double)tasks / (double)(k * slots);
+        if (fill > best_fill) { best_fill = fill; best = r; }
+    }
+    if (best) return best;
+    if ((long long)rows * nstrips / 12 <= 2 * slots) {  // short: one round
+        const long long chunks_max = slots / nstrips > 0 ? slots / nstrips : 1;
+        const long long r = (rows + chunks_max - 1) / chunks_max;
+        return (int)(r < 12 ? 12 : r > 40 ? 40 : r);
+    }
+    return 24;
 }
 // rows are padded to whole wave-strips (256 floats = 1 KiB): every lane of every wave is in bounds, always
 inline int pitch_for_cols(int cols) { return (cols + 255) / 256 * 256; }
