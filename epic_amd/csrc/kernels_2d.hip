@@ -17,7 +17,7 @@
 //  * Rows are addressed through buffer descriptors with the row / strip part of the address in an SGPR: loads and
 //    stores cost no VALU instruction either.  The kernel is bound by VALU issue, so every instruction that is not
 //    arithmetic of the update was moved to the scalar unit (precise math: 70 VALU instructions per cell, 41 of them f64 /
-//    conversions; tol math: 43 -- profiles/r02_sq_counters_*.txt).
+//    conversions; tol math: 41 -- profiles/r02_sq_counters_*.txt).
 //  * max |u_new - u_old| is reduced in registers, across the wave with shuffles, and leaves the wave as a
 //    single atomicMax on the float's bit pattern (valid order for non-negative floats).  No second kernel.
 //  * blockIdx is remapped so that each XCD sweeps a contiguous band of rows: vertically adjacent tasks share
@@ -30,7 +30,9 @@
 // fast math (v_exp_f32 / v_log_f32) the kernel stays there; with the default precise math (expf / logf bit-identical to
 // glibc, evaluated in f64) it is bound by VALU issue: 41 f64 / conversion instructions per cell plus 29 others at ~4
 // cycles per wave each, 138-146 us; with the tol math (one split per cell shared by its neighbours, cell_update.h) both
-// pipes are nearly full: 107-109 us = 0.62 of 8 TB/s.
+// pipes are nearly full: 107-109 us = 0.62 of 8 TB/s -- which is why pairs of plain tol
+// iterations run through jacobi_fused2d_kernel below instead: two iterations per pass over the field, 4 B per
+// cell-update, VALU-bound at 0.67-0.70 (section 4.2b).  rb_fused2d_kernel is its red-black counterpart (precise / fast math).
 #include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
