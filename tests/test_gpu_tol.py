@@ -134,6 +134,48 @@ def test_tol_fused_double_sweeps_equal_the_checker_bit_for_bit(m, seed, dens, ro
             assert gdelta == wdelta
 
 
+def test_tol_fused_pairs_with_live_edits_and_model_updates(monkeypatch):
+    """The navigation node's flow (src/epic_navigation_node_harmonic.cpp:165-189, :357-380) with the fused passes forced on:
+    update(k) batches (a check, then k - 1 plain iterations = pairs and an odd one), live cell edits on the resident state
+    between batches -- the edit lands in the buffer the last pass wrote, whichever of the two that is --, readback, then a
+    re-uploaded model."""
+    monkeypatch.setenv("EPIC_HIP_FUSE_MIN_CELLS", "0")
+    UP = ct.POINTER(ct.c_uint)
+    m = [48, 300]
+    u0, locked = synthetic_grid(m, 3, 0.05)
+    h = make(m, u0, locked)
+    gpu_init(h)
+    assert E.epic_hip_set_activity_tracking(h, 0) == 0 and E.epic_hip_iterations_per_pass(h) == 2
+    p = O.Problem(m, u0, locked)
+    lib = O.oracle()
+
+    def batch(k):
+        assert E.harmonic_update_and_check_gpu(h, NT) in (0, 1)
+        assert E.epic_hip_update_n_gpu(h, k - 1, 0) == 0
+        assert lib.oracle_tol_run(ct.byref(p.h), k, 0) == 0
+
+    for k, edits in ((10, [(250, 40, 0), (10, 5, 1)]), (25, [(251, 40, 1), (10, 5, 2), (200, 20, 0)]), (8, [(30, 30, 1)]), (13, [])):
+        batch(k)
+        assert E.harmonic_get_potential_values_gpu(h) == 0
+        assert np.array_equal(h.u_array().ravel(), p.u), f"after a batch of {k}"
+        if edits:
+            v = np.array([[x, y] for x, y, _ in edits], dtype=np.uint32)
+            t = np.array([ty for _, _, ty in edits], dtype=np.uint32)
+            args = (len(t), v.ctypes.data_as(UP), t.ctypes.data_as(UP))
+            assert E.harmonic_utilities_set_cells_2d_cpu(h, *args) == 0
+            assert E.harmonic_utilities_set_cells_2d_gpu(h, NT, *args) == 0
+            assert lib.oracle_set_cells_2d(ct.byref(p.h), *args) == 0
+    h.u_array().ravel()[:] = u0
+    h.locked_array().ravel()[:] = locked
+    assert E.harmonic_update_model_gpu(h) == 0
+    assert E.epic_hip_set_math_mode(h, eh.MATH_TOL) == 0
+    want, wdelta = checker_iterations(m, u0, locked, 7, eh.SCHEME_JACOBI)
+    assert E.epic_hip_update_n_gpu(h, 7, 1) in (0, 1)
+    assert E.harmonic_get_potential_values_gpu(h) == 0
+    assert np.array_equal(h.u_array().ravel(), want) and float(h.delta) == wdelta
+    gpu_fini(h)
+
+
 @pytest.mark.parametrize("m,rpt", [([66000, 300], 0), ([6, 80000], 0), ([1200, 9000], 60), ([40000, 520], 5), ([33, 257], 4)])
 def test_tol_extreme_aspect_ratios(m, rpt):
     u0, locked = synthetic_grid(m, 17, 0.05)
