@@ -29,9 +29,16 @@ UP = ct.POINTER(ct.c_uint)
 
 ALL_LISTS = [("0,0", "8"), ("0,0,0,0", "3"), ("0,0,0", "1"), ("0,0,0,0,0,0,0,0", "8")]
 ALL_IDS = ["2slabs_halo8", "4slabs_halo3", "3slabs_halo1", "8slabs_halo8"]
+# On a node with several GPUs the same tests also run with one slab per REAL device (hipMemcpyPeerAsync between devices,
+# per-device streams and events): every device once, and every device twice interleaved ("0,1,0,1"...).
+_NDEV = E.epic_hip_device_count()
+if _NDEV >= 2:
+    _real = ",".join(str(d) for d in range(min(_NDEV, 8)))
+    ALL_LISTS += [(_real, "8"), (_real + "," + _real, "3")]
+    ALL_IDS += ["%ddevices_halo8" % min(_NDEV, 8), "%ddevices_twice_halo3" % min(_NDEV, 8)]
 
 
-@pytest.fixture(params=ALL_LISTS[1::2], ids=ALL_IDS[1::2])
+@pytest.fixture(params=ALL_LISTS[1:4:2] + ALL_LISTS[4:], ids=ALL_IDS[1:4:2] + ALL_IDS[4:])
 def devices(request):
     """Most tests run with 4 slabs / 3 ghost rows and 8 slabs / 8 ghost rows; test_fixed_sweeps_equal_the_checker takes
     every list (2 and 3 slabs, the one-row halo of the north star's wording included)."""

@@ -166,3 +166,61 @@ def test_tol_slabs_with_fused_double_sweeps_equal_the_checker(world, halo, tmp_p
     assert np.array_equal(field.ravel(), p.u)
     assert all(float(q["delta"]) == want_delta for q in parts)
     assert all(int(q["pairs"]) >= 8 for q in parts)                 # the passes did run as pairs
+
+
+def _rccl_worker(rank, world, port, grid, seed, sweeps, halo, math, out_dir):
+    """One rank per GPU, RCCL send/recv of device rows: the branch of epic_amd/slab.py::_exchange a 1-GPU box never takes."""
+    import torch
+    import torch.distributed as dist
+
+    from epic_amd.slab import SlabSolver
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        s = SlabSolver(grid, rank, world, device=torch.device("cuda", rank), stagger=10, math=math, halo=halo)
+        s.load_synthetic(seed=seed, density=0.06)
+        done = 0
+        while done < sweeps:
+            k, check = s.advance(sweeps - done)
+            done += k
+            if check:
+                s.reduce_delta()
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), u=s.owned(), delta=s.delta)
+    finally:
+        dist.destroy_process_group()
+
+
+def _gpus():
+    import torch
+
+    return torch.cuda.device_count()
+
+
+@pytest.mark.multi_gpu
+@pytest.mark.parametrize("halo,math", [(1, "precise"), (8, "precise"), (8, "tol"), (3, "tol")])
+def test_rccl_slabs_one_rank_per_gpu_equal_single_domain(halo, math, tmp_path):
+    """Needs at least two GPUs (skipped on the 1-GPU boxes of this project; the driver's multi-GPU node runs it): 2 .. 4
+    ranks, one per device, halo rows over RCCL on the second stream while the interior is swept; 37 iterations at stagger
+    10, so checks fall on and off exchange iterations.  Bit-identical to the single domain, delta of the last check
+    included."""
+    ndev = _gpus()
+    if ndev < 2:
+        pytest.skip("needs >= 2 GPUs")
+    world = min(ndev, 4)
+    grid, seed, sweeps = [421, 1030], 12, 37
+    mp.spawn(_rccl_worker, args=(world, _free_port(), grid, seed, sweeps, halo, math, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    field = np.concatenate([p["u"] for p in parts], axis=0)
+    u0, locked = synthetic_grid(grid, seed, 0.06)
+    lib = O.oracle()
+    p = O.Problem(grid, u0, locked)
+    run = (lambda k: lib.oracle_tol_run(ct.byref(p.h), k, 0)) if math == "tol" else (lambda k: lib.oracle_jacobi_run(ct.byref(p.h), k))
+    assert run(31) == 0
+    want_delta = float(p.h.delta)
+    assert run(sweeps - 31) == 0
+    assert np.array_equal(field.ravel(), p.u)
+    assert all(float(q["delta"]) == want_delta for q in parts)
