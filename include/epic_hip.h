@@ -58,7 +58,8 @@ int epic_hip_set_rows_per_task(EpicHarmonicT *harmonic, unsigned int rows_per_ta
  *                        neighbour of, one f64 log per cell; every rounding stage of the reference kept.  2-D and 3-D,
  *                        Jacobi and red-black.  Jacobi stops by the reference's own test; converged fields within
  *                        1e-5 max(1, |u|) of the reference's on its seeded grids, basic.png and maze.png, 1.6e-5 on the
- *                        ill-conditioned umass.png.  ~1.3x faster per sweep than precise (the benchmarked mode);
+ *                        ill-conditioned umass.png.  ~1.35x faster per sweep than precise, ~1.5x where pairs of
+ *                        iterations run as one fused pass (epic_hip_iterations_per_pass); the benchmarked mode;
  *   1 fast               v_exp_f32 / v_log_f32: biased, ~1e-4 relative drift on ill-conditioned maps; no parity claim;
  *   2 traffic            diagnostic: same loads/stores, trivial arithmetic (2-D only).
  * (3 was round 1's df32 mode, removed: EPIC_ERROR_INVALID_DATA.) */
