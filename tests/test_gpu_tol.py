@@ -278,3 +278,30 @@ def test_tol_jacobi_and_redblack_end_in_the_same_field(goldens, tol_env):
     err = np.abs(a.astype(np.float64) - b) / np.maximum(1.0, np.abs(b))
     assert err.max() <= 2e-6, float(err.max())
     print("tol basic.png: Jacobi vs red-black fields differ in %d cells, max rel %.2e" % (int((a != b).sum()), err.max()))
+
+
+def test_execute_bypasses_the_work_lists_while_most_tiles_are_due_with_identical_results(tol_env, monkeypatch):
+    """harmonic_execute_gpu with tracking in its automatic mode (grids above 4 Mcell): after every check it looks at the
+    share of tiles due next and runs the following batch without the lists -- as fused pairs -- when that share is above
+    EPIC_HIP_TRACK_SWITCH (default 0.8), rebuilding the lists with two full iterations afterwards.  Whatever the
+    threshold -- never (2), default, always (0) -- and with tracking off altogether, field, iteration count and delta are
+    the same bits."""
+    m = [2112, 2112]
+    u0, locked = synthetic_grid(m, 11, 0.05)
+    results = []
+    for switch, track in (("2", 2), ("0.8", 2), ("0", 2), ("2", 0)):
+        monkeypatch.setenv("EPIC_HIP_TRACK_SWITCH", switch)
+        h = make(m, u0, locked)
+        for fn in (E.harmonic_initialize_dimension_size_gpu, E.harmonic_initialize_potential_values_gpu,
+                   E.harmonic_initialize_locked_gpu):
+            assert fn(h) == 0
+        assert E.epic_hip_set_activity_tracking(h, track) == 0
+        assert E.harmonic_execute_gpu(h, NT) == 0
+        for fn in (E.harmonic_uninitialize_dimension_size_gpu, E.harmonic_uninitialize_potential_values_gpu,
+                   E.harmonic_uninitialize_locked_gpu):
+            assert fn(h) == 0
+        results.append((h.u_array().ravel().copy(), int(h.currentIteration), float(h.delta)))
+    u, it, d = results[0]
+    assert it > 2000 and d < 1e-6
+    for v, it2, d2 in results[1:]:
+        assert it2 == it and d2 == d and np.array_equal(v, u)
