@@ -334,7 +334,7 @@ def main():
             # the complete relaxation, exactly as the plugin runs it (harmonic_execute_gpu), from the initial state: with the
             # benchmarked scheme (library default: activity tracking on), with the other scheme, and with tracking off
             other = "redblack" if args.scheme == "jacobi" else "jacobi"
-            for scheme, track in ((args.scheme, 1), (other, 1), (args.scheme, 0)):
+            for scheme, track in ((args.scheme, 2), (other, 2), (args.scheme, 0)):   # 2 = the library's automatic mode
                 h.u_array().ravel()[:] = u0
                 assert E.harmonic_update_model_gpu(h) == 0
                 assert E.epic_hip_set_scheme(h, 1 if scheme == "redblack" else 0) == 0
