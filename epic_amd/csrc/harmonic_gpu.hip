@@ -1276,11 +1276,7 @@ bool bypass_lists_for_batch(Ctx *c)
 {
     // (c->force > 0 is fine: a forced iteration runs every tile but still lists the tiles it changed)
     if (!c->track || c->track_mode != 2 || c->act_tiles == 0 || c->multi()) return false;
-    const bool saved = c->track;
-    c->track = false;
-    const bool fuses = fuses_jacobi(c);   // what the batch would run as without lists
-    c->track = saved;
-    if (!fuses) return false;
+    if (c->n != 2) return false;
     const char *e = getenv("EPIC_HIP_TRACK_SWITCH");   // share of due tiles above which lists are bypassed (tests: 0 / 2)
     const double limit = e ? atof(e) : 0.8;
     // the counter set the next launch would consume was filled by the check iteration that has just been read back
@@ -1371,8 +1367,10 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
             // middle third of a relaxation from scratch) a list-driven sweep costs more than the plain one -- 12 us + 115 us
             // x share against 97 us per iteration of the fused pass at 8192^2, tol math.  The check that has just completed
             // counted the tiles due next: above the switch share this batch runs without lists, and the next two
-            // iterations rebuild them (force = 2, as after an upload).  Only where pairs of iterations fuse (Jacobi, tol
-            // math), only with tracking in its automatic mode; fields and iteration counts do not depend on it.
+            // iterations rebuild them (force = 2, as after an upload).  2-D, one device, tracking in its automatic mode;
+            // measured on 8192^2 with every arithmetic and scheme (seconds to eps = 1e-6, never / 0.8): tol Jacobi 2.91 / 2.75,
+            // tol red-black 2.62 / 2.52, precise Jacobi 3.78 / 3.69, precise red-black 3.01 / 2.62.  Fields and iteration
+            // counts do not depend on it.
             const bool bypass = bypass_lists_for_batch(c);
             if (bypass) c->track = false;
             const hipError_t be = enqueue_plain_batch(c, batch, harmonic->currentIteration);

@@ -280,12 +280,15 @@ def test_tol_jacobi_and_redblack_end_in_the_same_field(goldens, tol_env):
     print("tol basic.png: Jacobi vs red-black fields differ in %d cells, max rel %.2e" % (int((a != b).sum()), err.max()))
 
 
-def test_execute_bypasses_the_work_lists_while_most_tiles_are_due_with_identical_results(tol_env, monkeypatch):
+@pytest.mark.parametrize("math,scheme", [("tol", "jacobi"), ("precise", "redblack"), ("precise", "jacobi"), ("tol", "redblack")])
+def test_execute_bypasses_the_work_lists_while_most_tiles_are_due_with_identical_results(math, scheme, monkeypatch):
     """harmonic_execute_gpu with tracking in its automatic mode (grids above 4 Mcell): after every check it looks at the
-    share of tiles due next and runs the following batch without the lists -- as fused pairs -- when that share is above
-    EPIC_HIP_TRACK_SWITCH (default 0.8), rebuilding the lists with two full iterations afterwards.  Whatever the
-    threshold -- never (2), default, always (0) -- and with tracking off altogether, field, iteration count and delta are
-    the same bits."""
+    share of tiles due next and runs the following batch without the lists -- as fused pairs where the arithmetic has a
+    fused pass -- when that share is above EPIC_HIP_TRACK_SWITCH (default 0.8), rebuilding the lists with two full
+    iterations afterwards.  Whatever the threshold -- never (2), default, always (0) -- and with tracking off
+    altogether, field, iteration count and delta are the same bits."""
+    monkeypatch.setenv("EPIC_HIP_MATH", math)
+    monkeypatch.setenv("EPIC_HIP_SCHEME", scheme)
     m = [2112, 2112]
     u0, locked = synthetic_grid(m, 11, 0.05)
     results = []
