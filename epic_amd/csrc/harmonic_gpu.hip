@@ -375,13 +375,16 @@ int fused_rows_per_task(const Ctx *c)
 // Whether two consecutive plain Jacobi iterations run as one fused pass in the context's current configuration.
 // EPIC_HIP_FUSE_MIN_CELLS: grids below it keep the single sweeps (default 4 Mcell: below, a sweep is launch-bound and the
 // fused pass's extra rows cost more than the second launch; read per batch, not cached -- the tests switch it).
-bool fuses_jacobi(const Ctx *c)
+bool fuses_tol(const Ctx *c)   // either scheme
 {
     if (getenv("EPIC_HIP_NO_FUSE") != nullptr) return false;
     const char *e = getenv("EPIC_HIP_FUSE_MIN_CELLS");
     const long long min_cells = e ? atoll(e) : (1ll << 22);
-    return !c->redblack && c->n == 2 && !c->track && c->math == 4 && (long long)c->rows * c->pitch >= min_cells;
+    return c->n == 2 && !c->track && c->math == 4 && (long long)c->rows * c->pitch >= min_cells;
 }
+bool fuses_jacobi(const Ctx *c) { return !c->redblack && fuses_tol(c); }
+// red-black, tol math: both colours in one pass (rb_tol_fused2d_kernel); one device only
+bool fuses_rb_tol(const Ctx *c) { return c->redblack && !c->multi() && fuses_tol(c); }
 // ... and whether the NEXT two can: on several devices a pass leaves two more ghost rows stale, so neither of its two
 // iterations may be one that ends with an exchange.
 bool next_two_fuse(const Ctx *c) { return !c->multi() || c->since + 2 < c->halo; }
@@ -423,6 +426,13 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
             }
         }
         return hipSuccess;
+    }
+    while (!no_fuse && fuses_rb_tol(c) && count - i >= 2) {
+        hipError_t e = epic_hip::launch_jacobi_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch,
+                                                        jacobi_fused_rows_per_task(c), c->math, c->stream, (int)((first + i) & 1u));
+        if (e != hipSuccess) return e;
+        c->cur ^= 1;
+        i += 2;
     }
     while (fuse && count - i >= 2) {
         hipError_t e = epic_hip::launch_rb_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch,
@@ -1584,7 +1594,7 @@ int epic_hip_iterations_per_pass(Harmonic *harmonic)
 {
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
     if (!c) return 0;
-    if (fuses_jacobi(c)) return 2;
+    if (fuses_jacobi(c) || fuses_rb_tol(c)) return 2;
     static const bool no_fuse = getenv("EPIC_HIP_NO_FUSE") != nullptr;
     const bool rb_fused = c->redblack && c->n == 2 && !no_fuse && !c->track && !c->multi() && c->math != 4 &&
                           (long long)c->rows * c->pitch >= (1ll << 22);

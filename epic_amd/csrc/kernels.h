@@ -48,9 +48,10 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, i
 // two red-black iterations fused into one in -> out pass (first colour = parity); see kernels_2d.hip
 hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
                               int math, int parity, hipStream_t stream);
-// Two Jacobi iterations in one pass (tol math only): in = u_k, out = u_{k+2}; in != out.
+// Two iterations in one pass (tol math only): in = u_k, out = u_{k+2}; in != out.  parity < 0: Jacobi; 0 / 1: the reference's
+// red-black scheme, parity = the first iteration's number & 1 (both colours are swept, the first one first).
 hipError_t launch_jacobi_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
-                                  int math, hipStream_t stream);
+                                  int math, hipStream_t stream, int parity = -1);
 hipError_t launch_eval_math(const float *in, float *out, size_t n, int which, hipStream_t stream);
 hipError_t launch_pack_mask_2d(const uint32_t *locked, int rows, int cols, int pitch, int ghost_top,
                                int ghost_bottom, uint32_t *maskw, hipStream_t stream);

@@ -515,11 +515,15 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
 #ifndef EPIC_FUSED_MIN_WAVES  // build knob (A/B)
 #define EPIC_FUSED_MIN_WAVES 4
 #endif
-template <int MATH>
-__global__ __launch_bounds__(kWave * kWavesPerBlock, EPIC_FUSED_MIN_WAVES) void jacobi_fused2d_kernel(Sweep2dArgs a)
+// RB = false: two Jacobi iterations.  RB = true: two iterations of the reference's red-black scheme (both colours) -- the
+// same march with half of the cells recomputed at each level: level A updates the cells of row r+1 with (row + col + it)
+// odd from the old rows (their neighbours all have the other colour and have not moved yet), level B the cells of row r
+// with (row + col + it + 1) odd from the level-A rows; a cell that a level does not touch passes through it.  Every
+// cell is recomputed once per pass (4 B of HBM traffic per cell-update against 16 for the in-place half-sweep), the rows
+// are split twice (before level A, and after it for level B).  Bit-identical to two in-place half-sweeps.
+template <bool RB>
+__device__ __forceinline__ void tol_fused_pass(const Sweep2dArgs &a, double *math_lds)
 {
-    static_assert(MATH == kMathTol, "the fused Jacobi pass exists for the tol math");
-    __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];
     const MathTab lds = math_tables_load(math_lds);
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -566,18 +570,27 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, EPIC_FUSED_MIN_WAVES) void 
     // results are never stored and never read by an owned cell.
     auto shl = [](float v) { return u2f(__builtin_amdgcn_mov_dpp(f2u(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true)); };  // from the left
     auto shr = [](float v) { return u2f(__builtin_amdgcn_mov_dpp(f2u(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true)); };  // from the right
+    // (red-black: `odd_cols` says which half of the row this level recomputes -- .y / .w or .x / .z; scalar)
     auto level = [&](const float4 &up, const float4 &c, const float4 &dn, const Split4 &su, const Split4 &sc, const Split4 &sd,
-                     const RowMask &k) -> float4 {
-        const float lf = shl(c.w), rt = shr(c.x);
-        const float ql = shl(sc.qw), qr = shr(sc.qx);
-        const uint32_t nl = f2u(shl(u2f(sc.nw))), nr = f2u(shr(u2f(sc.nx)));
-        float4 o;
-        o.x = sel(k.m0, c.x, tol_update_2d(up.x, dn.x, lf, c.y, su.qx, su.nx, sd.qx, sd.nx, ql, nl, sc.qy, sc.ny, lds));
-        o.y = sel(k.m1, c.y, tol_update_2d(up.y, dn.y, c.x, c.z, su.qy, su.ny, sd.qy, sd.ny, sc.qx, sc.nx, sc.qz, sc.nz, lds));
-        o.z = sel(k.m2, c.z, tol_update_2d(up.z, dn.z, c.y, c.w, su.qz, su.nz, sd.qz, sd.nz, sc.qy, sc.ny, sc.qw, sc.nw, lds));
-        o.w = sel(k.m3, c.w, tol_update_2d(up.w, dn.w, c.z, rt, su.qw, su.nw, sd.qw, sd.nw, sc.qz, sc.nz, qr, nr, lds));
+                     const RowMask &k, bool odd_cols) -> float4 {
+        float4 o = c;
+        if (!RB || !odd_cols) {
+            const float lf = shl(c.w), ql = shl(sc.qw);
+            const uint32_t nl = f2u(shl(u2f(sc.nw)));
+            o.x = sel(k.m0, c.x, tol_update_2d(up.x, dn.x, lf, c.y, su.qx, su.nx, sd.qx, sd.nx, ql, nl, sc.qy, sc.ny, lds));
+            o.z = sel(k.m2, c.z, tol_update_2d(up.z, dn.z, c.y, c.w, su.qz, su.nz, sd.qz, sd.nz, sc.qy, sc.ny, sc.qw, sc.nw, lds));
+        }
+        if (!RB || odd_cols) {
+            const float rt = shr(c.x), qr = shr(sc.qx);
+            const uint32_t nr = f2u(shr(u2f(sc.nx)));
+            o.y = sel(k.m1, c.y, tol_update_2d(up.y, dn.y, c.x, c.z, su.qy, su.ny, sd.qy, sd.ny, sc.qx, sc.nx, sc.qz, sc.nz, lds));
+            o.w = sel(k.m3, c.w, tol_update_2d(up.w, dn.w, c.z, rt, su.qw, su.nw, sd.qw, sd.nw, sc.qz, sc.nz, qr, nr, lds));
+        }
         return o;
     };
+    // which half a level recomputes in row `row`: level A belongs to iteration a.parity, level B to the one after it; the
+    // cells with (row + col + iteration) odd are the active ones (harmonic_cpu.cpp:46-51), col is even for .x / .z
+    auto odd_cols_of = [&](int row, int level_index) { return ((row + a.parity + level_index) & 1) == 0; };
 
     // Ring slots (row numbers relative to r0, trips start at multiples of 6):  u_k row x -> u[(x + 2) % 6],
     // its split -> su[(x + 2) % 3],  level-A row x and its split -> m / sm[(x + 1) % 3],  masks of row x -> k[(x + 1) % 3].
@@ -589,12 +602,15 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, EPIC_FUSED_MIN_WAVES) void 
     for (int x = 0; x < 6; ++x) u[x] = ld(min(r0 - 2 + x, r1 + 1));
     k[0] = row_mask(r0 - 1); k[1] = row_mask(r0); k[2] = row_mask(r0 + 1);
     su[0] = tol_split4(u[0]); su[1] = tol_split4(u[1]); su[2] = tol_split4(u[2]);
-    m[0] = level(u[0], u[1], u[2], su[0], su[1], su[2], k[0]);   // level A of row r0 - 1
+    m[0] = level(u[0], u[1], u[2], su[0], su[1], su[2], k[0], odd_cols_of(r0 - 1, 0));   // level A of row r0 - 1
     sm[0] = tol_split4(m[0]);
     su[0] = tol_split4(u[3]);                                    // the split of row r0 - 2 is done with
-    m[1] = level(u[1], u[2], u[3], su[1], su[2], su[0], k[1]);   // level A of row r0
+    m[1] = level(u[1], u[2], u[3], su[1], su[2], su[0], k[1], odd_cols_of(r0, 0));   // level A of row r0
     sm[1] = tol_split4(m[1]);
     const int nrows = r1 - r0;
+    // (red-black: the half a level recomputes is a scalar test per level.  Two straight-line versions of the trip, chosen by
+    // the one task-uniform bit that fixes the whole pattern, were built and measured: the scheduler then interleaves so much
+    // that the kernel needs ~170 VGPRs and still spills -- 82 us per iteration at three waves per SIMD against 76 like this.)
     for (int i = 0; i < nrows; i += kTrip) {
         auto step = [&](auto jc) {
             constexpr int j = decltype(jc)::value;
@@ -603,16 +619,31 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, EPIC_FUSED_MIN_WAVES) void 
                 u[j % 6] = ld(min(r + 4, r1 + 1));   // slot of row r - 2; past r1 + 1 (nothing needs those rows) the last row again: a cache hit
                 su[(j + 1) % 3] = tol_split4(u[(j + 4) % 6]);                    // row r + 2 (slot of row r - 1's split)
                 m[(j + 2) % 3] = level(u[(j + 2) % 6], u[(j + 3) % 6], u[(j + 4) % 6], su[(j + 2) % 3], su[j % 3],
-                                       su[(j + 1) % 3], k[(j + 2) % 3]);         // level A of row r + 1
+                                       su[(j + 1) % 3], k[(j + 2) % 3], odd_cols_of(r + 1, 0));   // level A of row r + 1
                 sm[(j + 2) % 3] = tol_split4(m[(j + 2) % 3]);
                 const float4 x = level(m[j % 3], m[(j + 1) % 3], m[(j + 2) % 3], sm[j % 3], sm[(j + 1) % 3], sm[(j + 2) % 3],
-                                       k[(j + 1) % 3]);                          // level B of row r
+                                       k[(j + 1) % 3], odd_cols_of(r, 1));       // level B of row r
                 k[j % 3] = row_mask(r + 2);                                      // slot of row r - 1's masks
                 if (owner) store_row(rout, x.x, x.y, x.z, x.w, lane_off, row_off(r));
             }
         };
         unrolled<kTrip>(step);
     }
+}
+
+template <int MATH>
+__global__ __launch_bounds__(kWave * kWavesPerBlock, EPIC_FUSED_MIN_WAVES) void jacobi_fused2d_kernel(Sweep2dArgs a)
+{
+    static_assert(MATH == kMathTol, "the fused Jacobi pass exists for the tol math");
+    __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];
+    tol_fused_pass<false>(a, math_lds);
+}
+
+// two red-black iterations of the tol math in one pass (the precise / fast math: rb_fused2d_kernel above)
+__global__ __launch_bounds__(kWave * kWavesPerBlock, EPIC_FUSED_MIN_WAVES) void rb_tol_fused2d_kernel(Sweep2dArgs a)
+{
+    __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];
+    tol_fused_pass<true>(a, math_lds);
 }
 
 // uint32-per-cell mask (the ABI's format, rows x cols, unpitched) -> lane masks (kernels.h).  One wave per (row,
@@ -804,7 +835,7 @@ hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw
 }
 
 hipError_t launch_jacobi_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
-                                  int math, hipStream_t stream)
+                                  int math, hipStream_t stream, int parity)
 {
     if (pitch <= 0 || (pitch % 256) != 0 || rows <= 0 || rows_per_task <= 0 || in == out) return hipErrorInvalidValue;
     if (math != kMathTol) return hipErrorInvalidValue;
@@ -820,12 +851,13 @@ hipError_t launch_jacobi_fused_2d(const float *in, float *out, const uint32_t *m
     a.rows_per_task = rows_per_task;
     a.nstrips = (pitch + kFusedOut - 1) / kFusedOut;
     a.ntasks = a.nstrips * ((rows + rows_per_task - 1) / rows_per_task);
-    a.parity = 0;
+    a.parity = parity < 0 ? 0 : parity & 1;
     a.flags = sweep_flags();
     a.nchunks = 0;
     a.wake = wake_args(nullptr, 0);
     const dim3 grid((a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
-    hipLaunchKernelGGL((jacobi_fused2d_kernel<kMathTol>), grid, block, 0, stream, a);
+    if (parity < 0) hipLaunchKernelGGL((jacobi_fused2d_kernel<kMathTol>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(rb_tol_fused2d_kernel, grid, block, 0, stream, a);
     return hipGetLastError();
 }
 

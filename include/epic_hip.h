@@ -44,7 +44,7 @@ int epic_hip_timed_sweeps_gpu(EpicHarmonicT *harmonic, unsigned int sweeps, unsi
 
 /* How many iterations one kernel launch of a batch of PLAIN (unchecked) iterations advances in the current configuration:
  * 2 where pairs of iterations run as one fused pass over the data -- Jacobi with the tol math (two sweeps, 4 B of HBM
- * traffic per cell-update instead of 8) and red-black with the precise / fast math (both colours), 2-D grids of at least
+ * traffic per cell-update instead of 8) and red-black with any math (both colours), 2-D grids of at least
  * 4 Mcell on one device with activity tracking off; results are bit-identical to single iterations, an odd iteration and
  * every check iteration run singly -- 1 otherwise, 0 without device state.  EPIC_HIP_NO_FUSE=1 switches the fusion off. */
 int epic_hip_iterations_per_pass(EpicHarmonicT *harmonic);

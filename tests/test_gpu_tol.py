@@ -112,6 +112,27 @@ FUSED_GRIDS = [([16, 16], 1, 0.05), ([23, 37], 4, 0.10), ([3, 3], 6, 0.0), ([3, 
 
 
 @pytest.mark.parametrize("m,seed,dens", FUSED_GRIDS)
+@pytest.mark.parametrize("rows", [0, 5, 6, 24])
+def test_tol_fused_redblack_pairs_equal_the_checker_bit_for_bit(m, seed, dens, rows, monkeypatch):
+    """The same pass for the reference's red-black scheme (rb_tol_fused2d_kernel): both colours of two consecutive
+    iterations in one pass, each level recomputing half of the cells; odd and even first iterations (k = 2, 3, ...)."""
+    monkeypatch.setenv("EPIC_HIP_FUSE_MIN_CELLS", "0")
+    if rows:
+        monkeypatch.setenv("EPIC_HIP_FUSED_ROWS", str(rows))
+    u0, locked = with_extra_goals(m, seed, dens)
+    for k in (2, 3, 4, 8, 41, 101):
+        want, wdelta = checker_iterations(m, u0, locked, k, eh.SCHEME_REDBLACK)
+        for graph in (True, False):
+            if graph:
+                monkeypatch.delenv("EPIC_HIP_NO_GRAPH", raising=False)
+            else:
+                monkeypatch.setenv("EPIC_HIP_NO_GRAPH", "1")
+            got, gdelta = gpu_iterations(m, u0, locked, k, eh.SCHEME_REDBLACK, 0)
+            assert np.array_equal(got, want), f"{m} after {k} red-black iterations, fused rows {rows}, graph {graph}"
+            assert gdelta == wdelta
+
+
+@pytest.mark.parametrize("m,seed,dens", FUSED_GRIDS)
 @pytest.mark.parametrize("rows", [0, 1, 5, 6, 7, 24])
 def test_tol_fused_double_sweeps_equal_the_checker_bit_for_bit(m, seed, dens, rows, monkeypatch):
     """Plain Jacobi iterations in pairs run as ONE pass (jacobi_fused2d_kernel: level A in registers, 248 owned columns
