@@ -254,7 +254,8 @@ def main():
         achieved = BYTES_PER_CELL_SWEEP * cells_per_launch * per_pass / (launch_us * 1e-6) / 1e9
         fused = per_pass == 2
         traffic = measured_traffic(n, math, scheme + ("_fused" if fused else "")) if single_device_full_grid else None
-        kernel = ("jacobi_fused2d_kernel" if scheme == "jacobi" else "rb_fused2d_kernel") if fused else "sweep2d_kernel"
+        kernel = (("jacobi_fused2d_kernel" if scheme == "jacobi" else "rb_tol_fused2d_kernel" if math == "tol" else "rb_fused2d_kernel")
+                  if fused else "sweep2d_kernel")
         return {
             "bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "launch_us": round(launch_us, 3),
