@@ -403,8 +403,9 @@ hipError_t multi_sweep_pair(Ctx *c);
 hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
 {
     static const bool no_fuse = getenv("EPIC_HIP_NO_FUSE") != nullptr;
-    // (the fused pass has its own 248-column tiling and no work lists: it is used when tracking is off)
-    // (and the precise / fast arithmetic only: the tol math runs the in-place half-sweeps)
+    // (the fused passes have their own 248-column tiling and no work lists: they are used when tracking is off -- or
+    //  bypassed for the batch, harmonic_execute_gpu; rb_fused2d_kernel for the precise / fast arithmetic, the RB instance of
+    //  the tol pass for tol)
     const bool fuse = c->redblack && c->n == 2 && !no_fuse && !c->track && !c->multi() && c->math != 4 && (long long)c->rows * c->pitch >= (1ll << 22);
     unsigned i = 0;
     // Jacobi, tol math, 2-D: two consecutive plain iterations run as one pass as well (kernels_2d.hip,
