@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "multi_gpu: needs at least two GPUs (always combined with gpu; skips itself otherwise)")
+    config.addinivalue_line("markers", "multi_gpu: needs at least two GPUs and EPIC_TEST_MULTI_GPU=1 (always combined with gpu; skips itself otherwise)")
 
 
 @pytest.fixture(scope="session", autouse=True)
