@@ -30,17 +30,22 @@ inline size_t sweep_2d_tiles(int rows, int pitch, int rows_per_task)
     return (size_t)((pitch + 255) / 256) * (size_t)((rows + rows_per_task - 1) / rows_per_task);
 }
 inline size_t sweep_2d_list_cap(size_t tiles) { return (tiles + kWakeListCount - 1) / kWakeListCount; }
-// blocks of a list-driven launch: enough waves to fill the chip (8192), or one per tile on small grids; a multiple of
-// the 8 XCDs
-inline int sweep_2d_list_blocks(size_t tiles)
+// Blocks of a list-driven launch: as many persistent waves as the chip holds of THIS kernel at a time (resident_blocks:
+// the occupancy of the instantiation x the CUs -- 4096 waves for the tracked tol sweeps, 5120 / 7168 for the precise ones),
+// or one per tile on small grids; a multiple of the 8 XCDs.  More than fit only start when the first ones have left
+// (8192^2 tol relaxation: 2.74 s with 8192 waves, 2.66 with 4096, 2.97 with 2048).  EPIC_HIP_LIST_WAVES overrides.
+inline int sweep_2d_list_blocks(size_t tiles, int resident_blocks)
 {
-    static const size_t waves = [] {
+    static const size_t forced = [] {
         const char *e = getenv("EPIC_HIP_LIST_WAVES");
         const long v = e ? atol(e) : 0;
-        return (size_t)(v >= 4 ? v : 8192);
+        return (size_t)(v >= 4 ? v : 0);
     }();
+    const size_t waves = forced ? forced : (size_t)(resident_blocks > 0 ? resident_blocks : 2048) * 4;
     return (int)(((tiles < waves ? tiles : waves) + 31) / 32) * 8;
 }
+// blocks of 256 threads of `kernel` the current device holds at a time (cached per kernel)
+int resident_blocks_of(const void *kernel);
 // parity < 0: Jacobi (in != out); parity 0 / 1: red-black half-sweep of that colour, in place (in == out).
 hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int row_begin,
                            int row_end, int rows_per_task, int math, int parity, unsigned *delta_bits,

@@ -39,6 +39,8 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 
 #include "cell_update.h"
 #include "kernels.h"
@@ -724,6 +726,22 @@ __global__ void eval_math_kernel(const float *in, float *out, size_t n, int whic
 
 }  // namespace
 
+int resident_blocks_of(const void *kernel)
+{
+    static std::mutex mu;
+    static std::map<const void *, int> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(kernel);
+    if (it != cache.end()) return it->second;
+    int blocks = 0, dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, kWave * kWavesPerBlock, 0) != hipSuccess || blocks < 1 || cus < 1) {
+        (void)hipGetLastError();
+        return cache[kernel] = 0;   // unknown: the caller's default
+    }
+    return cache[kernel] = blocks * cus;
+}
+
 hipError_t launch_eval_math(const float *in, float *out, size_t n, int which, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
@@ -747,11 +765,14 @@ int sweep_flags()
 template <bool CHECK, bool RB, bool TRACK>
 void launch_sweep_2d_math(int math, int nblocks, hipStream_t stream, const Sweep2dArgs &a)
 {
+    void (*kernel)(Sweep2dArgs) = math == kMathFast      ? sweep2d_kernel<CHECK, kMathFast, RB, TRACK>
+                                  : math == kMathTraffic ? sweep2d_kernel<CHECK, kMathTraffic, RB, TRACK>
+                                  : math == kMathTol     ? sweep2d_kernel<CHECK, kMathTol, RB, TRACK>
+                                                         : sweep2d_kernel<CHECK, kMathPrecise, RB, TRACK>;
+    // a list-driven launch is persistent waves: as many as the chip holds of this instantiation
+    if (TRACK && a.wake.list_in) nblocks = sweep_2d_list_blocks((size_t)a.ntasks, resident_blocks_of((const void *)kernel));
     const dim3 grid(nblocks), block(kWave * kWavesPerBlock);
-    if (math == kMathFast) hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathFast, RB, TRACK>), grid, block, 0, stream, a);
-    else if (math == kMathTraffic) hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathTraffic, RB, TRACK>), grid, block, 0, stream, a);
-    else if (math == kMathTol) hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathTol, RB, TRACK>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((sweep2d_kernel<CHECK, kMathPrecise, RB, TRACK>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL(kernel, grid, block, 0, stream, a);
 }
 template <bool CHECK, bool RB>
 void launch_sweep_2d_track(int math, int nblocks, hipStream_t stream, const Sweep2dArgs &a)
@@ -794,7 +815,6 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, i
     const bool whole = row_begin == 0 && row_end == rows;
     a.wake = wake_args(whole ? act : nullptr, (size_t)a.ntasks);
     int nblocks = (a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (a.wake.list_in) nblocks = sweep_2d_list_blocks((size_t)a.ntasks);  // persistent waves walking the lists
     if (parity < 0) {
         if (delta_bits) launch_sweep_2d_track<true, false>(math, nblocks, stream, a);
         else launch_sweep_2d_track<false, false>(math, nblocks, stream, a);

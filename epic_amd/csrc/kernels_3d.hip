@@ -283,17 +283,20 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void pack_mask_3d_kernel(co
 
 namespace {
 template <bool CHECK, bool RB, bool TRACK>
-void launch_sweep_3d_track(int math, dim3 grid, dim3 block, hipStream_t stream, const Sweep3dArgs &a)
+void launch_sweep_3d_track(int math, dim3 grid, dim3 block, hipStream_t stream, const Sweep3dArgs &a, size_t tiles)
 {
-    if (math == kMathFast) hipLaunchKernelGGL((sweep3d_kernel<CHECK, kMathFast, RB, TRACK>), grid, block, 0, stream, a);
-    else if (math == kMathTol) hipLaunchKernelGGL((sweep3d_kernel<CHECK, kMathTol, RB, TRACK>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((sweep3d_kernel<CHECK, kMathPrecise, RB, TRACK>), grid, block, 0, stream, a);
+    void (*kernel)(Sweep3dArgs) = math == kMathFast  ? sweep3d_kernel<CHECK, kMathFast, RB, TRACK>
+                                  : math == kMathTol ? sweep3d_kernel<CHECK, kMathTol, RB, TRACK>
+                                                     : sweep3d_kernel<CHECK, kMathPrecise, RB, TRACK>;
+    // a list-driven launch is persistent waves: as many as the chip holds of this instantiation (kernels.h)
+    if (TRACK && a.wake.list_in) grid = dim3((unsigned)sweep_2d_list_blocks(tiles, resident_blocks_of((const void *)kernel)));
+    hipLaunchKernelGGL(kernel, grid, block, 0, stream, a);
 }
 template <bool CHECK, bool RB>
-void launch_sweep_3d_math(int math, dim3 grid, dim3 block, hipStream_t stream, const Sweep3dArgs &a)
+void launch_sweep_3d_math(int math, dim3 grid, dim3 block, hipStream_t stream, const Sweep3dArgs &a, size_t tiles)
 {
-    if (a.wake.list_out) launch_sweep_3d_track<CHECK, RB, true>(math, grid, block, stream, a);
-    else launch_sweep_3d_track<CHECK, RB, false>(math, grid, block, stream, a);
+    if (a.wake.list_out) launch_sweep_3d_track<CHECK, RB, true>(math, grid, block, stream, a, tiles);
+    else launch_sweep_3d_track<CHECK, RB, false>(math, grid, block, stream, a, tiles);
 }
 }  // namespace
 
@@ -327,13 +330,13 @@ hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, i
     const bool whole = plane_begin == 0 && plane_end == m0;
     const size_t tiles = sweep_3d_tiles(m0, m1, pitch);
     a.wake = wake_args(whole ? act : nullptr, tiles);
-    const dim3 grid(a.wake.list_in ? (unsigned)sweep_2d_list_blocks(tiles) : (unsigned)nblocks), block(kWave * kWavesPerBlock);
+    const dim3 grid((unsigned)nblocks), block(kWave * kWavesPerBlock);   // (list-driven launches: resized in launch_sweep_3d_track)
     if (parity < 0) {
-        if (delta_bits) launch_sweep_3d_math<true, false>(math, grid, block, stream, a);
-        else launch_sweep_3d_math<false, false>(math, grid, block, stream, a);
+        if (delta_bits) launch_sweep_3d_math<true, false>(math, grid, block, stream, a, tiles);
+        else launch_sweep_3d_math<false, false>(math, grid, block, stream, a, tiles);
     } else {
-        if (delta_bits) launch_sweep_3d_math<true, true>(math, grid, block, stream, a);
-        else launch_sweep_3d_math<false, true>(math, grid, block, stream, a);
+        if (delta_bits) launch_sweep_3d_math<true, true>(math, grid, block, stream, a, tiles);
+        else launch_sweep_3d_math<false, true>(math, grid, block, stream, a, tiles);
     }
     return hipGetLastError();
 }
