@@ -173,6 +173,12 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+    host_group = None   # a host-side (gloo) group for the waits around the in-library leg: an RCCL barrier would leave a
+    if world > 1 and backend == "nccl":   # spinning kernel on every GPU that rank 0 is about to use from this process
+        try:
+            host_group = dist.new_group(backend="gloo")
+        except Exception:                 # evidence leg only: never lose the headline line
+            host_group = None
 
     from epic_amd import epic_harmonic as eh
     from epic_amd.synthetic import synthetic_grid
@@ -185,6 +191,16 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def host_barrier():
+        """Ranks meet on the host (no collective kernel left waiting on any GPU)."""
+        torch.cuda.synchronize()
+        if world > 1:
+            if host_group is not None:
+                dist.barrier(group=host_group)
+            else:
+                dist.barrier()
+                torch.cuda.synchronize()
 
     def max_over_ranks(*vals):
         if world == 1:
@@ -467,8 +483,8 @@ def main():
                 "frac_per_gpu": round(BYTES_PER_CELL_SWEEP * w["rows_local"] * n / (wl * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
                 "note": "the other scaling mode, same run, fewer steps"}
             # the same 8192^2 grid through the C-ABI in ONE process on all GPUs (EPIC_HIP_DEVICES; halos by
-            # hipMemcpyPeerAsync): rank 0 drives, the other ranks wait at the barrier with their GPUs idle
-            barrier()
+            # hipMemcpyPeerAsync): rank 0 drives, the other ranks wait on the host with their GPUs idle
+            host_barrier()
             if rank == 0 and backend == "nccl" and ndev >= world:
                 try:
                     grid = [n, n]
@@ -487,7 +503,7 @@ def main():
                         "note": "harmonic_*_gpu on one Harmonic in ONE process, EPIC_HIP_DEVICES=0..N-1; host-clocked"}
                 except Exception as exc:   # evidence leg only: never lose the headline line
                     out["in_library"] = {"error": repr(exc)}
-            barrier()
+            host_barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
