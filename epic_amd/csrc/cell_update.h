@@ -191,6 +191,50 @@ __device__ __forceinline__ v2f splat(float x) { return v2f{x, x}; }
 // here; it was no faster than the reworked precise kernel, could not stop by the reference's test under Jacobi on umass,
 // and is superseded by the tol mode below.  Removed in round 2; DESIGN.md section 2 keeps what was learned from it.)
 
+// ---- kMathTol: the logarithm of the sum ---------------------------------------------------------------------------
+// ln S for the sum S of 2n terms <= 1.4143 of which the largest is >= 0.7071 (S in [0.5, 8) in 2-D, [0.5, 16) in 3-D).
+// The tol mode makes no claim on glibc's bits, so its logarithm is built for this chip's instruction prices rather than
+// copied from logf (round 2 used glibc's algorithm in f64: 8 f64-class instructions):
+//     ln S = lnc + log1p(r),   r = S invc - 1,
+// over 256 sub-intervals per binade picked by the exponent's low bits and the top 8 mantissa bits of S.  invc = v / 512
+// 2^-k with a 9-bit integer v (the rounded reciprocal of the sub-interval's centre), so S invc - 1 has at most 24
+// significant bits and ONE f32 fma gives r EXACTLY (|r| <= 2^-8.45); log1p(r) = r + r^2 (-1/2 + r / 3) needs nothing beyond
+// f32 (three cheap instructions), and only lnc -- the table's -ln(invc), correctly rounded double -- is added in f64.
+// Measured against 200-bit arithmetic over [0.707, 8.49] (tools/gen_ln_table.py): max error 2^-32.9, rms 2^-35.0, mean
+// +1e-12; the glibc algorithm in f64 it replaces: max 2^-28.7, rms 2^-32.1, mean -8e-12.  Cost: 2 integer + 3 f32 + 2
+// f64-class instructions against 3 + 0 + 8.  The table is 16 bytes per entry, 16 KiB (2-D: four binades, the entry of
+// binade k at ((k & 3) << 8) + j so that the raw bits of S index it) or 20 KiB (3-D: five binades in order); every
+// workgroup copies it from constant memory into LDS once (tol_ln_stage: all its waves, one barrier), which is why the
+// tol kernels are launched as resident workgroups that walk their tasks (kernels_2d.hip, kernels_3d.hip).
+struct alignas(16) TolLnEntry { double lnc; float invc; float pad; };
+__constant__ const TolLnEntry kTolLnTab[5 * 256] = {
+#include "tol_ln_table.inc"
+};
+template <int BINADES> struct TolLn {
+    static_assert(BINADES == 4 || BINADES == 5, "2-D sums stay below 8, 3-D sums below 16");
+    static constexpr int kEntries = BINADES * 256;
+    static constexpr int kLdsBytes = kEntries * (int)sizeof(TolLnEntry);
+    // Every thread of the workgroup copies its share; ends with a workgroup barrier: call it before any wave may leave.
+    static __device__ __forceinline__ void stage(TolLnEntry *lds)
+    {
+        for (int e = threadIdx.x; e < kEntries; e += blockDim.x) {
+            const int slot = BINADES == 4 ? (((((e >> 8) + 126) & 3) << 8) | (e & 255)) : e;
+            lds[slot] = kTolLnTab[e];
+        }
+        __syncthreads();
+    }
+    static __device__ __forceinline__ double ln(float s, const TolLnEntry *lds)
+    {
+        const uint32_t b = f2u(s);
+        const uint32_t off = BINADES == 4 ? ((b >> 11) & 0x3ff0u) : (((b - 0x3f000000u) >> 11) & 0x7ff0u);
+        const TolLnEntry e = *reinterpret_cast<const TolLnEntry *>(reinterpret_cast<const char *>(lds) + off);
+        const float r = __builtin_fmaf(s, e.invc, -1.0f);
+        const float r2 = r * r;
+        const float w = __builtin_fmaf(r2, __builtin_fmaf(r, 0x1.555556p-2f, -0.5f), r);
+        return e.lnc + (double)w;
+    }
+};
+
 // ---- kMathTol: one exp-class evaluation and one log per CELL instead of per NEIGHBOUR -------------------------------
 // The reference evaluates u' = mx + ln(sum_i e^(u_i - mx)) - ln 2n with 2n expf and one logf per cell
 // (harmonic_cpu.cpp:60-70), and every u_i goes through expf 2n times per sweep, once for each of its neighbours.  Here
@@ -281,26 +325,136 @@ __device__ __forceinline__ TolMax tol_max(float mx)
 //     l = (float)(ln S - f ln2)          ONE rounding to f32, where the reference rounds logf(s)
 //     t = mx + l                         f32, as the reference
 //     u' = (float)((double)t - ln 2n)    as the reference (kLn4 / kLn6)
-__device__ __forceinline__ float tol_finish(float s, const TolMax &m, double ln2n, const MathTab &tab)
+template <int BINADES>
+__device__ __forceinline__ float tol_finish(float s, const TolMax &m, double ln2n, const TolLnEntry *tab)
 {
-    const float l = (float)__builtin_fma(-(double)m.f, kLn2d, precise_ln_d(s, tab));
+    const float l = (float)__builtin_fma(-(double)m.f, kLn2d, TolLn<BINADES>::ln(s, tab));
     const float t = m.mx + l;
     return (float)((double)t - ln2n);
 }
+// The same update for TWO cells at a time, in three phases, so that a kernel can keep the table reads of one pair of cells
+// in flight while it works on the other pair: pre(x, z), issue(x, z), pre(y, w), issue(y, w), wait for the first pair,
+// post(x, z), wait for the second, post(y, w).  One cell at a time the compiler issued a lookup and parked the wave at
+// s_waitcnt lgkmcnt(0) twice per cell -- sixteen LDS round trips per step of the fused pass (28 % of all wave cycles; with
+// the reads merely grouped and waited for at once they still cost 10 % of the pass: 190 vs 171 us per launch with the reads
+// compiled out, same box; profiles/r03_experiments.txt).  The element-wise parts (N and f of the maximum, the sum) are
+// packed f32 over the pair.  Same operations on the same values as tol_update_2d / _3d: same bits.
+struct TolPre2 { v2f s, mx, f; };
+struct TolLnRaw { uint32_t lo, hi, invc; };  // a table entry as it leaves the LDS: the two halves of lnc, and invc
+// N (bit patterns) and f of the two maxima: tol_max, packed
+__device__ __forceinline__ void tol_max2(v2f mx, v2f &f, uint32_t &n0, uint32_t &n1)
+{
+    const v2f zm = pk_fma(mx, splat(kTolLog2eHi), splat(kTolMagic));
+    const v2f nf = zm - splat(kTolMagic);
+    f = pk_fma(mx, splat(kTolLog2eHi), -nf);
+    f = pk_fma(mx, splat(kTolLog2eLo), f);
+    n0 = f2u(zm.x);
+    n1 = f2u(zm.y);
+}
+// cell 0: neighbours a0 b0 c0 d0 in the reference's order of summation (their u, q, n); cell 1 likewise
+__device__ __forceinline__ TolPre2 tol_pre2_2d(float ua0, float ub0, float uc0, float ud0, float qa0, uint32_t na0, float qb0, uint32_t nb0,
+                                               float qc0, uint32_t nc0, float qd0, uint32_t nd0, float ua1, float ub1, float uc1, float ud1,
+                                               float qa1, uint32_t na1, float qb1, uint32_t nb1, float qc1, uint32_t nc1, float qd1,
+                                               uint32_t nd1)
+{
+    TolPre2 p;
+    p.mx = v2f{max2(max2(max2(ua0, ub0), uc0), ud0), max2(max2(max2(ua1, ub1), uc1), ud1)};
+    uint32_t n0, n1;
+    tol_max2(p.mx, p.f, n0, n1);
+    v2f s = v2f{tol_term(qa0, na0, n0), tol_term(qa1, na1, n1)} + v2f{tol_term(qb0, nb0, n0), tol_term(qb1, nb1, n1)};
+    s = s + v2f{tol_term(qc0, nc0, n0), tol_term(qc1, nc1, n1)};
+    p.s = s + v2f{tol_term(qd0, nd0, n0), tol_term(qd1, nd1, n1)};
+    return p;
+}
+// six neighbours each, x0-1, x0+1, x1-1, x1+1, x2-1, x2+1 (harmonic_cpu.cpp:118-123): u[], q[], n[] of cell 0 and of cell 1
+struct TolNb6 { float u0, u1, u2, u3, u4, u5, q0, q1, q2, q3, q4, q5; uint32_t n0, n1, n2, n3, n4, n5; };
+__device__ __forceinline__ TolPre2 tol_pre2_3d(const TolNb6 &a, const TolNb6 &b)
+{
+    TolPre2 p;
+    p.mx = v2f{max2(max2(max2(max2(max2(a.u0, a.u1), a.u2), a.u3), a.u4), a.u5),
+               max2(max2(max2(max2(max2(b.u0, b.u1), b.u2), b.u3), b.u4), b.u5)};
+    uint32_t n0, n1;
+    tol_max2(p.mx, p.f, n0, n1);
+    v2f s = v2f{tol_term(a.q0, a.n0, n0), tol_term(b.q0, b.n0, n1)} + v2f{tol_term(a.q1, a.n1, n0), tol_term(b.q1, b.n1, n1)};
+    s = s + v2f{tol_term(a.q2, a.n2, n0), tol_term(b.q2, b.n2, n1)};
+    s = s + v2f{tol_term(a.q3, a.n3, n0), tol_term(b.q3, b.n3, n1)};
+    s = s + v2f{tol_term(a.q4, a.n4, n0), tol_term(b.q4, b.n4, n1)};
+    p.s = s + v2f{tol_term(a.q5, a.n5, n0), tol_term(b.q5, b.n5, n1)};
+    return p;
+}
+// LDS byte address of the table entry of S (the low half of a generic pointer into LDS is the LDS address)
+template <int BINADES>
+__device__ __forceinline__ uint32_t tol_ln_addr(float s, const TolLnEntry *lds)
+{
+    const uint32_t b = f2u(s);
+    const uint32_t off = BINADES == 4 ? ((b >> 11) & 0x3ff0u) : (((b - 0x3f000000u) >> 11) & 0x7ff0u);
+#ifdef EPIC_EXP_LDS_UNIFORM  // timing experiment only (wrong results): every lane reads the same entry -- no bank conflicts
+    return (uint32_t)(uintptr_t)lds + (off & 0x10u);
+#endif
+    return (uint32_t)(uintptr_t)lds + off;
+}
+// The reads of a pair are ISSUED here and WAITED FOR later (tol_ln_wait).  Written out in assembly: the compiler waits after
+// every read of its own, and it does not count LDS operations issued from inline assembly, so the waits are ours.  LDS
+// operations of a wave complete in order, so "at most N outstanding" (lgkmcnt(N)) leaves only the N youngest reads in
+// flight whatever scalar loads are in flight beside them.  The scheduling barriers keep the compiler from moving the code
+// that is meant to cover the round trip to the other side of the statement.
+typedef unsigned vu3_t __attribute__((ext_vector_type(3)));
+struct TolLnPair { vu3_t a, b; };
+template <int BINADES>
+__device__ __forceinline__ TolLnPair tol_ln_issue(const TolPre2 &p, const TolLnEntry *lds)
+{
+    TolLnPair r;
+    const uint32_t a0 = tol_ln_addr<BINADES>(p.s.x, lds), a1 = tol_ln_addr<BINADES>(p.s.y, lds);
+#ifdef EPIC_EXP_NOLDS  // timing experiment only (wrong results): no table lookups
+    r.a = r.b = vu3_t{a0 + a1, 0x3ff00000u, 0x3f800000u};
+#else
+    asm volatile("ds_read_b96 %0, %2\n\tds_read_b96 %1, %3" : "=&v"(r.a), "=&v"(r.b) : "v"(a0), "v"(a1));
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    return r;
+}
+// the pair is in its registers once at most `N` younger LDS reads of this wave are still outstanding
+template <int N>
+__device__ __forceinline__ void tol_ln_wait(TolLnPair &r, TolLnRaw &e0, TolLnRaw &e1)
+{
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef EPIC_EXP_NOLDS
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(r.a), "+v"(r.b) : "n"(N));
+#endif
+    e0 = TolLnRaw{r.a.x, r.a.y, r.a.z};
+    e1 = TolLnRaw{r.b.x, r.b.y, r.b.z};
+}
+// phase 3 of one cell up to l (TolLn::ln and the first rounding of tol_finish) ...
+__device__ __forceinline__ float tol_post_l(float s, float f, const TolLnRaw &e)
+{
+    const float invc = u2f(e.invc);
+    const double lnc = __builtin_bit_cast(double, (uint64_t)e.lo | ((uint64_t)e.hi << 32));
+    const float r = __builtin_fmaf(s, invc, -1.0f);
+    const float r2 = r * r;
+    const float w = __builtin_fmaf(r2, __builtin_fmaf(r, 0x1.555556p-2f, -0.5f), r);
+    return (float)__builtin_fma(-(double)f, kLn2d, lnc + (double)w);
+}
+// ... and of the pair: t = mx + l (packed), u' = (float)((double)t - ln 2n)
+__device__ __forceinline__ void tol_post2(const TolPre2 &p, const TolLnRaw &e0, const TolLnRaw &e1, double ln2n, float &o0, float &o1)
+{
+    const v2f t = p.mx + v2f{tol_post_l(p.s.x, p.f.x, e0), tol_post_l(p.s.y, p.f.y, e1)};
+    o0 = (float)((double)t.x - ln2n);
+    o1 = (float)((double)t.y - ln2n);
+}
 // neighbours in the reference's order of summation: up, down, left, right (harmonic_cpu.cpp:65-68); u* = their values
 __device__ __forceinline__ float tol_update_2d(float uu, float ud, float ul, float ur, float qu, uint32_t nu, float qd,
-                                               uint32_t nd, float ql, uint32_t nl, float qr, uint32_t nr, const MathTab &tab)
+                                               uint32_t nd, float ql, uint32_t nl, float qr, uint32_t nr, const TolLnEntry *tab)
 {
     const TolMax m = tol_max(max2(max2(max2(uu, ud), ul), ur));
     float s = tol_term(qu, nu, m.nmax) + tol_term(qd, nd, m.nmax);
     s = s + tol_term(ql, nl, m.nmax);
     s = s + tol_term(qr, nr, m.nmax);
-    return tol_finish(s, m, kLn4, tab);
+    return tol_finish<4>(s, m, kLn4, tab);
 }
 // x0-1, x0+1, x1-1, x1+1, x2-1, x2+1 (harmonic_cpu.cpp:118-123)
 __device__ __forceinline__ float tol_update_3d(float u0, float u1, float u2, float u3, float u4, float u5, float q0, uint32_t n0,
                                                float q1, uint32_t n1, float q2, uint32_t n2, float q3, uint32_t n3, float q4,
-                                               uint32_t n4, float q5, uint32_t n5, const MathTab &tab)
+                                               uint32_t n4, float q5, uint32_t n5, const TolLnEntry *tab)
 {
     const TolMax m = tol_max(max2(max2(max2(max2(max2(u0, u1), u2), u3), u4), u5));
     float s = tol_term(q0, n0, m.nmax) + tol_term(q1, n1, m.nmax);
@@ -308,7 +462,7 @@ __device__ __forceinline__ float tol_update_3d(float u0, float u1, float u2, flo
     s = s + tol_term(q3, n3, m.nmax);
     s = s + tol_term(q4, n4, m.nmax);
     s = s + tol_term(q5, n5, m.nmax);
-    return tol_finish(s, m, kLn6, tab);
+    return tol_finish<5>(s, m, kLn6, tab);
 }
 
 // ---- selects on lane masks held in SGPR pairs ----------------------------------------------------------------------

@@ -49,9 +49,10 @@ struct Ctx {
     int rows_per_task = 0;         // 0 = automatic
     int math = 0;                  // 0 = precise (default), 1 = fast, 2 = traffic, 4 = tol; EPIC_HIP_MATH / epic_hip_set_math_mode
     // Launch-bound grids replay the plain sweeps between two checks from a captured hipGraph; key = (count, starting
-    // buffer, starting parity, math, scheme, rows_per_task) -- everything a captured launch sequence depends on.
-    struct Replay { hipGraphExec_t exec; int cur_flip; };  // cur_flip: whether the sequence ends in the other buffer
-    std::map<std::tuple<unsigned, int, int, int, int, int>, Replay> graphs;
+    // buffer, starting parity, math, scheme, rows_per_task, fused-pass configuration) -- everything a captured launch
+    // sequence depends on.
+    struct Replay { hipGraphExec_t exec; int cur_flip; double work; };  // cur_flip: whether the sequence ends in the other buffer; work: what it adds to work_full
+    std::map<std::tuple<unsigned, int, int, int, int, int, int>, Replay> graphs;
     bool graphs_broken = false;    // a capture / instantiate / launch failed once: batches run eagerly from then on
     // Activity tracking: every iteration lists the tiles its successor has to recompute; tiles whose inputs did
     // not change are never touched (bit-identical results, see kernels_2d.hip).  One device block `wake` holds 3 counter
@@ -65,11 +66,17 @@ struct Ctx {
     size_t act_tiles = 0;
     static constexpr size_t kL = epic_hip::kWakeListCount, kCS = epic_hip::kWakeCounterStride;
     uint32_t *wake_counter(int set) const { return wake + kL * kCS * set; }
-    uint32_t *wake_queued(int i) const { return wake + 3 * kL * kCS + (size_t)i * act_tiles; }
-    uint32_t *wake_list(int i) const { return wake + 3 * kL * kCS + 2 * act_tiles + (size_t)i * kL * epic_hip::sweep_2d_list_cap(act_tiles); }
-    static size_t wake_words(size_t tiles) { return 3 * kL * kCS + 2 * tiles + 2 * kL * epic_hip::sweep_2d_list_cap(tiles); }
-    static size_t wake_zeroed_words(size_t tiles) { return 3 * kL * kCS + 2 * tiles; }  // counters and marks; lists need no init
-    bool redblack = false;         // 2-D scheme: false = Jacobi ping-pong (default), true = in-place red-black (EPIC_HIP_SCHEME)
+    uint32_t *wake_list(int i) const { return wake + 3 * kL * kCS + 2 + 2 * act_tiles + (size_t)i * kL * epic_hip::sweep_2d_list_cap(act_tiles); }
+    // two words behind the counters: the running sum (64 bits) of the tiles handed to list-driven launches
+    unsigned long long *wake_total() const { return reinterpret_cast<unsigned long long *>(wake + 3 * kL * kCS); }
+    uint32_t *wake_queued(int i) const { return wake + 3 * kL * kCS + 2 + (size_t)i * act_tiles; }
+    static size_t wake_words(size_t tiles) { return 3 * kL * kCS + 2 + 2 * tiles + 2 * kL * epic_hip::sweep_2d_list_cap(tiles); }
+    static size_t wake_zeroed_words(size_t tiles) { return 3 * kL * kCS + 2 + 2 * tiles; }  // counters, sum and marks; lists need no init
+    // Work accounting (epic_hip_work_done): whole-grid iterations' worth of cells recomputed since the last reset.  Launches
+    // that run every tile count 1 (a fused pass 2) on the host; list-driven launches add their tile counts on the device.
+    double work_full = 0.0;
+    bool redblack = true;          // scheme: true = the reference's in-place red-black half-sweeps (default: with the precise math that is
+                                   // harmonic_complete_cpu bit for bit), false = Jacobi ping-pong (EPIC_HIP_SCHEME=jacobi / epic_hip_set_scheme)
     // Multi-device mode (EPIC_HIP_DEVICES=0,1,... ; 2-D grids): the rows are cut into one slab per listed device, every
     // interior side carries `halo` ghost rows that are swept like owned rows and traded every `halo` iterations (see the
     // "several devices in one process" section below).  buf / maskw / d_delta / stream above then stay unused.
@@ -104,6 +111,7 @@ std::mutex g_mu;
 std::unordered_map<Harmonic *, Ctx *> g_ctx;
 
 void resolve_tracking(Ctx *c);
+void fold_listed_work(Ctx *c);
 void drop_graphs(Ctx *c);  // captured launch sequences hold the buffer addresses: drop them whenever a buffer goes away
 bool multi_plan(Ctx *c);   // multi-device mode (EPIC_HIP_DEVICES): see "several devices in one process" below
 void multi_destroy(Ctx *c);
@@ -194,6 +202,7 @@ Ctx *get_ctx(Harmonic *h, bool create)
     if (e && strcmp(e, "tol") == 0) c->math = 4;
     e = getenv("EPIC_HIP_SCHEME");
     if (e && strcmp(e, "redblack") == 0) c->redblack = true;
+    if (e && strcmp(e, "jacobi") == 0) c->redblack = false;
     e = getenv("EPIC_HIP_TRACK");
     if (e && (strcmp(e, "0") == 0 || strcmp(e, "1") == 0)) c->track_mode = atoi(e);
     e = getenv("EPIC_HIP_HALO");
@@ -293,13 +302,14 @@ hipError_t enqueue_sweep(Ctx *c, bool check, unsigned iteration)
     const float *in = c->buf[c->cur];
     float *out = c->buf[c->cur ^ 1];
     // wake lists of this iteration (2-D only); (re)allocated when the tiling changes
-    epic_hip::Activity act = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    epic_hip::Activity act = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (c->track) {
         const int rpt = c->n == 2 ? auto_rows_per_task(c) : 32;   // the 3-D kernel has a fixed task shape
         const size_t tiles = c->n == 2 ? epic_hip::sweep_2d_tiles(c->rows, c->pitch, rpt)
                                        : epic_hip::sweep_3d_tiles(c->m[0], c->m[1], c->pitch);
         if (tiles != c->act_tiles || rpt != c->act_rpt) {
             drop_graphs(c);  // captured sequences hold the old lists (never reached during a capture: force > 0)
+            fold_listed_work(c);  // the sum kept in the old block
             if (c->wake) (void)hipFree(c->wake);
             c->wake = nullptr;
             c->act_tiles = 0;
@@ -324,8 +334,10 @@ hipError_t enqueue_sweep(Ctx *c, bool check, unsigned iteration)
             act.count_zero = c->wake_counter((ci + 2) % 3);
             act.queued_in = c->wake_queued(li);
             act.queued_out = c->wake_queued(li ^ 1);
+            act.total = c->wake_total();
         }
     }
+    if (!act.list_in) c->work_full += 1.0;  // every tile runs (untracked, or a forced iteration of a tracked run)
     auto advance = [&](hipError_t e) {
         if (e == hipSuccess && act.list_out) {
             c->phase = (c->phase + 1) % 6;
@@ -350,6 +362,20 @@ hipError_t enqueue_sweep(Ctx *c, bool check, unsigned iteration)
                                               check ? c->d_delta : nullptr, c->stream, &act));
     if (e == hipSuccess) c->cur ^= 1;
     return e;
+}
+
+// Adds what the device has summed for the list-driven launches (in tiles) to the host's count and clears it; waits for
+// the stream.
+void fold_listed_work(Ctx *c)
+{
+    if (!c->wake || c->act_tiles == 0) return;
+    unsigned long long t = 0;
+    if (hipStreamSynchronize(c->stream) == hipSuccess &&
+        hipMemcpy(&t, c->wake_total(), sizeof t, hipMemcpyDeviceToHost) == hipSuccess &&
+        hipMemset(c->wake_total(), 0, sizeof t) == hipSuccess)
+        c->work_full += (double)t / (double)c->act_tiles;
+    else
+        (void)hipGetLastError();
 }
 
 void drop_graphs(Ctx *c)
@@ -418,7 +444,7 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
                                           : epic_hip::launch_jacobi_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows,
                                                                              c->pitch, jacobi_fused_rows_per_task(c), c->math, c->stream);
                 if (e != hipSuccess) return e;
-                if (!c->multi()) c->cur ^= 1;
+                if (!c->multi()) { c->cur ^= 1; c->work_full += 2.0; }
                 i += 2;
             } else {
                 hipError_t e = enqueue_sweep(c, false, first + i);
@@ -433,6 +459,7 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
                                                         jacobi_fused_rows_per_task(c), c->math, c->stream, (int)((first + i) & 1u));
         if (e != hipSuccess) return e;
         c->cur ^= 1;
+        c->work_full += 2.0;
         i += 2;
     }
     while (fuse && count - i >= 2) {
@@ -440,6 +467,7 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
                                                     fused_rows_per_task(c), c->math, (int)((first + i) & 1u), c->stream);
         if (e != hipSuccess) return e;
         c->cur ^= 1;
+        c->work_full += 2.0;
         i += 2;
     }
     for (; i < count; i++) {
@@ -456,14 +484,18 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
     // a captured sequence bakes in the work-list buffers and list mode: run eagerly until the forced iterations are over
     if (!small || count < 8 || no_graph || c->multi() || (c->track && (c->force > 0 || c->act_tiles == 0)))
         return enqueue_plain_run(c, count, first);
+    // (the fused-pass switches are read per batch -- EPIC_HIP_NO_FUSE, EPIC_HIP_FUSE_MIN_CELLS, EPIC_HIP_FUSED_ROWS --, so they
+    // belong to the key: 0 = single sweeps, otherwise the task height of the pass)
+    const int fuse_cfg = fuses_tol(c) ? jacobi_fused_rows_per_task(c) : 0;
     const auto key = std::make_tuple(count, c->cur + 2 * (c->track ? 1 + c->phase : 0), (int)(first & 1u), c->math,
-                                     (int)c->redblack, auto_rows_per_task(c));
+                                     (int)c->redblack, auto_rows_per_task(c), fuse_cfg);
     if (c->graphs_broken) return enqueue_plain_run(c, count, first);
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         // Capture is an optimisation: whatever goes wrong in it (begin, a launch during capture, end, instantiate), the
         // state is put back as it was, the error is cleared, the context stops trying and the batch runs eagerly.
         const int cur0 = c->cur, phase0 = c->phase, force0 = c->force;
+        const double work0 = c->work_full;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
@@ -476,6 +508,8 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
         c->cur = cur0;  // nothing has run yet
         c->phase = phase0;
         c->force = force0;
+        const double work = c->work_full - work0;
+        c->work_full = work0;
         if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         if (graph) (void)hipGraphDestroy(graph);
         if (e != hipSuccess) {
@@ -484,7 +518,7 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
             return enqueue_plain_run(c, count, first);
         }
         if (c->graphs.size() >= 16) drop_graphs(c);
-        it = c->graphs.emplace(key, Ctx::Replay{exec, cur_flip}).first;
+        it = c->graphs.emplace(key, Ctx::Replay{exec, cur_flip, work}).first;
     }
     hipError_t e = hipGraphLaunch(it->second.exec, c->stream);
     if (e != hipSuccess) {  // nothing was enqueued: run the batch eagerly instead, and stop replaying
@@ -493,6 +527,7 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
         return enqueue_plain_run(c, count, first);
     }
     c->cur ^= it->second.cur_flip;
+    c->work_full += it->second.work;
     if (c->track) c->phase = (int)((c->phase + count) % 6);
     return hipSuccess;
 }
@@ -763,7 +798,7 @@ int multi_upload_locked(Harmonic *h, Ctx *c, const char *fn)
         (void)hipFree(tmp);
         if (rc != EPIC_SUCCESS) return rc;
     }
-    c->since = 0;  // the ghost rows were just uploaded with everything else: exact
+    // (`since` is left alone: the mask does not refresh the ghost rows of u -- multi_upload_u does, and resets the countdown)
     return EPIC_SUCCESS;
 }
 
@@ -845,6 +880,7 @@ hipError_t multi_sweep(Ctx *c, bool check, unsigned iteration)
         c->since++;
     }
     if (!c->redblack) c->cur ^= 1;
+    c->work_full += 1.0;
     return hipSuccess;
 }
 
@@ -862,6 +898,7 @@ hipError_t multi_sweep_pair(Ctx *c)
     }
     c->since += 2;
     c->cur ^= 1;
+    c->work_full += 2.0;
     return hipSuccess;
 }
 
@@ -1283,7 +1320,7 @@ int harmonic_get_potential_values_gpu(Harmonic *harmonic)  // harmonic_gpu.cu:41
 }
 
 // harmonic_execute_gpu: should the plain batch that follows a check run without the work lists?  (see the call site)
-bool bypass_lists_for_batch(Ctx *c)
+static bool bypass_lists_for_batch(Ctx *c)
 {
     // (c->force > 0 is fine: a forced iteration runs every tile but still lists the tiles it changed)
     if (!c->track || c->track_mode != 2 || c->act_tiles == 0 || c->multi()) return false;
@@ -1325,6 +1362,8 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
     }
 
     harmonic->currentIteration = 0;
+    fold_listed_work(c);
+    c->work_full = 0.0;  // epic_hip_work_done counts from here
     int result = harmonic_initialize_gpu(harmonic, numThreads);
     if (result != EPIC_SUCCESS) {
         report(fn, "Failed to initialize GPU variables.");
@@ -1557,8 +1596,12 @@ int epic_hip_timed_sweeps_gpu(Harmonic *harmonic, unsigned int sweeps, unsigned 
         *elapsed_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return rc;
     }
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return EPIC_ERROR_DEVICE_MALLOC;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        (void)hipGetLastError();
+        if (e0) (void)hipEventDestroy(e0);
+        return EPIC_ERROR_DEVICE_MALLOC;
+    }
     int rc = EPIC_SUCCESS;
     (void)hipEventRecord(e0, c->stream);
     bool checked = false;
@@ -1748,6 +1791,17 @@ int epic_hip_activity_stats2(Harmonic *harmonic, unsigned long long *active_tile
     *active_tiles = c->force > 0 ? c->act_tiles : pair[1];
     if (due_tiles) *due_tiles = c->force > 0 ? c->act_tiles : pair[0];
     *tiles = c->act_tiles;
+    return EPIC_SUCCESS;
+}
+
+int epic_hip_work_done(Harmonic *harmonic, double *grid_iterations, int reset)
+{
+    Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
+    if (!c || !grid_iterations) return EPIC_ERROR_INVALID_DATA;
+    if (c->multi()) { DeviceGuard g; multi_sync(c); }
+    fold_listed_work(c);
+    *grid_iterations = c->work_full;
+    if (reset) c->work_full = 0.0;
     return EPIC_SUCCESS;
 }
 

@@ -24,6 +24,7 @@ struct Activity {
     uint32_t *count_zero;
     uint32_t *queued_in;
     uint32_t *queued_out;
+    unsigned long long *total;   // running sum of the tiles the list-driven launches were handed (epic_hip_work_done)
 };
 inline size_t sweep_2d_tiles(int rows, int pitch, int rows_per_task)
 {

@@ -75,6 +75,7 @@ struct Sweep2dArgs {
     // the last row of the tile above and the first row of the tile below (5-point stencil).
     WakeArgs wake;
     int nchunks;
+    int nblocks;            // logical blocks (ceil(ntasks / 4)): a launch may hold fewer workgroups, which then walk them (tol math)
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (b % 8 labels the XCD group).  Give each group a
@@ -106,15 +107,20 @@ template <bool CHECK, int MATH, bool RB, bool TRACK> struct SweepOcc {
 template <bool CHECK, int MATH, bool RB, bool TRACK>
 __global__ __launch_bounds__(kWave * kWavesPerBlock, (SweepOcc<CHECK, MATH, RB, TRACK>::kMinWaves)) EPIC_SWEEP_OCC void sweep2d_kernel(Sweep2dArgs a)
 {
-    __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];  // glibc's expf / logf tables (precise math only)
+    constexpr bool TOL = MATH == kMathTol;  // one split (exp-class evaluation) per cell, shared by its neighbours (cell_update.h)
+    // precise math: glibc's expf / logf tables (3 KiB, every wave writes them itself); tol math: the table of its own
+    // logarithm (16 KiB, copied by the whole workgroup before anything else happens -- one barrier, no wave has left yet)
+    __shared__ __attribute__((aligned(16))) char math_lds_bytes[TOL ? TolLn<4>::kLdsBytes : kMathLdsDoubles * (int)sizeof(double)];
+    double *const math_lds = reinterpret_cast<double *>(math_lds_bytes);
+    const TolLnEntry *const tl = reinterpret_cast<const TolLnEntry *>(math_lds_bytes);
+    if (TOL) TolLn<4>::stage(reinterpret_cast<TolLnEntry *>(math_lds_bytes));
     // libm tables in LDS (precise math only): fetched here, written to LDS only after the first task's row loads are
     // under way, so that the fetch from constant memory hides behind them (the small ROS maps run one row per wave:
     // 3.45 -> 2.95 us per sweep of the 482 x 482 map)
     const MathTab lds = math_tables_at(math_lds);
     MathTabRegs tab_regs = {};
-    constexpr bool TOL = MATH == kMathTol;  // one split (exp-class evaluation) per cell, shared by its neighbours (cell_update.h)
-    if (MATH == kMathPrecise || TOL) tab_regs = math_tables_fetch();
-    bool tables_pending = MATH == kMathPrecise || TOL;
+    if (MATH == kMathPrecise) tab_regs = math_tables_fetch();
+    bool tables_pending = MATH == kMathPrecise;
     const int lane = threadIdx.x & (kWave - 1);
     // wave-uniform quantities are forced into SGPRs: the row loop, its addresses and branches are scalar
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -127,11 +133,17 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (SweepOcc<CHECK, MATH, RB, 
     const int rlast = a.rows - 1;
     const size_t pitch = (size_t)a.pitch;
 
-    for (;;) {  // one pass per task: exactly one unless the launch is list-driven
+    int vb = blockIdx.x;  // logical block of this pass (launches with fewer workgroups than logical blocks walk them)
+    for (;;) {  // one pass per task: exactly one unless the launch is list-driven or holds fewer workgroups than blocks
     int task;
     if (listed) task = wake_tile(a.wake, cursor);
-    else task = xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
-    if (task >= a.ntasks) break;
+    else task = xcd_contiguous_block(vb, a.nblocks) * kWavesPerBlock + wave;
+    if (task >= a.ntasks) {  // the spare waves of the last logical block
+        if (listed) break;
+        vb += gridDim.x;
+        if (vb >= a.nblocks) break;
+        continue;
+    }
     if (TRACK && lane == 0) a.wake.queued_in[task] = 0;
     const int strip = task % a.nstrips;
     const int chunk = task / a.nstrips;
@@ -206,14 +218,46 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (SweepOcc<CHECK, MATH, RB, 
             const float ql = wave_from_left(sc.qw, he.ql), qr = wave_from_right(sc.qx, he.qr);
             const uint32_t nl = f2u(wave_from_left(u2f(sc.nw), he.zl)), nr = f2u(wave_from_right(u2f(sc.nx), he.zr));
             o = c;
+            // the cells of the row this iteration updates, two at a time in the three phases of cell_update.h (tol_pre2_2d,
+            // tol_ln_issue / tol_ln_wait, tol_post2): the table reads of one pair are in flight while the other pair is worked on
             const bool odd_cols = !RB || ((r + a.parity) & 1) == 0, even_cols = !RB || !odd_cols;  // scalar
-            if (even_cols) {
-                o.x = sel(h.m0, c.x, tol_update_2d(up.x, dn.x, lf, c.y, su.qx, su.nx, sd.qx, sd.nx, ql, nl, sc.qy, sc.ny, lds));
-                o.z = sel(h.m2, c.z, tol_update_2d(up.z, dn.z, c.y, c.w, su.qz, su.nz, sd.qz, sd.nz, sc.qy, sc.ny, sc.qw, sc.nw, lds));
-            }
-            if (odd_cols) {
-                o.y = sel(h.m1, c.y, tol_update_2d(up.y, dn.y, c.x, c.z, su.qy, su.ny, sd.qy, sd.ny, sc.qx, sc.nx, sc.qz, sc.nz, lds));
-                o.w = sel(h.m3, c.w, tol_update_2d(up.w, dn.w, c.z, rt, su.qw, su.nw, sd.qw, sd.nw, sc.qz, sc.nz, qr, nr, lds));
+            auto pre_xz = [&] {
+                return tol_pre2_2d(up.x, dn.x, lf, c.y, su.qx, su.nx, sd.qx, sd.nx, ql, nl, sc.qy, sc.ny,
+                                   up.z, dn.z, c.y, c.w, su.qz, su.nz, sd.qz, sd.nz, sc.qy, sc.ny, sc.qw, sc.nw);
+            };
+            auto pre_yw = [&] {
+                return tol_pre2_2d(up.y, dn.y, c.x, c.z, su.qy, su.ny, sd.qy, sd.ny, sc.qx, sc.nx, sc.qz, sc.nz,
+                                   up.w, dn.w, c.z, rt, su.qw, su.nw, sd.qw, sd.nw, sc.qz, sc.nz, qr, nr);
+            };
+            float nx, ny, nz, nw;
+            TolLnRaw ea, eb;
+            if (!RB) {
+                const TolPre2 pxz = pre_xz();
+                TolLnPair f0 = tol_ln_issue<4>(pxz, tl);
+                const TolPre2 pyw = pre_yw();
+                TolLnPair f1 = tol_ln_issue<4>(pyw, tl);
+                tol_ln_wait<2>(f0, ea, eb);
+                tol_post2(pxz, ea, eb, kLn4, nx, nz);
+                o.x = sel(h.m0, c.x, nx);
+                o.z = sel(h.m2, c.z, nz);
+                tol_ln_wait<0>(f1, ea, eb);
+                tol_post2(pyw, ea, eb, kLn4, ny, nw);
+                o.y = sel(h.m1, c.y, ny);
+                o.w = sel(h.m3, c.w, nw);
+            } else if (even_cols) {
+                const TolPre2 pxz = pre_xz();
+                TolLnPair f0 = tol_ln_issue<4>(pxz, tl);
+                tol_ln_wait<0>(f0, ea, eb);
+                tol_post2(pxz, ea, eb, kLn4, nx, nz);
+                o.x = sel(h.m0, c.x, nx);
+                o.z = sel(h.m2, c.z, nz);
+            } else {
+                const TolPre2 pyw = pre_yw();
+                TolLnPair f1 = tol_ln_issue<4>(pyw, tl);
+                tol_ln_wait<0>(f1, ea, eb);
+                tol_post2(pyw, ea, eb, kLn4, ny, nw);
+                o.y = sel(h.m1, c.y, ny);
+                o.w = sel(h.m3, c.w, nw);
             }
         } else if (RB) {
             o = c;
@@ -372,7 +416,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (SweepOcc<CHECK, MATH, RB, 
         if (lane == 4) { t = task + a.nstrips; want = chunk + 1 < a.nchunks && last_row; }   // the tile below
         wake_push(a.wake, t, want && lane < 5);
     }
-    if (!listed || !wake_next(cursor)) break;
+    if (listed) { if (!wake_next(cursor)) break; }
+    else { vb += gridDim.x; if (vb >= a.nblocks) break; }
     }  // task loop
 
     if (CHECK) {
@@ -425,6 +470,13 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
     const int rlo = max(r0 - 2, 0);  // rows r0 - 2 .. r1 + 2 are touched
     const __amdgpu_buffer_rsrc_t rin = raw_buffer(a.in + (size_t)rlo * pitch), rout = raw_buffer(a.out + (size_t)rlo * pitch);
     const unsigned lane_off = (unsigned)lcol * 4u;
+    // Stores: the halo lanes (and lanes past the last column) must not write.  A branch around the store would do -- and did,
+    // until the ISA showed what it costs: with a store that may or may not have been issued the compiler can no longer count
+    // the memory operations in flight behind the row it is waiting for, waits for vmcnt(0) / vmcnt(1) at the top of every step,
+    // and with that for the acknowledgement of the store issued a moment ago (37 % of all wave cycles parked at s_waitcnt).
+    // Instead every lane stores, the lanes that own nothing at an offset beyond the descriptor's range, where the hardware
+    // drops the write (raw buffers check voffset against num_records = 2 GiB): one store per step, exact counts.
+    const unsigned store_off = owner ? lane_off : 0x80000000u;
     auto row_off = [&](int r) -> unsigned { return (unsigned)((r - rlo) * a.pitch) * 4u; };  // r already clamped
     auto ld = [&](int r) -> float4 {
         r = min(max(r, 0), rlast);
@@ -484,8 +536,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
         mr = stage(r + 1, false, mq, o1, o2, knext);           // colour A of row r+1: up = row r (its B cells still old)
         const float4 x = stage(r, true, mp, mq, mr, kcur);    // colour B of row r from the fresh A cells around it
         kcur = knext;
-        if (owner)  // non-temporal, as in the plain sweep
-            store_row(rout, x.x, x.y, x.z, x.w, lane_off, row_off(r));
+        store_row(rout, x.x, x.y, x.z, x.w, store_off, row_off(r));  // non-temporal, as in the plain sweep
     };
     int r = r0;
     for (; r + 3 <= r1; r += 3) {
@@ -524,13 +575,16 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
 // cell is recomputed once per pass (4 B of HBM traffic per cell-update against 16 for the in-place half-sweep), the rows
 // are split twice (before level A, and after it for level B).  Bit-identical to two in-place half-sweeps.
 template <bool RB>
-__device__ __forceinline__ void tol_fused_pass(const Sweep2dArgs &a, double *math_lds)
+__device__ __forceinline__ void tol_fused_pass(const Sweep2dArgs &a, TolLnEntry *math_lds)
 {
-    const MathTab lds = math_tables_load(math_lds);
+    TolLn<4>::stage(math_lds);  // the whole workgroup, one barrier: before any wave may find itself without a task
+    const TolLnEntry *const tl = math_lds;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int task = xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
-    if (task >= a.ntasks) return;
+    // the launch holds as many workgroups as the chip keeps resident; each walks its share of the logical blocks
+    for (int vb = blockIdx.x; vb < a.nblocks; vb += gridDim.x) {
+    const int task = xcd_contiguous_block(vb, a.nblocks) * kWavesPerBlock + wave;
+    if (task >= a.ntasks) continue;
     const int strip = task % a.nstrips;
     const int chunk = task / a.nstrips;
     const int r0 = a.row_begin + chunk * a.rows_per_task;
@@ -545,28 +599,47 @@ __device__ __forceinline__ void tol_fused_pass(const Sweep2dArgs &a, double *mat
     const int rlo = max(r0 - 2, 0);  // rows r0 - 2 .. r1 + 4 are touched (clamped to the grid)
     const __amdgpu_buffer_rsrc_t rin = raw_buffer(a.in + (size_t)rlo * pitch), rout = raw_buffer(a.out + (size_t)rlo * pitch);
     const unsigned lane_off = (unsigned)lcol * 4u;
+    // Stores: the halo lanes (and lanes past the last column) must not write.  A branch around the store would do -- and did,
+    // until the ISA showed what it costs: with a store that may or may not have been issued the compiler can no longer count
+    // the memory operations in flight behind the row it is waiting for, waits for vmcnt(0) / vmcnt(1) at the top of every step,
+    // and with that for the acknowledgement of the store issued a moment ago (37 % of all wave cycles parked at s_waitcnt).
+    // Instead every lane stores, the lanes that own nothing at an offset beyond the descriptor's range, where the hardware
+    // drops the write (raw buffers check voffset against num_records = 2 GiB): one store per step, exact counts.
+    const unsigned store_off = owner ? lane_off : 0x80000000u;
     auto row_off = [&](int r) -> unsigned { return (unsigned)((r - rlo) * a.pitch) * 4u; };  // r already clamped
     auto ld = [&](int r) -> float4 {
         r = min(max(r, 0), rlast);
         const vu4 q = __builtin_amdgcn_raw_buffer_load_b128(rin, lane_off, row_off(r), 0);
         return make_float4(u2f(q.x), u2f(q.y), u2f(q.z), u2f(q.w));
     };
-    // lane masks of a row for this kernel's lane -> column mapping: as in rb_fused2d_kernel
+    // lane masks of a row for this kernel's lane -> column mapping (lane L holds quad strip * 62 - 1 + L of the row, the stored
+    // masks are cut at multiples of 64 quads): a funnel shift of two neighbouring mask words, all scalar.  In two phases: the
+    // eight words are FETCHED (two s_load_dwordx8, nothing depends on them yet) at the top of a step and CUT at its end.
+    // (As one function with a test of `sh` between the loads -- round 2 -- the wave made eight scalar-memory round trips in a
+    // row at the end of every step: the larger part of the 28-37 % of wave cycles spent at s_waitcnt.)
     typedef const __attribute__((address_space(4))) uint64_t cu64;
     struct RowMask { lmask m0, m1, m2, m3; };
+    struct RowMaskRaw { lmask lo0, lo1, lo2, lo3, hi0, hi1, hi2, hi3; };
     const int nstd = a.pitch >> 8;
     const int g0 = strip * (kFusedOut / kColsPerLane) - 1;
     const int sw = max(g0, 0) >> 6, sh = max(g0, 0) & 63, sw1 = min(sw + 1, nstd - 1);
-    auto row_mask = [&](int r) -> RowMask {
+    auto mask_fetch = [&](int r) -> RowMaskRaw {
+#ifdef EPIC_EXP_NOMASK  // timing experiment only (wrong results): no mask loads at all
+        return RowMaskRaw{0, 0, 0, 0, 0, 0, 0, 0};
+#endif
         r = min(max(r, 0), rlast);
         cu64 *lo = (cu64 *)a.maskw + ((size_t)r * nstd + sw) * 4, *hi = (cu64 *)a.maskw + ((size_t)r * nstd + sw1) * 4;
-        auto cut = [&](int j) -> lmask {
-            lmask m = lo[j];
-            if (sh) m = (m >> sh) | (hi[j] << (64 - sh));
+        return RowMaskRaw{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    auto mask_cut = [&](const RowMaskRaw &w) -> RowMask {
+        // (lo >> sh) | (hi << (64 - sh)) without a branch for sh = 0: (hi << 1) << (63 - sh) is 0 there
+        auto cut = [&](lmask lo, lmask hi) -> lmask {
+            const lmask m = (lo >> sh) | ((hi << 1) << (63 - sh));
             return g0 < 0 ? m << 1 : m;
         };
-        return RowMask{cut(0), cut(1), cut(2), cut(3)};
+        return RowMask{cut(w.lo0, w.hi0), cut(w.lo1, w.hi1), cut(w.lo2, w.hi2), cut(w.lo3, w.hi3)};
     };
+    auto row_mask = [&](int r) -> RowMask { return mask_cut(mask_fetch(r)); };
     // One iteration of one row from its three rows and their splits.  The outer cells of the halo lanes have no neighbour
     // on one side: the shift gives them zero bits there (bound_ctrl: one instruction, no edge operand to set up) -- their
     // results are never stored and never read by an owned cell.
@@ -576,17 +649,50 @@ __device__ __forceinline__ void tol_fused_pass(const Sweep2dArgs &a, double *mat
     auto level = [&](const float4 &up, const float4 &c, const float4 &dn, const Split4 &su, const Split4 &sc, const Split4 &sd,
                      const RowMask &k, bool odd_cols) -> float4 {
         float4 o = c;
-        if (!RB || !odd_cols) {
+        // the cells this level updates, two at a time in the three phases of cell_update.h: the table reads of one pair are in
+        // flight while the other pair is worked on
+        const bool even = !RB || !odd_cols;
+        auto pre_xz = [&] {
             const float lf = shl(c.w), ql = shl(sc.qw);
             const uint32_t nl = f2u(shl(u2f(sc.nw)));
-            o.x = sel(k.m0, c.x, tol_update_2d(up.x, dn.x, lf, c.y, su.qx, su.nx, sd.qx, sd.nx, ql, nl, sc.qy, sc.ny, lds));
-            o.z = sel(k.m2, c.z, tol_update_2d(up.z, dn.z, c.y, c.w, su.qz, su.nz, sd.qz, sd.nz, sc.qy, sc.ny, sc.qw, sc.nw, lds));
-        }
-        if (!RB || odd_cols) {
+            return tol_pre2_2d(up.x, dn.x, lf, c.y, su.qx, su.nx, sd.qx, sd.nx, ql, nl, sc.qy, sc.ny,
+                               up.z, dn.z, c.y, c.w, su.qz, su.nz, sd.qz, sd.nz, sc.qy, sc.ny, sc.qw, sc.nw);
+        };
+        auto pre_yw = [&] {
             const float rt = shr(c.x), qr = shr(sc.qx);
             const uint32_t nr = f2u(shr(u2f(sc.nx)));
-            o.y = sel(k.m1, c.y, tol_update_2d(up.y, dn.y, c.x, c.z, su.qy, su.ny, sd.qy, sd.ny, sc.qx, sc.nx, sc.qz, sc.nz, lds));
-            o.w = sel(k.m3, c.w, tol_update_2d(up.w, dn.w, c.z, rt, su.qw, su.nw, sd.qw, sd.nw, sc.qz, sc.nz, qr, nr, lds));
+            return tol_pre2_2d(up.y, dn.y, c.x, c.z, su.qy, su.ny, sd.qy, sd.ny, sc.qx, sc.nx, sc.qz, sc.nz,
+                               up.w, dn.w, c.z, rt, su.qw, su.nw, sd.qw, sd.nw, sc.qz, sc.nz, qr, nr);
+        };
+        float nx, ny, nz, nw;
+        TolLnRaw ea, eb;
+        if (!RB) {
+            const TolPre2 pxz = pre_xz();
+            TolLnPair f0 = tol_ln_issue<4>(pxz, tl);
+            const TolPre2 pyw = pre_yw();
+            TolLnPair f1 = tol_ln_issue<4>(pyw, tl);
+            tol_ln_wait<2>(f0, ea, eb);
+            tol_post2(pxz, ea, eb, kLn4, nx, nz);
+            o.x = sel(k.m0, c.x, nx);
+            o.z = sel(k.m2, c.z, nz);
+            tol_ln_wait<0>(f1, ea, eb);
+            tol_post2(pyw, ea, eb, kLn4, ny, nw);
+            o.y = sel(k.m1, c.y, ny);
+            o.w = sel(k.m3, c.w, nw);
+        } else if (even) {
+            const TolPre2 pxz = pre_xz();
+            TolLnPair f0 = tol_ln_issue<4>(pxz, tl);
+            tol_ln_wait<0>(f0, ea, eb);
+            tol_post2(pxz, ea, eb, kLn4, nx, nz);
+            o.x = sel(k.m0, c.x, nx);
+            o.z = sel(k.m2, c.z, nz);
+        } else {
+            const TolPre2 pyw = pre_yw();
+            TolLnPair f1 = tol_ln_issue<4>(pyw, tl);
+            tol_ln_wait<0>(f1, ea, eb);
+            tol_post2(pyw, ea, eb, kLn4, ny, nw);
+            o.y = sel(k.m1, c.y, ny);
+            o.w = sel(k.m3, c.w, nw);
         }
         return o;
     };
@@ -619,32 +725,34 @@ __device__ __forceinline__ void tol_fused_pass(const Sweep2dArgs &a, double *mat
             if (i + j < nrows) {  // scalar
                 const int r = r0 + i + j;
                 u[j % 6] = ld(min(r + 4, r1 + 1));   // slot of row r - 2; past r1 + 1 (nothing needs those rows) the last row again: a cache hit
+                const RowMaskRaw kraw = mask_fetch(r + 2);                       // cut at the end of the step
                 su[(j + 1) % 3] = tol_split4(u[(j + 4) % 6]);                    // row r + 2 (slot of row r - 1's split)
                 m[(j + 2) % 3] = level(u[(j + 2) % 6], u[(j + 3) % 6], u[(j + 4) % 6], su[(j + 2) % 3], su[j % 3],
                                        su[(j + 1) % 3], k[(j + 2) % 3], odd_cols_of(r + 1, 0));   // level A of row r + 1
                 sm[(j + 2) % 3] = tol_split4(m[(j + 2) % 3]);
                 const float4 x = level(m[j % 3], m[(j + 1) % 3], m[(j + 2) % 3], sm[j % 3], sm[(j + 1) % 3], sm[(j + 2) % 3],
                                        k[(j + 1) % 3], odd_cols_of(r, 1));       // level B of row r
-                k[j % 3] = row_mask(r + 2);                                      // slot of row r - 1's masks
-                if (owner) store_row(rout, x.x, x.y, x.z, x.w, lane_off, row_off(r));
+                k[j % 3] = mask_cut(kraw);                                       // slot of row r - 1's masks
+                store_row(rout, x.x, x.y, x.z, x.w, store_off, row_off(r));
             }
         };
         unrolled<kTrip>(step);
     }
+    }  // logical blocks
 }
 
 template <int MATH>
 __global__ __launch_bounds__(kWave * kWavesPerBlock, EPIC_FUSED_MIN_WAVES) void jacobi_fused2d_kernel(Sweep2dArgs a)
 {
     static_assert(MATH == kMathTol, "the fused Jacobi pass exists for the tol math");
-    __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];
+    __shared__ TolLnEntry math_lds[TolLn<4>::kEntries];
     tol_fused_pass<false>(a, math_lds);
 }
 
 // two red-black iterations of the tol math in one pass (the precise / fast math: rb_fused2d_kernel above)
 __global__ __launch_bounds__(kWave * kWavesPerBlock, EPIC_FUSED_MIN_WAVES) void rb_tol_fused2d_kernel(Sweep2dArgs a)
 {
-    __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];
+    __shared__ TolLnEntry math_lds[TolLn<4>::kEntries];
     tol_fused_pass<true>(a, math_lds);
 }
 
@@ -762,6 +870,15 @@ int sweep_flags()
     return flags;
 }
 
+// Workgroups of a launch whose workgroups walk `nblocks` logical blocks: what the chip keeps resident of `kernel`, in whole
+// groups of the 8 XCDs (blocks are dealt round-robin over them; a stride that is a multiple of 8 keeps a workgroup's blocks
+// in its XCD's band).  Unknown occupancy: one workgroup per block, as before.
+int resident_grid(int nblocks, const void *kernel)
+{
+    const int res = resident_blocks_of(kernel) / kNumXcd * kNumXcd;
+    return (res >= kNumXcd && nblocks > res) ? res : nblocks;
+}
+
 template <bool CHECK, bool RB, bool TRACK>
 void launch_sweep_2d_math(int math, int nblocks, hipStream_t stream, const Sweep2dArgs &a)
 {
@@ -771,6 +888,7 @@ void launch_sweep_2d_math(int math, int nblocks, hipStream_t stream, const Sweep
                                                          : sweep2d_kernel<CHECK, kMathPrecise, RB, TRACK>;
     // a list-driven launch is persistent waves: as many as the chip holds of this instantiation
     if (TRACK && a.wake.list_in) nblocks = sweep_2d_list_blocks((size_t)a.ntasks, resident_blocks_of((const void *)kernel));
+    else if (math == kMathTol) nblocks = resident_grid(nblocks, (const void *)kernel);  // every workgroup stages the 16 KiB table once
     const dim3 grid(nblocks), block(kWave * kWavesPerBlock);
     hipLaunchKernelGGL(kernel, grid, block, 0, stream, a);
 }
@@ -815,6 +933,7 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, i
     const bool whole = row_begin == 0 && row_end == rows;
     a.wake = wake_args(whole ? act : nullptr, (size_t)a.ntasks);
     int nblocks = (a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock;
+    a.nblocks = nblocks;
     if (parity < 0) {
         if (delta_bits) launch_sweep_2d_track<true, false>(math, nblocks, stream, a);
         else launch_sweep_2d_track<false, false>(math, nblocks, stream, a);
@@ -831,6 +950,10 @@ hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw
 {
     if (pitch <= 0 || (pitch % 256) != 0 || rows <= 0 || rows_per_task <= 0 || in == out) return hipErrorInvalidValue;
     if (math != kMathPrecise && math != kMathFast && math != kMathTraffic) return hipErrorInvalidValue;  // (tol: in-place half-sweeps)
+    // the kernel addresses a task's rows with 32-bit byte offsets from a base 2 rows above it (rows_per_task + 5 rows)
+    const long long max_rows = 0x7fffffffLL / ((long long)pitch * 4) - 8;
+    if (max_rows < 1) return hipErrorInvalidValue;
+    rows_per_task = (int)std::min<long long>(rows_per_task, max_rows);
     Sweep2dArgs a;
     a.in = in;
     a.out = out;
@@ -847,7 +970,8 @@ hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw
     a.flags = sweep_flags();
     a.nchunks = 0;
     a.wake = wake_args(nullptr, 0);
-    const dim3 grid((a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
+    a.nblocks = (a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock;
+    const dim3 grid(a.nblocks), block(kWave * kWavesPerBlock);
     if (math == kMathFast) hipLaunchKernelGGL((rb_fused2d_kernel<kMathFast>), grid, block, 0, stream, a);
     else if (math == kMathTraffic) hipLaunchKernelGGL((rb_fused2d_kernel<kMathTraffic>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((rb_fused2d_kernel<kMathPrecise>), grid, block, 0, stream, a);
@@ -859,6 +983,10 @@ hipError_t launch_jacobi_fused_2d(const float *in, float *out, const uint32_t *m
 {
     if (pitch <= 0 || (pitch % 256) != 0 || rows <= 0 || rows_per_task <= 0 || in == out) return hipErrorInvalidValue;
     if (math != kMathTol) return hipErrorInvalidValue;
+    // 32-bit byte offsets from a base 2 rows above the task (rows_per_task + 7 rows): as launch_sweep_2d clamps its tasks
+    const long long max_rows = 0x7fffffffLL / ((long long)pitch * 4) - 8;
+    if (max_rows < 1) return hipErrorInvalidValue;
+    rows_per_task = (int)std::min<long long>(rows_per_task, max_rows);
     Sweep2dArgs a;
     a.in = in;
     a.out = out;
@@ -875,9 +1003,10 @@ hipError_t launch_jacobi_fused_2d(const float *in, float *out, const uint32_t *m
     a.flags = sweep_flags();
     a.nchunks = 0;
     a.wake = wake_args(nullptr, 0);
-    const dim3 grid((a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
-    if (parity < 0) hipLaunchKernelGGL((jacobi_fused2d_kernel<kMathTol>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL(rb_tol_fused2d_kernel, grid, block, 0, stream, a);
+    a.nblocks = (a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock;
+    void (*kernel)(Sweep2dArgs) = parity < 0 ? jacobi_fused2d_kernel<kMathTol> : rb_tol_fused2d_kernel;
+    const dim3 grid(resident_grid(a.nblocks, (const void *)kernel)), block(kWave * kWavesPerBlock);
+    hipLaunchKernelGGL(kernel, grid, block, 0, stream, a);
     return hipGetLastError();
 }
 

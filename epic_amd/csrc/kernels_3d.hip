@@ -40,6 +40,7 @@ struct Sweep3dArgs {
     int m0, m1, pitch;
     int plane_begin, plane_end;
     int nstrips, nchunks, nplane_groups;
+    int nblocks;  // logical blocks: nstrips * nchunks * nplane_groups (a tol launch holds fewer workgroups, which walk them)
     int parity;  // red-black scheme only: currentIteration & 1
     WakeArgs wake;  // TRACK kernels, whole-grid launches only
 };
@@ -63,10 +64,14 @@ template <bool CHECK, int MATH, bool RB, bool TRACK> struct Sweep3dOcc {
 template <bool CHECK, int MATH, bool RB, bool TRACK>
 __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB, TRACK>::kMinWaves)) void sweep3d_kernel(Sweep3dArgs a)
 {
-    __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];  // glibc's expf / logf tables (precise math only)
     constexpr bool TOL = MATH == kMathTol;  // one split per cell, shared by the six cells it is a neighbour of (cell_update.h)
-    MathTab lds = {};  // libm tables in LDS (precise and tol math)
-    if (MATH == kMathPrecise || TOL) lds = math_tables_load(math_lds);
+    // precise math: glibc's expf / logf tables (every wave writes them itself); tol math: the table of its own logarithm,
+    // five binades, copied by the whole workgroup before any wave may leave (one barrier)
+    __shared__ __attribute__((aligned(16))) char math_lds_bytes[TOL ? TolLn<5>::kLdsBytes : kMathLdsDoubles * (int)sizeof(double)];
+    const TolLnEntry *const tl = reinterpret_cast<const TolLnEntry *>(math_lds_bytes);
+    if (TOL) TolLn<5>::stage(reinterpret_cast<TolLnEntry *>(math_lds_bytes));
+    MathTab lds = {};
+    if (MATH == kMathPrecise) lds = math_tables_load(reinterpret_cast<double *>(math_lds_bytes));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (TRACK) wake_reset_next(a.wake);
@@ -75,7 +80,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB
     if (listed && !wake_begin(a.wake, lane, wave, kWavesPerBlock, cursor)) return;
     float dmax = 0.0f;
 
-    for (;;) {  // one pass per task: exactly one unless the launch is list-driven
+    int vb = blockIdx.x;  // logical block of this pass
+    for (;;) {  // one pass per task: exactly one unless the launch is list-driven or holds fewer workgroups than blocks
     int strip, chunk, x0;
     if (listed) {
         int t = wake_tile(a.wake, cursor);  // tile id = (x0 * nchunks + chunk) * nstrips + strip
@@ -84,13 +90,18 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB
         chunk = t % a.nchunks;
         x0 = t / a.nchunks;
     } else {
-        int b = blockIdx.x;
+        int b = vb;
         strip = b % a.nstrips;
         b /= a.nstrips;
         chunk = b % a.nchunks;
         x0 = a.plane_begin + (b / a.nchunks) * kWavesPerBlock + wave;
     }
-    if (x0 >= a.plane_end) break;  // wave-uniform
+    if (x0 >= a.plane_end) {  // wave-uniform: the spare waves of the last plane group
+        if (listed) break;
+        vb += gridDim.x;
+        if (vb >= a.nblocks) break;
+        continue;
+    }
     const int tile = (x0 * a.nchunks + chunk) * a.nstrips + strip;
     if (TRACK && lane == 0) a.wake.queued_in[tile] = 0;
     const int r0 = chunk * kRowsPerTask;
@@ -147,17 +158,45 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB
             const uint32_t nl = f2u(wave_from_left(u2f(sc.nw), hs.zm.x)), nr = f2u(wave_from_right(u2f(sc.nx), hs.zm.y));
             o = c;
             const bool even_cols = !RB || ((x0 + r + a.parity) & 1) == 0, odd_cols = !RB || !even_cols;  // scalar
-            if (even_cols) {
-                o.x = sel(h.m0, c.x, tol_update_3d(pa.x, pb.x, up.x, dn.x, lf, c.y, sa.qx, sa.nx, sb.qx, sb.nx, su.qx, su.nx,
-                                                   sd.qx, sd.nx, ql, nl, sc.qy, sc.ny, lds));
-                o.z = sel(h.m2, c.z, tol_update_3d(pa.z, pb.z, up.z, dn.z, c.y, c.w, sa.qz, sa.nz, sb.qz, sb.nz, su.qz, su.nz,
-                                                   sd.qz, sd.nz, sc.qy, sc.ny, sc.qw, sc.nw, lds));
-            }
-            if (odd_cols) {
-                o.y = sel(h.m1, c.y, tol_update_3d(pa.y, pb.y, up.y, dn.y, c.x, c.z, sa.qy, sa.ny, sb.qy, sb.ny, su.qy, su.ny,
-                                                   sd.qy, sd.ny, sc.qx, sc.nx, sc.qz, sc.nz, lds));
-                o.w = sel(h.m3, c.w, tol_update_3d(pa.w, pb.w, up.w, dn.w, c.z, rt, sa.qw, sa.nw, sb.qw, sb.nw, su.qw, su.nw,
-                                                   sd.qw, sd.nw, sc.qz, sc.nz, qr, nr, lds));
+            // the cells this iteration updates, two at a time in the three phases of cell_update.h: the table reads of one pair are
+            // in flight while the other pair is worked on
+            auto pre_xz = [&] {
+                return tol_pre2_3d(TolNb6{pa.x, pb.x, up.x, dn.x, lf, c.y, sa.qx, sb.qx, su.qx, sd.qx, ql, sc.qy, sa.nx, sb.nx, su.nx, sd.nx, nl, sc.ny},
+                                   TolNb6{pa.z, pb.z, up.z, dn.z, c.y, c.w, sa.qz, sb.qz, su.qz, sd.qz, sc.qy, sc.qw, sa.nz, sb.nz, su.nz, sd.nz, sc.ny, sc.nw});
+            };
+            auto pre_yw = [&] {
+                return tol_pre2_3d(TolNb6{pa.y, pb.y, up.y, dn.y, c.x, c.z, sa.qy, sb.qy, su.qy, sd.qy, sc.qx, sc.qz, sa.ny, sb.ny, su.ny, sd.ny, sc.nx, sc.nz},
+                                   TolNb6{pa.w, pb.w, up.w, dn.w, c.z, rt, sa.qw, sb.qw, su.qw, sd.qw, sc.qz, qr, sa.nw, sb.nw, su.nw, sd.nw, sc.nz, nr});
+            };
+            float nx, ny, nz, nw;
+            TolLnRaw ea, eb;
+            if (!RB) {
+                const TolPre2 pxz = pre_xz();
+                TolLnPair f0 = tol_ln_issue<5>(pxz, tl);
+                const TolPre2 pyw = pre_yw();
+                TolLnPair f1 = tol_ln_issue<5>(pyw, tl);
+                tol_ln_wait<2>(f0, ea, eb);
+                tol_post2(pxz, ea, eb, kLn6, nx, nz);
+                o.x = sel(h.m0, c.x, nx);
+                o.z = sel(h.m2, c.z, nz);
+                tol_ln_wait<0>(f1, ea, eb);
+                tol_post2(pyw, ea, eb, kLn6, ny, nw);
+                o.y = sel(h.m1, c.y, ny);
+                o.w = sel(h.m3, c.w, nw);
+            } else if (even_cols) {
+                const TolPre2 pxz = pre_xz();
+                TolLnPair f0 = tol_ln_issue<5>(pxz, tl);
+                tol_ln_wait<0>(f0, ea, eb);
+                tol_post2(pxz, ea, eb, kLn6, nx, nz);
+                o.x = sel(h.m0, c.x, nx);
+                o.z = sel(h.m2, c.z, nz);
+            } else {
+                const TolPre2 pyw = pre_yw();
+                TolLnPair f1 = tol_ln_issue<5>(pyw, tl);
+                tol_ln_wait<0>(f1, ea, eb);
+                tol_post2(pyw, ea, eb, kLn6, ny, nw);
+                o.y = sel(h.m1, c.y, ny);
+                o.w = sel(h.m3, c.w, nw);
             }
         } else if (RB) {
             o = c;
@@ -243,7 +282,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB
         if (lane == 6) { t = tile + per_plane; want = x0 + 1 < a.m0 && any; }
         wake_push(a.wake, t, want && lane < 7);
     }
-    if (!listed || !wake_next(cursor)) break;
+    if (listed) { if (!wake_next(cursor)) break; }
+    else { vb += gridDim.x; if (vb >= a.nblocks) break; }
     }  // task loop
 
     if (CHECK) {
@@ -290,6 +330,10 @@ void launch_sweep_3d_track(int math, dim3 grid, dim3 block, hipStream_t stream, 
                                                      : sweep3d_kernel<CHECK, kMathPrecise, RB, TRACK>;
     // a list-driven launch is persistent waves: as many as the chip holds of this instantiation (kernels.h)
     if (TRACK && a.wake.list_in) grid = dim3((unsigned)sweep_2d_list_blocks(tiles, resident_blocks_of((const void *)kernel)));
+    else if (math == kMathTol) {  // every workgroup stages the 20 KiB table once: as many as the chip keeps resident, in whole groups of 8
+        const int res = resident_blocks_of((const void *)kernel) / 8 * 8;
+        if (res >= 8 && (int)grid.x > res) grid = dim3((unsigned)res);
+    }
     hipLaunchKernelGGL(kernel, grid, block, 0, stream, a);
 }
 template <bool CHECK, bool RB>
@@ -326,6 +370,7 @@ hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, i
     a.nplane_groups = (plane_end - plane_begin + kWavesPerBlock - 1) / kWavesPerBlock;
     const long long nblocks = (long long)a.nstrips * a.nchunks * a.nplane_groups;
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    a.nblocks = (int)nblocks;
     a.parity = parity < 0 ? 0 : (parity & 1);
     const bool whole = plane_begin == 0 && plane_end == m0;
     const size_t tiles = sweep_3d_tiles(m0, m1, pitch);

@@ -39,12 +39,13 @@ struct WakeArgs {
     uint32_t *count_zero;
     uint32_t *queued_in;        // marks of the tiles listed for this launch: cleared as they are taken
     uint32_t *queued_out;       // 1 = already in list_out
+    unsigned long long *total;  // += the number of tiles listed for this launch (list-driven launches only)
     int list_cap;
 };
 
 inline WakeArgs wake_args(const Activity *act, size_t tiles)
 {
-    WakeArgs w = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    WakeArgs w = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (act && act->list_out) {
         w.list_in = act->list_in;
         w.count_in = act->count_in;
@@ -53,6 +54,7 @@ inline WakeArgs wake_args(const Activity *act, size_t tiles)
         w.count_zero = act->count_zero;
         w.queued_in = act->queued_in;
         w.queued_out = act->queued_out;
+        w.total = act->total;
         w.list_cap = (int)sweep_2d_list_cap(tiles);
     }
     return w;
@@ -82,6 +84,7 @@ __device__ __forceinline__ bool wake_begin(const WakeArgs &w, int lane, int wave
         if (lane >= d) k.incl += up;
     }
     const long long all = __builtin_amdgcn_readlane((int)k.incl, 63);
+    if (w.total && blockIdx.x == 0 && wave == 0 && lane == 0) atomicAdd(w.total, (unsigned long long)all);
     k.step = (gridDim.x / kWakeXcds) * waves_per_block;
     k.g = (blockIdx.x / kWakeXcds) * waves_per_block + wave + (int)(all * xcd / kWakeXcds);
     k.end = (int)(all * (xcd + 1) / kWakeXcds);

@@ -65,10 +65,11 @@ int epic_hip_set_rows_per_task(EpicHarmonicT *harmonic, unsigned int rows_per_ta
  * (3 was round 1's df32 mode, removed: EPIC_ERROR_INVALID_DATA.) */
 int epic_hip_set_math_mode(EpicHarmonicT *harmonic, int mode);
 
-/* Iteration scheme of the 2-D solver: 0 = Jacobi ping-pong (default: one iteration recomputes every unlocked cell),
- * 1 = the reference's red-black Gauss-Seidel, in place (one iteration = one colour, libepic/src/harmonic/harmonic_cpu.cpp:
- * 46-51); with the precise math mode every half-sweep, the iteration count and the converged field are bit-identical to
- * harmonic_complete_cpu.  Also EPIC_HIP_SCHEME=jacobi|redblack in the environment at initialisation. */
+/* Iteration scheme: 1 = the reference's red-black Gauss-Seidel, in place (DEFAULT: one iteration = one colour,
+ * libepic/src/harmonic/harmonic_cpu.cpp:46-51, :89-102; with the default precise math every half-sweep, the iteration count
+ * and the converged field are bit-identical to harmonic_complete_cpu), 0 = Jacobi ping-pong (one iteration recomputes
+ * every unlocked cell: what BASELINE.json's metric names and bench.py times; twice the arithmetic for the same answer).
+ * Also EPIC_HIP_SCHEME=jacobi|redblack in the environment at initialisation. */
 int epic_hip_set_scheme(EpicHarmonicT *harmonic, int scheme);
 
 /* Activity tracking: 0 off, 1 on, 2 automatic (default: on for grids above 4 Mcell; also
@@ -103,6 +104,12 @@ int epic_hip_activity_stats(EpicHarmonicT *harmonic, unsigned long long *active_
  * number: the tiles a launch changed are the tiles it lists, apart from woken neighbours); due_tiles may be NULL. */
 int epic_hip_activity_stats2(EpicHarmonicT *harmonic, unsigned long long *active_tiles, unsigned long long *due_tiles,
                              unsigned long long *tiles);
+
+/* Work accounting: how many whole-grid iterations' worth of tiles the kernels have actually RUN since the last reset --
+ * an iteration that runs every tile counts 1 (a fused pass over two iterations 2), a list-driven iteration of a tracked
+ * run counts (tiles listed) / (tiles).  harmonic_execute_gpu resets it when it starts; reset != 0 resets it after reading.
+ * currentIteration minus this number is what activity tracking skipped.  Synchronises the stream. */
+int epic_hip_work_done(EpicHarmonicT *harmonic, double *grid_iterations, int reset);
 
 /* Test hook: d_out[i] = which ? ln(d_in[i]) : exp(d_in[i]) with the precise device routines (which = 0 / 1). */
 int epic_hip_eval_math(const float *d_in, float *d_out, size_t n, int which, void *stream);

@@ -61,31 +61,21 @@ static inline void tol_split(float u, float *q, uint32_t *zb)
     *zb = tol_f2u(zm);
 }
 
-/* glibc logf's table (sysdeps/ieee754/flt-32/e_logf_data.c) and cubic, evaluated in double and NOT rounded to float
- * (cell_update.h: precise_ln_d, including its table layout {invc 2^-k, logc + k ln2}) */
-static const double kTolLogTab[32] = {
-    0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2, 0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2,
-    0x1.49539f0f010bp+0,  -0x1.01eae7f513a67p-2, 0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3,
-    0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3, 0x1.25e227b0b8eap+0,  -0x1.1aa2bc79c81p-3,
-    0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4, 0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4,
-    0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5, 0x1p+0,               0x0p+0,
-    0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5,  0x1.ca4b31f026aap-1,  0x1.c5e53aa362eb4p-4,
-    0x1.b2036576afce6p-1, 0x1.526e57720db08p-3,  0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3,
-    0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2,  0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2,
+/* ln S for S in [0.5, 16): 256 sub-intervals per binade chosen by the top 8 mantissa bits; r = S invc - 1 is EXACT in one
+ * f32 fma (invc = v / 512 2^-k with a 9-bit v: tools/gen_ln_table.py), log1p(r) = r + r^2 (-1/2 + r/3) in f32, the table's
+ * ln c is added in double (cell_update.h: tol_ln_d).  Good to 2^-33 absolute, unbiased to 1e-12. */
+typedef struct { double lnc; float invc; } TolLnEntry;
+static const TolLnEntry kTolLnTab[5 * 256] = {
+#include "tol_ln_table.inc"
 };
-static inline double tol_ln_core(double sd, int i, int k)   /* entry 16 k + i = {invc 2^-k, logc + k ln2} */
-{
-    const double invc = ldexp(kTolLogTab[2 * i], -k), y0 = kTolLogTab[2 * i + 1] + (double)k * 0x1.62e42fefa39efp-1;
-    const double r = fma(sd, invc, -1.0);
-    const double r2 = r * r;
-    double y = fma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);
-    y = fma(-0x1.00ea348b88334p-2, r2, y);
-    return fma(y, r2, y0 + r);
-}
 static inline double tol_ln(float sf)
 {
-    const uint32_t tmp = tol_f2u(sf) - 0x3f330000u;
-    return tol_ln_core((double)sf, (tmp >> 19) & 15, (int)(tmp >> 23) & 3);
+    const uint32_t idx = ((tol_f2u(sf) - 0x3f000000u) >> 15) & 0x7ffu;   /* (k - 126) * 256 + j */
+    const TolLnEntry e = kTolLnTab[idx < 5 * 256 ? idx : 5 * 256 - 1];
+    const float r = fmaf(sf, e.invc, -1.0f);
+    const float r2 = r * r;
+    const float w = fmaf(r2, fmaf(r, 0x1.555556p-2f, -0.5f), r);
+    return e.lnc + (double)w;
 }
 static inline float tol_fmax(float a, float b) { return a < b ? b : a; }
 static inline float tol_term(float q, uint32_t zb, uint32_t nmax)

@@ -139,11 +139,10 @@ def test_redblack_is_the_reference_iteration(devices, goldens, name):
 
 
 def test_redblack_map_is_the_reference_result(devices, goldens):
-    os.environ["EPIC_HIP_SCHEME"] = "redblack"
-    try:
+    from conftest import scheme_env
+
+    with scheme_env("redblack"):
         P.test_redblack_maps_are_the_reference_result(goldens, "basic", None)
-    finally:
-        del os.environ["EPIC_HIP_SCHEME"]
 
 
 @pytest.mark.parametrize("m,seed,dens,rpt", [g for g in T.GRIDS if g[0] in ([211, 530], [257, 513])])

@@ -509,9 +509,10 @@ def test_removed_and_unknown_math_modes_are_refused():
 # REFERENCE-GENERATED goldens directly, tolerance 0, including iteration counts and the final delta.
 @pytest.fixture
 def redblack_env():
-    os.environ["EPIC_HIP_SCHEME"] = "redblack"
-    yield
-    del os.environ["EPIC_HIP_SCHEME"]
+    from conftest import scheme_env
+
+    with scheme_env("redblack"):
+        yield
 
 
 SMALL_2D = SMALL  # 2-D and 3-D: both have the reference colouring on the device

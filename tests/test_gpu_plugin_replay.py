@@ -63,8 +63,11 @@ def read_paths(buf, n, offset):
 
 
 def run(exe, mode, inp, outp, scheme, ok=(0,)):
-    env = dict(os.environ, EPIC_HIP_SCHEME=scheme)
-    env.pop("EPIC_HIP_MATH", None)
+    env = dict(os.environ)
+    for var in ("EPIC_HIP_SCHEME", "EPIC_HIP_MATH"):   # scheme None: the library default, no variable at all (as under ROS)
+        env.pop(var, None)
+    if scheme is not None:
+        env["EPIC_HIP_SCHEME"] = scheme
     r = subprocess.run([exe, mode, inp, outp], capture_output=True, text=True, env=env, timeout=800)
     assert r.returncode in ok, (r.returncode, r.stderr[-2000:])
     return open(outp, "rb").read(), r.stderr
@@ -79,16 +82,17 @@ def test_navigation_node_sequence_on_maze_gives_the_reference_paths(replay_exe, 
     starts = [paths[f"maze/path{j}_start"] for j in range(6)]
     inp, outp = str(tmp_path / "maze.in"), str(tmp_path / "maze.out")
     write_input(inp, occupied, goals, starts)
-    buf, err = run(replay_exe, "node", inp, outp, "redblack")
-    (iterations,) = struct.unpack_from("<I", buf, 0)
-    assert iterations == goldens["manifest"]["maps"]["maze"]["runs"]["1e-06"]["iterations"], err
-    got, _ = read_paths(buf, 6, 4)
-    for j, (rc, k, pts) in enumerate(got):
-        assert rc == int(paths[f"maze/path{j}_rc"]), j
-        assert k == int(paths[f"maze/path{j}_k"]), j
-        if rc == 0:
-            assert np.array_equal(pts[:16], paths[f"maze/path{j}_head"]) and np.array_equal(pts[-16:], paths[f"maze/path{j}_tail"])
-            assert hashlib.sha256(pts.tobytes()).digest() == paths[f"maze/path{j}_sha256"].tobytes(), j
+    for scheme in (None, "redblack"):   # None: an EMPTY environment -- the library default must be the reference's iteration
+        buf, err = run(replay_exe, "node", inp, outp, scheme)
+        (iterations,) = struct.unpack_from("<I", buf, 0)
+        assert iterations == goldens["manifest"]["maps"]["maze"]["runs"]["1e-06"]["iterations"], (scheme, err)
+        got, _ = read_paths(buf, 6, 4)
+        for j, (rc, k, pts) in enumerate(got):
+            assert rc == int(paths[f"maze/path{j}_rc"]), j
+            assert k == int(paths[f"maze/path{j}_k"]), j
+            if rc == 0:
+                assert np.array_equal(pts[:16], paths[f"maze/path{j}_head"]) and np.array_equal(pts[-16:], paths[f"maze/path{j}_tail"])
+                assert hashlib.sha256(pts.tobytes()).digest() == paths[f"maze/path{j}_sha256"].tobytes(), j
 
 
 def test_nav_core_plugin_sequence_equals_its_cpu_fallback(replay_exe, tmp_path):
@@ -102,7 +106,7 @@ def test_nav_core_plugin_sequence_equals_its_cpu_fallback(replay_exe, tmp_path):
               (float(free[len(free) // 3][1]) + 0.25, float(free[len(free) // 3][0]) - 0.25, 0.05, 0.5)]
     inp, outp = str(tmp_path / "plugin.in"), str(tmp_path / "plugin.out")
     write_input(inp, locked != 0, goals, starts)
-    buf, err = run(replay_exe, "plugin", inp, outp, "redblack")
+    buf, err = run(replay_exe, "plugin", inp, outp, None)   # empty environment: the library default
     off = 0
     for g in range(2):
         iterations, same = struct.unpack_from("<II", buf, off)
@@ -113,7 +117,7 @@ def test_nav_core_plugin_sequence_equals_its_cpu_fallback(replay_exe, tmp_path):
         if path[0] == 0:
             assert path[1] > 10 and np.isfinite(path[2]).all()
             assert abs(path[2][0] - starts[g][0]) < 1e-6 and abs(path[2][1] - starts[g][1]) < 1e-6
-    # The default scheme (Jacobi) through the same binary.  The second makePlan is the case a plain Jacobi iteration never
+    # The Jacobi scheme (EPIC_HIP_SCHEME=jacobi, what bench.py times) through the same binary.  The second makePlan is the case a plain Jacobi iteration never
     # finishes (its two chains stagnate one ulp apart: tests/test_gpu_jacobi_handover.py); harmonic_execute_gpu hands over
     # to the reference's half-sweeps there, so both calls return.  Exit code 9 = "not bit-identical to the CPU fallback"
     # is allowed here: the iteration counts differ by construction.

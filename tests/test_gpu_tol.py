@@ -286,15 +286,14 @@ def test_tol_jacobi_and_redblack_end_in_the_same_field(goldens, tol_env):
     """Jacobi's two interleaved chains and the red-black chain see the same term for the same neighbour value; on the
     reference's maps they stop in one field (within one ulp where the last sweep still moved a cell by less than eps)."""
     fields = []
+    from conftest import scheme_env
+
     for scheme in ("jacobi", "redblack"):
-        os.environ["EPIC_HIP_SCHEME"] = scheme
-        try:
+        with scheme_env(scheme):
             h = HarmonicMap().load(os.path.join(O.ROOT, "tests", "golden", "maps", "basic.png"))
             h.solve(process="gpu", epsilon=1e-6)
             assert h.delta < 1e-6
             fields.append(h.u_array().copy())
-        finally:
-            del os.environ["EPIC_HIP_SCHEME"]
     a, b = fields
     err = np.abs(a.astype(np.float64) - b) / np.maximum(1.0, np.abs(b))
     assert err.max() <= 2e-6, float(err.max())
