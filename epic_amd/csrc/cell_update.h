@@ -351,6 +351,67 @@ __device__ __forceinline__ void tol_max2(v2f mx, v2f &f, uint32_t &n0, uint32_t 
     n0 = f2u(zm.x);
     n1 = f2u(zm.y);
 }
+// A neighbour that lives in the NEXT LANE (the fused passes: lane i - 1 holds the cell to the left of lane i's first cell, lane
+// i + 1 the one to the right of its last) costs three lane shifts -- u, q, n -- as moves.  Two of the three consumers are VOP2
+// instructions, which take the shift as a DPP modifier on their first operand: the maximum and the exponent difference are
+// therefore written out with the shift folded in (the compiler forms v_max3 first and then cannot); only q still moves.
+// s_nop 1: a DPP operand must not have been written by the VALU in the two wait states before (the compiler does not look
+// into the statement).  Lanes without a neighbour read zero bits (bound_ctrl), as with the plain shifts: halo lanes.
+__device__ __forceinline__ float max_from_left(float v, float m)   // lane i: max(v of lane i - 1, m)
+{
+    float r;
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(m));
+    return r;
+}
+__device__ __forceinline__ float max_from_right(float v, float m)  // lane i: max(v of lane i + 1, m)
+{
+    float r;
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(m));
+    return r;
+}
+__device__ __forceinline__ uint32_t sub_from_left(uint32_t n, uint32_t nmax)   // lane i: n of lane i - 1, minus nmax
+{
+    uint32_t r;
+    asm("s_nop 1\n\tv_sub_u32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(n), "v"(nmax));
+    return r;
+}
+__device__ __forceinline__ uint32_t sub_from_right(uint32_t n, uint32_t nmax)
+{
+    uint32_t r;
+    asm("s_nop 1\n\tv_sub_u32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(n), "v"(nmax));
+    return r;
+}
+// The pair (x, z) of a fused pass: x's left neighbour (third in the reference's order) is the LAST cell of the lane to the
+// left -- uw, nw are this lane's own last cell (unshifted), qw_left its q already shifted.  Otherwise tol_pre2_2d.
+__device__ __forceinline__ TolPre2 tol_pre2_2d_left(float ua0, float ub0, float uw, float ud0, float qa0, uint32_t na0, float qb0, uint32_t nb0,
+                                                    float qw_left, uint32_t nw, float qd0, uint32_t nd0, float ua1, float ub1, float uc1,
+                                                    float ud1, float qa1, uint32_t na1, float qb1, uint32_t nb1, float qc1, uint32_t nc1,
+                                                    float qd1, uint32_t nd1)
+{
+    TolPre2 p;
+    p.mx = v2f{max_from_left(uw, max2(max2(ua0, ub0), ud0)), max2(max2(max2(ua1, ub1), uc1), ud1)};
+    uint32_t n0, n1;
+    tol_max2(p.mx, p.f, n0, n1);
+    v2f s = v2f{tol_term(qa0, na0, n0), tol_term(qa1, na1, n1)} + v2f{tol_term(qb0, nb0, n0), tol_term(qb1, nb1, n1)};
+    s = s + v2f{__builtin_ldexpf(qw_left, (int)sub_from_left(nw, n0)), tol_term(qc1, nc1, n1)};
+    p.s = s + v2f{tol_term(qd0, nd0, n0), tol_term(qd1, nd1, n1)};
+    return p;
+}
+// The pair (y, w): w's right neighbour (fourth) is the FIRST cell of the lane to the right -- ux, nx this lane's own first cell.
+__device__ __forceinline__ TolPre2 tol_pre2_2d_right(float ua0, float ub0, float uc0, float ud0, float qa0, uint32_t na0, float qb0, uint32_t nb0,
+                                                     float qc0, uint32_t nc0, float qd0, uint32_t nd0, float ua1, float ub1, float uc1,
+                                                     float ux, float qa1, uint32_t na1, float qb1, uint32_t nb1, float qc1, uint32_t nc1,
+                                                     float qx_right, uint32_t nx)
+{
+    TolPre2 p;
+    p.mx = v2f{max2(max2(max2(ua0, ub0), uc0), ud0), max_from_right(ux, max2(max2(ua1, ub1), uc1))};
+    uint32_t n0, n1;
+    tol_max2(p.mx, p.f, n0, n1);
+    v2f s = v2f{tol_term(qa0, na0, n0), tol_term(qa1, na1, n1)} + v2f{tol_term(qb0, nb0, n0), tol_term(qb1, nb1, n1)};
+    s = s + v2f{tol_term(qc0, nc0, n0), tol_term(qc1, nc1, n1)};
+    p.s = s + v2f{tol_term(qd0, nd0, n0), __builtin_ldexpf(qx_right, (int)sub_from_right(nx, n1))};
+    return p;
+}
 // cell 0: neighbours a0 b0 c0 d0 in the reference's order of summation (their u, q, n); cell 1 likewise
 __device__ __forceinline__ TolPre2 tol_pre2_2d(float ua0, float ub0, float uc0, float ud0, float qa0, uint32_t na0, float qb0, uint32_t nb0,
                                                float qc0, uint32_t nc0, float qd0, uint32_t nd0, float ua1, float ub1, float uc1, float ud1,

@@ -101,10 +101,15 @@ struct Ctx {
     int halo_env = 0;              // EPIC_HIP_HALO (0 = not given: chosen by slab height in multi_plan)
     bool multi() const { return !slabs.empty(); }
     size_t u_bytes() const { return (size_t)rows * pitch * sizeof(float); }
+    // 2-D: the lane masks are kept twice in one block -- the standard layout, and behind it the same bits cut for the fused
+    // passes' lane -> column mapping (kernels.h: fused layout; derived on the device after every upload and edit)
+    static size_t mask_words_both_2d(int rows, int pitch) { return epic_hip::mask_words_2d(rows, pitch) + epic_hip::mask_words_fused_2d(rows, pitch); }
     size_t mask_bytes() const
     {
-        return sizeof(uint32_t) * (n == 2 ? epic_hip::mask_words_2d(rows, pitch) : epic_hip::mask_words_3d(m[0], m[1], pitch));
+        return sizeof(uint32_t) * (n == 2 ? mask_words_both_2d(rows, pitch) : epic_hip::mask_words_3d(m[0], m[1], pitch));
     }
+    uint32_t *maskf() const { return n == 2 && maskw ? maskw + epic_hip::mask_words_2d(rows, pitch) : nullptr; }
+    uint32_t *maskf(const Slab &sl) const { return sl.maskw ? sl.maskw + epic_hip::mask_words_2d(sl.rows, pitch) : nullptr; }
 };
 
 std::mutex g_mu;
@@ -442,7 +447,8 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
             if (count - i >= 2 && next_two_fuse(c)) {
                 hipError_t e = c->multi() ? multi_sweep_pair(c)
                                           : epic_hip::launch_jacobi_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows,
-                                                                             c->pitch, jacobi_fused_rows_per_task(c), c->math, c->stream);
+                                                                             c->pitch, jacobi_fused_rows_per_task(c), c->math, c->stream, -1,
+                                                                             c->maskf());
                 if (e != hipSuccess) return e;
                 if (!c->multi()) { c->cur ^= 1; c->work_full += 2.0; }
                 i += 2;
@@ -456,7 +462,8 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
     }
     while (!no_fuse && fuses_rb_tol(c) && count - i >= 2) {
         hipError_t e = epic_hip::launch_jacobi_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch,
-                                                        jacobi_fused_rows_per_task(c), c->math, c->stream, (int)((first + i) & 1u));
+                                                        jacobi_fused_rows_per_task(c), c->math, c->stream, (int)((first + i) & 1u),
+                                                        c->maskf());
         if (e != hipSuccess) return e;
         c->cur ^= 1;
         c->work_full += 2.0;
@@ -594,6 +601,7 @@ int upload_locked(Harmonic *h, Ctx *c, const char *fn)
         hipError_t e = c->n == 2
                            ? epic_hip::launch_pack_mask_2d(tmp, c->rows, c->cols, c->pitch, 0, 0, c->maskw, c->stream)
                            : epic_hip::launch_pack_mask_3d(tmp, c->m[0], c->m[1], c->m[2], c->pitch, c->maskw, c->stream);
+        if (e == hipSuccess && c->n == 2) e = epic_hip::launch_fuse_masks_2d(c->maskw, c->rows, c->pitch, c->maskf(), c->stream);
         if (e != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
             report(fn, "Failed to execute the 'pack mask' kernel.");
             rc = EPIC_ERROR_KERNEL_EXECUTION;
@@ -791,6 +799,7 @@ int multi_upload_locked(Harmonic *h, Ctx *c, const char *fn)
             rc = EPIC_ERROR_MEMCPY_TO_DEVICE;
         } else if (epic_hip::launch_pack_mask_2d(tmp, sl.rows, c->cols, c->pitch, sl.g_top > 0, sl.g_bot > 0, sl.maskw,
                                                  sl.stream) != hipSuccess ||
+                   epic_hip::launch_fuse_masks_2d(sl.maskw, sl.rows, c->pitch, c->maskf(sl), sl.stream) != hipSuccess ||
                    hipStreamSynchronize(sl.stream) != hipSuccess) {
             report(fn, "Failed to execute the 'pack mask' kernel.");
             rc = EPIC_ERROR_KERNEL_EXECUTION;
@@ -893,7 +902,8 @@ hipError_t multi_sweep_pair(Ctx *c)
     for (auto &sl : c->slabs) {
         hipError_t e = hipSetDevice(sl.dev);
         if (e == hipSuccess)
-            e = epic_hip::launch_jacobi_fused_2d(sl.buf[c->cur], sl.buf[c->cur ^ 1], sl.maskw, sl.rows, c->pitch, rpt, c->math, sl.stream);
+            e = epic_hip::launch_jacobi_fused_2d(sl.buf[c->cur], sl.buf[c->cur ^ 1], sl.maskw, sl.rows, c->pitch, rpt, c->math, sl.stream, -1,
+                                                 c->maskf(sl));
         if (e != hipSuccess) return e;
     }
     c->since += 2;
@@ -960,7 +970,8 @@ int multi_set_cells(Ctx *c, unsigned k, const unsigned *v, const unsigned *types
             report(fn, "Failed to copy memory from host to device for the cell locations and types.");
             rc = EPIC_ERROR_MEMCPY_TO_DEVICE;
         } else if (epic_hip::launch_set_cells_2d(sl.buf[c->cur], sl.maskw, sl.rows, c->cols, c->pitch, k, d_v, d_types, sl.stream,
-                                                 sl.top(), c->rows, sl.g_top > 0, sl.g_bot > 0) != hipSuccess) {
+                                                 sl.top(), c->rows, sl.g_top > 0, sl.g_bot > 0) != hipSuccess ||
+                   epic_hip::launch_fuse_masks_2d(sl.maskw, sl.rows, c->pitch, c->maskf(sl), sl.stream) != hipSuccess) {
             report(fn, "Failed to execute the 'set cells' kernel.");
             rc = EPIC_ERROR_KERNEL_EXECUTION;
         }
@@ -1134,7 +1145,7 @@ int harmonic_initialize_locked_gpu(Harmonic *harmonic)  // harmonic_model_gpu.cu
             DeviceGuard g;
             for (auto &sl : c->slabs)
                 if (hipSetDevice(sl.dev) != hipSuccess ||
-                    hipMalloc((void **)&sl.maskw, sizeof(uint32_t) * epic_hip::mask_words_2d(sl.rows, c->pitch)) != hipSuccess) {
+                    hipMalloc((void **)&sl.maskw, sizeof(uint32_t) * Ctx::mask_words_both_2d(sl.rows, c->pitch)) != hipSuccess) {
                     (void)hipGetLastError();
                     report(fn, "Failed to allocate device-side memory for the locked cells.");
                     multi_free_mask(c);
@@ -1500,7 +1511,8 @@ int harmonic_utilities_set_cells_2d_gpu(Harmonic *harmonic, unsigned int numThre
         report(fn, "Failed to copy memory from host to device for the cell locations and types.");
         rc = EPIC_ERROR_MEMCPY_TO_DEVICE;
     } else if (epic_hip::launch_set_cells_2d(c->buf[c->cur], c->maskw, c->rows, c->cols, c->pitch, k, d_v, d_types,
-                                             c->stream) != hipSuccess) {
+                                             c->stream) != hipSuccess ||
+               epic_hip::launch_fuse_masks_2d(c->maskw, c->rows, c->pitch, c->maskf(), c->stream) != hipSuccess) {
         report(fn, "Failed to execute the 'set cells' kernel.");
         rc = EPIC_ERROR_KERNEL_EXECUTION;
     }
@@ -1823,7 +1835,7 @@ int epic_hip_get_layout(Harmonic *harmonic, unsigned int *pitch, size_t *u_bytes
         size_t ub = 0, mb = 0;
         for (const auto &sl : c->slabs) {
             ub += (size_t)sl.rows * c->pitch * sizeof(float);
-            mb += sizeof(uint32_t) * epic_hip::mask_words_2d(sl.rows, c->pitch);
+            mb += sizeof(uint32_t) * Ctx::mask_words_both_2d(sl.rows, c->pitch);
         }
         if (u_bytes) *u_bytes = ub;
         if (mask_bytes) *mask_bytes = mb;

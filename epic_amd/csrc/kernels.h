@@ -56,8 +56,14 @@ hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw
                               int math, int parity, hipStream_t stream);
 // Two iterations in one pass (tol math only): in = u_k, out = u_{k+2}; in != out.  parity < 0: Jacobi; 0 / 1: the reference's
 // red-black scheme, parity = the first iteration's number & 1 (both colours are swept, the first one first).
+// maskf (may be null): the masks in the fused layout below -- saves the pass a funnel shift of two mask words per row.
 hipError_t launch_jacobi_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
-                                  int math, hipStream_t stream, int parity = -1);
+                                  int math, hipStream_t stream, int parity = -1, const uint32_t *maskf = nullptr);
+// Fused layout: a fused pass cuts a row into strips of 248 columns, lane L of strip S holding columns 248 S - 4 + 4 L .. + 3
+// (lanes 0 and 63 are halo lanes); per row and such strip four 64-bit words as in the standard layout (bit L of word j =
+// cell 4 L + j of that mapping).  Derived from the standard masks after every upload and every edit.
+inline size_t mask_words_fused_2d(int rows, int pitch) { return (size_t)rows * (size_t)((pitch + 247) / 248) * 8u; }
+hipError_t launch_fuse_masks_2d(const uint32_t *maskw, int rows, int pitch, uint32_t *maskf, hipStream_t stream);
 hipError_t launch_eval_math(const float *in, float *out, size_t n, int which, hipStream_t stream);
 hipError_t launch_pack_mask_2d(const uint32_t *locked, int rows, int cols, int pitch, int ghost_top,
                                int ghost_bottom, uint32_t *maskw, hipStream_t stream);

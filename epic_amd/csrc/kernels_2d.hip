@@ -61,6 +61,7 @@ struct Sweep2dArgs {
     const float *in;
     float *out;
     const uint32_t *maskw;  // lane masks (kernels.h): per row and strip four 64-bit words, bit L of word j = cell 4 L + j; 1 = locked
+    const uint32_t *maskf;  // fused passes only, may be null: the same masks cut for THEIR lane -> column mapping (kernels.h: fused layout)
     unsigned *delta_bits;   // max |du| as float bits (atomicMax), used when CHECK
     int rows;               // rows of the (local) grid, including ghost rows in slab mode
     int pitch;              // floats per row, multiple of 256
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
 // with (row + col + it + 1) odd from the level-A rows; a cell that a level does not touch passes through it.  Every
 // cell is recomputed once per pass (4 B of HBM traffic per cell-update against 16 for the in-place half-sweep), the rows
 // are split twice (before level A, and after it for level B).  Bit-identical to two in-place half-sweeps.
-template <bool RB>
+template <bool RB, bool FMASK>
 __device__ __forceinline__ void tol_fused_pass(const Sweep2dArgs &a, TolLnEntry *math_lds)
 {
     TolLn<4>::stage(math_lds);  // the whole workgroup, one barrier: before any wave may find itself without a task
@@ -623,15 +624,22 @@ __device__ __forceinline__ void tol_fused_pass(const Sweep2dArgs &a, TolLnEntry 
     const int nstd = a.pitch >> 8;
     const int g0 = strip * (kFusedOut / kColsPerLane) - 1;
     const int sw = max(g0, 0) >> 6, sh = max(g0, 0) & 63, sw1 = min(sw + 1, nstd - 1);
+    // (FMASK: the library keeps a second copy of the masks already cut for this mapping -- kernels.h, fused layout --, one
+    // s_load_dwordx8 per row and no shifts; the funnel remains for callers that hold the standard layout only)
     auto mask_fetch = [&](int r) -> RowMaskRaw {
 #ifdef EPIC_EXP_NOMASK  // timing experiment only (wrong results): no mask loads at all
         return RowMaskRaw{0, 0, 0, 0, 0, 0, 0, 0};
 #endif
         r = min(max(r, 0), rlast);
+        if (FMASK) {
+            cu64 *mk = (cu64 *)a.maskf + ((size_t)r * a.nstrips + strip) * 4;
+            return RowMaskRaw{mk[0], mk[1], mk[2], mk[3], 0, 0, 0, 0};
+        }
         cu64 *lo = (cu64 *)a.maskw + ((size_t)r * nstd + sw) * 4, *hi = (cu64 *)a.maskw + ((size_t)r * nstd + sw1) * 4;
         return RowMaskRaw{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
     auto mask_cut = [&](const RowMaskRaw &w) -> RowMask {
+        if (FMASK) return RowMask{w.lo0, w.lo1, w.lo2, w.lo3};
         // (lo >> sh) | (hi << (64 - sh)) without a branch for sh = 0: (hi << 1) << (63 - sh) is 0 there
         auto cut = [&](lmask lo, lmask hi) -> lmask {
             const lmask m = (lo >> sh) | ((hi << 1) << (63 - sh));
@@ -652,17 +660,14 @@ __device__ __forceinline__ void tol_fused_pass(const Sweep2dArgs &a, TolLnEntry 
         // the cells this level updates, two at a time in the three phases of cell_update.h: the table reads of one pair are in
         // flight while the other pair is worked on
         const bool even = !RB || !odd_cols;
+        // (the neighbours in the next lanes: only q is shifted as a move, u and n ride on the instructions that use them)
         auto pre_xz = [&] {
-            const float lf = shl(c.w), ql = shl(sc.qw);
-            const uint32_t nl = f2u(shl(u2f(sc.nw)));
-            return tol_pre2_2d(up.x, dn.x, lf, c.y, su.qx, su.nx, sd.qx, sd.nx, ql, nl, sc.qy, sc.ny,
-                               up.z, dn.z, c.y, c.w, su.qz, su.nz, sd.qz, sd.nz, sc.qy, sc.ny, sc.qw, sc.nw);
+            return tol_pre2_2d_left(up.x, dn.x, c.w, c.y, su.qx, su.nx, sd.qx, sd.nx, shl(sc.qw), sc.nw, sc.qy, sc.ny,
+                                    up.z, dn.z, c.y, c.w, su.qz, su.nz, sd.qz, sd.nz, sc.qy, sc.ny, sc.qw, sc.nw);
         };
         auto pre_yw = [&] {
-            const float rt = shr(c.x), qr = shr(sc.qx);
-            const uint32_t nr = f2u(shr(u2f(sc.nx)));
-            return tol_pre2_2d(up.y, dn.y, c.x, c.z, su.qy, su.ny, sd.qy, sd.ny, sc.qx, sc.nx, sc.qz, sc.nz,
-                               up.w, dn.w, c.z, rt, su.qw, su.nw, sd.qw, sd.nw, sc.qz, sc.nz, qr, nr);
+            return tol_pre2_2d_right(up.y, dn.y, c.x, c.z, su.qy, su.ny, sd.qy, sd.ny, sc.qx, sc.nx, sc.qz, sc.nz,
+                                     up.w, dn.w, c.z, c.x, su.qw, su.nw, sd.qw, sd.nw, sc.qz, sc.nz, shr(sc.qx), sc.nx);
         };
         float nx, ny, nz, nw;
         TolLnRaw ea, eb;
@@ -741,19 +746,38 @@ __device__ __forceinline__ void tol_fused_pass(const Sweep2dArgs &a, TolLnEntry 
     }  // logical blocks
 }
 
-template <int MATH>
+template <int MATH, bool FMASK>
 __global__ __launch_bounds__(kWave * kWavesPerBlock, EPIC_FUSED_MIN_WAVES) void jacobi_fused2d_kernel(Sweep2dArgs a)
 {
     static_assert(MATH == kMathTol, "the fused Jacobi pass exists for the tol math");
     __shared__ TolLnEntry math_lds[TolLn<4>::kEntries];
-    tol_fused_pass<false>(a, math_lds);
+    tol_fused_pass<false, FMASK>(a, math_lds);
 }
 
 // two red-black iterations of the tol math in one pass (the precise / fast math: rb_fused2d_kernel above)
+template <bool FMASK>
 __global__ __launch_bounds__(kWave * kWavesPerBlock, EPIC_FUSED_MIN_WAVES) void rb_tol_fused2d_kernel(Sweep2dArgs a)
 {
     __shared__ TolLnEntry math_lds[TolLn<4>::kEntries];
-    tol_fused_pass<true>(a, math_lds);
+    tol_fused_pass<true, FMASK>(a, math_lds);
+}
+
+// The masks of a grid cut for the fused passes' lane -> column mapping (kernels.h: fused layout), from the standard lane
+// masks: one thread per (row, fused strip, word), the funnel shift the passes would otherwise do per row and wave.
+__global__ void fuse_masks_2d_kernel(const uint32_t *maskw, int rows, int pitch, uint32_t *maskf)
+{
+    const int nstd = pitch >> 8, nfused = (pitch + kFusedOut - 1) / kFusedOut;
+    const size_t n = (size_t)rows * nfused * 4, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int j = (int)(i & 3), strip = (int)((i >> 2) % nfused);
+    const size_t r = (i >> 2) / nfused;
+    const int g0 = strip * (kFusedOut / kColsPerLane) - 1;
+    const int sw = max(g0, 0) >> 6, sh = max(g0, 0) & 63, sw1 = min(sw + 1, nstd - 1);
+    const unsigned long long *std64 = reinterpret_cast<const unsigned long long *>(maskw);
+    const unsigned long long lo = std64[(r * nstd + sw) * 4 + j], hi = std64[(r * nstd + sw1) * 4 + j];
+    unsigned long long m = (lo >> sh) | ((hi << 1) << (63 - sh));
+    if (g0 < 0) m <<= 1;
+    reinterpret_cast<unsigned long long *>(maskf)[i] = m;
 }
 
 // uint32-per-cell mask (the ABI's format, rows x cols, unpitched) -> lane masks (kernels.h).  One wave per (row,
@@ -918,6 +942,7 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, i
     a.in = in;
     a.out = out;
     a.maskw = maskw;
+    a.maskf = nullptr;
     a.delta_bits = delta_bits;
     a.rows = rows;
     a.pitch = pitch;
@@ -958,6 +983,7 @@ hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw
     a.in = in;
     a.out = out;
     a.maskw = maskw;
+    a.maskf = nullptr;
     a.delta_bits = nullptr;
     a.rows = rows;
     a.pitch = pitch;
@@ -978,8 +1004,16 @@ hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw
     return hipGetLastError();
 }
 
+hipError_t launch_fuse_masks_2d(const uint32_t *maskw, int rows, int pitch, uint32_t *maskf, hipStream_t stream)
+{
+    if (!maskw || !maskf || rows <= 0 || pitch <= 0 || (pitch % 256) != 0) return hipErrorInvalidValue;
+    const size_t n = mask_words_fused_2d(rows, pitch) / 2;
+    hipLaunchKernelGGL(fuse_masks_2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, maskw, rows, pitch, maskf);
+    return hipGetLastError();
+}
+
 hipError_t launch_jacobi_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
-                                  int math, hipStream_t stream, int parity)
+                                  int math, hipStream_t stream, int parity, const uint32_t *maskf)
 {
     if (pitch <= 0 || (pitch % 256) != 0 || rows <= 0 || rows_per_task <= 0 || in == out) return hipErrorInvalidValue;
     if (math != kMathTol) return hipErrorInvalidValue;
@@ -991,6 +1025,7 @@ hipError_t launch_jacobi_fused_2d(const float *in, float *out, const uint32_t *m
     a.in = in;
     a.out = out;
     a.maskw = maskw;
+    a.maskf = nullptr;
     a.delta_bits = nullptr;
     a.rows = rows;
     a.pitch = pitch;
@@ -1004,7 +1039,9 @@ hipError_t launch_jacobi_fused_2d(const float *in, float *out, const uint32_t *m
     a.nchunks = 0;
     a.wake = wake_args(nullptr, 0);
     a.nblocks = (a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock;
-    void (*kernel)(Sweep2dArgs) = parity < 0 ? jacobi_fused2d_kernel<kMathTol> : rb_tol_fused2d_kernel;
+    a.maskf = maskf;
+    void (*kernel)(Sweep2dArgs) = parity < 0 ? (maskf ? jacobi_fused2d_kernel<kMathTol, true> : jacobi_fused2d_kernel<kMathTol, false>)
+                                             : (maskf ? rb_tol_fused2d_kernel<true> : rb_tol_fused2d_kernel<false>);
     const dim3 grid(resident_grid(a.nblocks, (const void *)kernel)), block(kWave * kWavesPerBlock);
     hipLaunchKernelGGL(kernel, grid, block, 0, stream, a);
     return hipGetLastError();
