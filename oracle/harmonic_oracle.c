@@ -195,21 +195,27 @@ int oracle_complete(OracleHarmonic *h)
  * scheme does not move the f32 stagnation point).  Not in the reference: it exists so
  * that fixed-sweep-count GPU results can be compared cell by cell. ------------------ */
 
+/* (rows are dealt to OpenMP threads on large grids -- a Jacobi sweep reads `in` only, so the result is the sequential one
+ * bit for bit; the full-size whole-field tests sweep 8192^2 and 512^3 with it) */
+#define ORACLE_OMP_MIN_CELLS ((size_t)1 << 17)
 static void jacobi_sweep_2d(const OracleHarmonic *h, const float *in, float *out, float *delta)
 {
     const unsigned int m0 = h->m[0], m1 = h->m[1];
     float d = 0.0f;
+    uint64_t n = 0;
     memcpy(out, in, (size_t)m0 * m1 * sizeof(float));
-    for (unsigned int x0 = 1; x0 + 1 < m0; x0++) {
+#pragma omp parallel for schedule(static) reduction(max : d) reduction(+ : n) if ((size_t)m0 * m1 >= ORACLE_OMP_MIN_CELLS)
+    for (unsigned int x0 = 1; x0 < m0 - 1; x0++) {
         for (unsigned int x1 = 1; x1 + 1 < m1; x1++) {
             size_t c = (size_t)x0 * m1 + x1;
             if (h->locked[c]) continue;
             float v = cell_update_2d(in[c - m1], in[c + m1], in[c - 1], in[c + 1]);
             out[c] = v;
             d = fmax2(d, (float)fabs(in[c] - v));
-            g_updates++;
+            n++;
         }
     }
+    g_updates += n;
     if (delta) *delta = d;
 }
 
@@ -218,8 +224,10 @@ static void jacobi_sweep_3d(const OracleHarmonic *h, const float *in, float *out
     const unsigned int m0 = h->m[0], m1 = h->m[1], m2 = h->m[2];
     const size_t s0 = (size_t)m1 * m2, s1 = m2;
     float d = 0.0f;
+    uint64_t n = 0;
     memcpy(out, in, (size_t)m0 * s0 * sizeof(float));
-    for (unsigned int x0 = 1; x0 + 1 < m0; x0++)
+#pragma omp parallel for schedule(static) reduction(max : d) reduction(+ : n) if ((size_t)m0 * s0 >= ORACLE_OMP_MIN_CELLS)
+    for (unsigned int x0 = 1; x0 < m0 - 1; x0++)
         for (unsigned int x1 = 1; x1 + 1 < m1; x1++)
             for (unsigned int x2 = 1; x2 + 1 < m2; x2++) {
                 size_t c = x0 * s0 + x1 * s1 + x2;
@@ -227,8 +235,9 @@ static void jacobi_sweep_3d(const OracleHarmonic *h, const float *in, float *out
                 float v = cell_update_3d(in[c - s0], in[c + s0], in[c - s1], in[c + s1], in[c - 1], in[c + 1]);
                 out[c] = v;
                 d = fmax2(d, (float)fabs(in[c] - v));
-                g_updates++;
+                n++;
             }
+    g_updates += n;
     if (delta) *delta = d;
 }
 
@@ -352,6 +361,7 @@ void oracle_synthetic(unsigned int n, const unsigned int *m, uint64_t seed, doub
     for (unsigned int i = 0; i < n; i++) cells *= m[i];
     for (unsigned int i = 0; i < n; i++) goal = goal * m[i] + m[i] / 2;
     const uint64_t thresh = (uint64_t)(density * 9007199254740992.0); /* density * 2^53 */
+#pragma omp parallel for schedule(static) if (cells >= ((size_t)1 << 20))
     for (size_t idx = 0; idx < cells; idx++) {
         size_t r = idx;
         int border = 0;
@@ -367,6 +377,22 @@ void oracle_synthetic(unsigned int n, const unsigned int *m, uint64_t seed, doub
     }
     u[goal] = 0.0f;
     locked[goal] = 1;
+}
+
+/* A seeded NON-UNIFORM start for the full-size whole-field tests: every unlocked cell gets lo + (hi - lo) * hash01(seed, idx)
+ * (the same counter-based hash), locked cells keep what they hold.  From the uniform start (-1e6 everywhere but the goal) a
+ * store that lands in the wrong row or strip far from the goal writes the seed over the seed and cannot be seen. */
+void oracle_scramble_free(unsigned int n, const unsigned int *m, uint64_t seed, float lo, float hi, float *u,
+                          const unsigned int *locked)
+{
+    size_t cells = 1;
+    for (unsigned int i = 0; i < n; i++) cells *= m[i];
+#pragma omp parallel for schedule(static)
+    for (size_t idx = 0; idx < cells; idx++) {
+        if (locked[idx]) continue;
+        const uint64_t hsh = mix64(seed ^ ((uint64_t)idx * 0x9E3779B97F4A7C15ULL));
+        u[idx] = lo + (hi - lo) * (float)((double)(hsh >> 11) * 0x1p-53);
+    }
 }
 
 /* ---- row-range Jacobi on a pitched local array (checker side of the slab-decomposition tests) ----------------

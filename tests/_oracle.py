@@ -92,6 +92,9 @@ def oracle():
         lib.oracle_synthetic.argtypes = (ct.c_uint, ct.POINTER(ct.c_uint), ct.c_uint64, ct.c_double,
                                          ct.POINTER(ct.c_float), ct.POINTER(ct.c_uint))
         lib.oracle_synthetic.restype = None
+        lib.oracle_scramble_free.argtypes = (ct.c_uint, ct.POINTER(ct.c_uint), ct.c_uint64, ct.c_float, ct.c_float,
+                                             ct.POINTER(ct.c_float), ct.POINTER(ct.c_uint))
+        lib.oracle_scramble_free.restype = None
         lib.oracle_cell_updates.restype = ct.c_uint64
         lib.oracle_reset_counters.restype = None
         lib.oracle_tol_run.argtypes = (P, ct.c_uint, ct.c_int)      # oracle/tol_checker.c
@@ -134,6 +137,15 @@ def oracle_synthetic(m, seed=20240601, density=0.05):
                               u.ctypes.data_as(ct.POINTER(ct.c_float)),
                               locked.ctypes.data_as(ct.POINTER(ct.c_uint)))
     return u, locked
+
+
+def scramble_free(m, u, locked, seed=77, lo=-50.0, hi=0.0):
+    """In place: every unlocked cell of u (float32, flat) gets a seeded value in [lo, hi) -- see oracle_scramble_free."""
+    m = np.asarray(m, dtype=np.uint32)
+    assert u.dtype == np.float32 and locked.dtype == np.uint32 and u.flags.c_contiguous and locked.flags.c_contiguous
+    oracle().oracle_scramble_free(len(m), m.ctypes.data_as(ct.POINTER(ct.c_uint)), seed, lo, hi,
+                                  u.ctypes.data_as(ct.POINTER(ct.c_float)), locked.ctypes.data_as(ct.POINTER(ct.c_uint)))
+    return u
 
 
 def load_png_reference_rule(path):

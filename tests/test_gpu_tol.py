@@ -11,7 +11,9 @@ Two kinds of statement, kept apart:
   on the twelve seeded grids, basic.png and maps/maze.png.  maps/umass.png is the ill-conditioned one (SURVEY.md App. A:
   two equally faithful f32 implementations of the reference's own sequence end 2e-4 apart there, and the reference is
   2.9e-2 from the exact solution): the tol mode ends 2.4e-4 from the reference's field, 1.6e-5 relative where |u| ~ 12 --
-  above the bar, asserted at 3e-5 and reported.  The bit-exact `precise` mode is the one that meets 1e-5 there.
+  ABOVE the bar: a reported miss (a strict expected failure against 1e-5, plus a guard that the miss has not grown), not a
+  widened tolerance.  The bit-exact `precise` mode -- the library default -- is the one that meets 1e-5 there.
+  At the benchmark's own sizes: tests/test_gpu_bench_parity.py.
 """
 import ctypes as ct
 import os
@@ -30,7 +32,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
 E = eh._epic
 NT = 1024
 CONVERGED_TOL = 1e-5
-UMASS_TOL = 3e-5
+UMASS_REGRESSION_GUARD = 2e-5   # the tol mode's known miss on umass.png is 1.6e-5: see test_tol_umass_is_within_the_stated_bar
 
 
 def make(m, u, locked, eps=1e-6, stagger=100):
@@ -262,24 +264,51 @@ def test_tol_complete_gpu_vs_reference_golden(goldens, name, tol_env):
     assert_close(h.u_array(), g[name + "/converged"], g[name + "/locked"], CONVERGED_TOL, name)
 
 
-@pytest.mark.parametrize("name,tol", [("basic", CONVERGED_TOL), ("maze", CONVERGED_TOL), ("umass", UMASS_TOL)])
-def test_tol_maps_converge_under_jacobi_by_the_reference_test(goldens, name, tol, tol_env, record_property):
-    """BASELINE configs 1-2 with the tol arithmetic, Jacobi: the reference's absolute test max |du| < 1e-6 fires (the
-    packed double-float mode of round 1 never terminated on umass under Jacobi), after about as many iterations as the
-    reference needed, and the field is within the stated bar of the reference's (umass: see the module docstring)."""
+def _tol_map_run(goldens, name, record_property):
     want = goldens["maps"][name + "/converged_1e-06"]
     run = goldens["manifest"]["maps"][name]["runs"]["1e-06"]
     h = HarmonicMap().load(os.path.join(O.ROOT, "tests", "golden", "maps", name + ".png"))
     h.solve(process="gpu", epsilon=1e-6)
     assert h.delta < 1e-6
     assert abs(h.currentIteration - run["iterations"]) <= 0.02 * run["iterations"]
-    worst = assert_close(h.u_array(), want, h.locked_array(), tol, name)
     free = h.locked_array().ravel() == 0
-    absmax = float(np.abs(h.u_array().ravel()[free] - want[free]).max())
+    got = h.u_array().ravel()
+    assert np.array_equal(got[~free], want[~free])
+    d = np.abs(got[free].astype(np.float64) - want[free])
+    worst, absmax = float((d / np.maximum(1.0, np.abs(want[free]))).max()), float(d.max())
     record_property("max_rel_err", worst)
     record_property("max_abs_err", absmax)
     print(f"tol {name}: {h.currentIteration} sweeps (reference {run['iterations']} half-sweeps), delta {h.delta:.3e}, "
           f"max rel {worst:.3e}, max abs {absmax:.3e}")
+    return worst
+
+
+@pytest.mark.parametrize("name", ["basic", "maze"])
+def test_tol_maps_converge_under_jacobi_by_the_reference_test(goldens, name, tol_env, record_property):
+    """BASELINE configs 1-2 with the tol arithmetic, Jacobi: the reference's absolute test max |du| < 1e-6 fires (the
+    packed double-float mode of round 1 never terminated on umass under Jacobi), after about as many iterations as the
+    reference needed, and the field is within the stated bar of the reference's."""
+    assert _tol_map_run(goldens, name, record_property) <= CONVERGED_TOL
+
+
+@pytest.mark.xfail(strict=True, reason="KNOWN MISS of the tol mode: umass.png converges 1.6e-5 max(1, |u|) from the reference's field, "
+                                       "above the stated 1e-5 (DESIGN.md section 2; the bit-exact default mode meets it)")
+def test_tol_umass_is_within_the_stated_bar(goldens, tol_env, record_property):
+    """BASELINE config 2 (maps/umass.yaml) with the tol arithmetic: stops by the reference's test after about the
+    reference's number of iterations, but ends 1.6e-5 (relative; 2.4e-4 absolute at |u| ~ 12) from the reference's
+    field.  Kept as an EXPECTED FAILURE against the stated bar -- a miss that is reported, not a tolerance that was widened;
+    strict, so that an arithmetic that closes the gap shows up as XPASS.  What the study found: on this map the stagnation
+    point of the f32 iteration moves by ~2e-4 under any change of the noise below the roundings; an arithmetic whose exp
+    and log are CORRECTLY ROUNDED (99.95 % of terms equal to glibc's) lands 1.0e-6 away, so the bar is a statement about the
+    reference's bits (tools/cr_study.c)."""
+    worst = _tol_map_run(goldens, "umass", record_property)
+    assert worst <= UMASS_REGRESSION_GUARD, "further from the reference than the known miss"   # (XFAIL either way; read the log)
+    assert worst <= CONVERGED_TOL
+
+
+def test_tol_umass_known_miss_has_not_grown(goldens, tol_env, record_property):
+    """The same run held to the size of the known miss, so that a regression of the arithmetic cannot hide behind the xfail."""
+    assert _tol_map_run(goldens, "umass", record_property) <= UMASS_REGRESSION_GUARD
 
 
 def test_tol_jacobi_and_redblack_end_in_the_same_field(goldens, tol_env):

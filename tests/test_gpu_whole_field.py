@@ -1,0 +1,217 @@
+"""Whole-field comparisons with the checker at FULL size (BASELINE configs[2], [3], [4]), from a NON-UNIFORM start.
+
+The window properties of tests/test_gpu_full_configs.py start from the solver's own initial state -- u = -1e6 everywhere but
+the goal -- and so cannot see a store that lands in the wrong row or strip far from the goal: it writes the seed over the
+seed.  Here every unlocked cell starts from a seeded value in [-50, 0) (oracle_scramble_free: the counter-based hash of
+the grid generator), K = 4..6 iterations run on the device through the C-ABI, and
+
+  * at 8192 x 8192 and 512^3 the ENTIRE field (and the check iteration's max |du|) is compared, bit for bit, with the checker
+    sweeping the same field on the host cores (OpenMP) -- single sweeps and fused pairs, work lists on and off, one device
+    and eight slabs, both arithmetics, both schemes;
+  * at 32768 x 32768 (the checker cannot sweep 2^30 cells in test time) 72 windows spread over the grid -- strip seams of both
+    tilings (256 and 248 columns), task seams, the seams of 4 and 8 slabs, corners, the goal -- are compared with the checker
+    run on each window plus a margin of K cells (a cell K or more away from a window's frozen rim sees, after K iterations,
+    exactly what it sees in the whole grid).
+
+Reference behaviour matched: the per-cell update and the colour rules of harmonic_cpu.cpp:38-133 (through the checker, which
+is pinned to the reference in tests/test_oracle.py); tol arithmetic: oracle/tol_checker.c.
+"""
+import ctypes as ct
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from epic_amd import epic_harmonic as eh
+from epic_amd.harmonic import Harmonic
+from epic_amd.synthetic import synthetic_grid
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1500)]
+
+E = eh._epic
+NT = 1024
+
+
+def make(m, u, locked):
+    h = Harmonic()
+    h.set_grid(m, u, locked)
+    h.epsilon = 1e-6
+    h.numIterationsToStaggerCheck = 100
+    return h
+
+
+def run_gpu(m, u0, locked, k, math, scheme, track, devices=None):
+    """k iterations, the first one a check iteration; returns (field, delta of the check iteration).  The field is the
+    Harmonic's own host array (no copy: 4.3 GB at 32768^2), kept alive by the returned array's `owner` attribute."""
+    if devices:
+        os.environ["EPIC_HIP_DEVICES"] = devices
+    try:
+        h = make(m, u0, locked)
+        for fn in (E.harmonic_initialize_dimension_size_gpu, E.harmonic_initialize_potential_values_gpu,
+                   E.harmonic_initialize_locked_gpu):
+            assert fn(h) == 0, fn.__name__
+    finally:
+        os.environ.pop("EPIC_HIP_DEVICES", None)
+    assert E.harmonic_initialize_gpu(h, NT) == 0
+    assert E.epic_hip_set_math_mode(h, math) == 0 and E.epic_hip_set_scheme(h, scheme) == 0
+    if not devices:
+        assert E.epic_hip_set_activity_tracking(h, track) == 0
+    assert E.harmonic_update_and_check_gpu(h, NT) in (0, 1)
+    delta = float(h.delta)
+    assert E.epic_hip_update_n_gpu(h, k - 1, 0) == 0
+    assert h.currentIteration == k
+    assert E.harmonic_get_potential_values_gpu(h) == 0
+    for fn in (E.harmonic_uninitialize_gpu, E.harmonic_uninitialize_dimension_size_gpu,
+               E.harmonic_uninitialize_potential_values_gpu, E.harmonic_uninitialize_locked_gpu):
+        assert fn(h) == 0, fn.__name__
+    class Field(np.ndarray):
+        pass
+
+    out = h.u_array().ravel().view(Field)
+    out.owner = h
+    return out, delta
+
+
+def run_checker(m, u0, locked, k, math, scheme):
+    """The same k iterations on the host; returns (field, delta of the FIRST iteration)."""
+    lib = O.oracle()
+    p = O.Problem(m, u0, locked)
+    if math == eh.MATH_TOL:
+        assert lib.oracle_tol_run(ct.byref(p.h), 1, scheme) == 0
+        first = float(p.h.delta)
+        assert lib.oracle_tol_run(ct.byref(p.h), k - 1, scheme) == 0
+        return p.u, first
+    if scheme == eh.SCHEME_JACOBI:
+        assert lib.oracle_jacobi_run(ct.byref(p.h), 1) == 0
+        first = float(p.h.delta)
+        assert lib.oracle_jacobi_run(ct.byref(p.h), k - 1) == 0
+        return p.u, first
+    threads = int(os.environ.get("OMP_NUM_THREADS", "8"))
+    first = None
+    for i in range(k):
+        if i == 0 or len(m) == 3:     # the first one with the check; 3-D has no parallel half-sweep
+            (lib.oracle_update_and_check if i == 0 else lib.oracle_update)(ct.byref(p.h))
+            if i == 0:
+                first = float(p.h.delta)
+        else:
+            assert lib.oracle_update_parallel_2d(ct.byref(p.h), threads) == 0
+    return p.u, first
+
+
+@pytest.fixture(scope="module")
+def grid_8192():
+    m = [8192, 8192]
+    u0, locked = synthetic_grid(m)                 # BASELINE configs[2]: what bench.py times
+    O.scramble_free(m, u0, locked, seed=20240601)
+    return m, u0, locked
+
+
+CASES_2D = [
+    # math, scheme, tracking, devices, what runs
+    (eh.MATH_TOL, eh.SCHEME_JACOBI, 0, None),          # check sweep + fused pairs (jacobi_fused2d_kernel): the benchmarked path
+    (eh.MATH_TOL, eh.SCHEME_JACOBI, 1, None),          # work lists
+    (eh.MATH_TOL, eh.SCHEME_REDBLACK, 0, None),        # fused red-black pairs (rb_tol_fused2d_kernel)
+    (eh.MATH_TOL, eh.SCHEME_REDBLACK, 1, None),
+    (eh.MATH_PRECISE, eh.SCHEME_JACOBI, 0, None),
+    (eh.MATH_PRECISE, eh.SCHEME_REDBLACK, 0, None),    # rb_fused2d_kernel pairs: the library default's untracked batches
+    (eh.MATH_PRECISE, eh.SCHEME_REDBLACK, 1, None),    # the library default above 4 Mcell
+    (eh.MATH_TOL, eh.SCHEME_JACOBI, 0, "0,0,0,0,0,0,0,0"),      # eight slabs, ghost rows, fused pairs per slab
+    (eh.MATH_PRECISE, eh.SCHEME_REDBLACK, 0, "0,0,0"),          # three slabs (ragged cut), the default arithmetic
+]
+
+
+@pytest.mark.parametrize("math,scheme,track,devices", CASES_2D)
+def test_8192_squared_whole_field_equals_the_checker(grid_8192, math, scheme, track, devices):
+    m, u0, locked = grid_8192
+    K = 5   # check + 4 plain iterations: two fused pairs where the configuration fuses
+    got, gdelta = run_gpu(m, u0, locked, K, math, scheme, track, devices)
+    want, wdelta = run_checker(m, u0, locked, K, math, scheme)
+    assert gdelta == wdelta, (gdelta, wdelta)
+    if not np.array_equal(got, want):
+        bad = np.flatnonzero(got != want)
+        r, c = np.unravel_index(bad[:8], m)
+        raise AssertionError("%d cells differ, first at rows %s cols %s" % (bad.size, r.tolist(), c.tolist()))
+
+
+@pytest.fixture(scope="module")
+def grid_512_cubed():
+    m = [512, 512, 512]
+    u0, locked = synthetic_grid(m)                 # BASELINE configs[4]
+    O.scramble_free(m, u0, locked, seed=512)
+    return m, u0, locked
+
+
+@pytest.mark.parametrize("math,scheme,track", [(eh.MATH_TOL, eh.SCHEME_JACOBI, 0), (eh.MATH_TOL, eh.SCHEME_JACOBI, 1),
+                                               (eh.MATH_TOL, eh.SCHEME_REDBLACK, 0), (eh.MATH_PRECISE, eh.SCHEME_JACOBI, 0),
+                                               (eh.MATH_PRECISE, eh.SCHEME_REDBLACK, 0)])
+def test_512_cubed_whole_field_equals_the_checker(grid_512_cubed, math, scheme, track):
+    m, u0, locked = grid_512_cubed
+    K = 4
+    got, gdelta = run_gpu(m, u0, locked, K, math, scheme, track)
+    want, wdelta = run_checker(m, u0, locked, K, math, scheme)
+    assert gdelta == wdelta, (gdelta, wdelta)
+    if not np.array_equal(got, want):
+        bad = np.flatnonzero(got != want)
+        raise AssertionError("%d cells differ, first at %s" % (bad.size, [np.unravel_index(b, m) for b in bad[:4]]))
+
+
+def windows_32768(n, W):
+    """Top-left corners of W x W windows: seams of the 256- and 248-column strips, of 10- and 23-row tasks, of 4 and 8 slabs,
+    the corners, the centre goal, and a seeded scatter."""
+    pts = set()
+    rows = [0, n - W, n // 2 - W // 2, n // 8 - W // 2, n // 4 - W // 2, 3 * n // 8 - W // 2, 5 * n // 8 - W // 2,
+            7 * n // 8 - W // 2, 23 * 700 - W // 2, 10 * 1501 - W // 2]
+    cols = [0, n - W, n // 2 - W // 2, 256 * 17 - W // 2, 248 * 33 - W // 2, 248 * 131 - W // 2, 256 * 127 - W // 2]
+    for r in rows:
+        for c in cols:
+            pts.add((min(max(r, 0), n - W), min(max(c, 0), n - W)))
+    rng = np.random.default_rng(5)
+    while len(pts) < 72:
+        pts.add((int(rng.integers(0, n - W)), int(rng.integers(0, n - W))))
+    return sorted(pts)
+
+
+@pytest.mark.parametrize("math,scheme,track,devices", [
+    (eh.MATH_TOL, eh.SCHEME_JACOBI, 0, None),                 # fused pairs, 133 strips of 248 columns
+    (eh.MATH_PRECISE, eh.SCHEME_REDBLACK, 2, None),           # the library default (work lists)
+    (eh.MATH_TOL, eh.SCHEME_JACOBI, 0, "0,0,0,0,0,0,0,0"),    # BASELINE configs[3]: eight slabs
+])
+def test_32768_squared_windows_all_over_the_grid(math, scheme, track, devices):
+    n, K, W = 32768, 6, 96
+    m = [n, n]
+    u0, locked = O.oracle_synthetic(m)
+    O.scramble_free(m, u0, locked, seed=32768)
+    wins = windows_32768(n, W)
+    u2, l2 = u0.reshape(m), locked.reshape(m)
+    cases = []
+    for r, c in wins:    # the initial state of every window, before the solver overwrites its input array
+        cases.append((u2[r:r + W, c:c + W].copy(), l2[r:r + W, c:c + W].copy()))
+    got, _ = run_gpu(m, u0, locked, K, math, scheme, track, devices)
+    del u0
+    got = got.reshape(m)
+    for (r, c), (uw, lw) in zip(wins, cases):
+        # the window as a grid of its own: its rim frozen (locked at the initial values) unless it IS the grid's border,
+        # which is locked anyway; cells K or more from a frozen rim are exact after K iterations
+        lw = lw.copy()
+        lw[0, :] = lw[-1, :] = lw[:, 0] = lw[:, -1] = 1
+        # the red-black colour of a cell depends on (row + column): keep the window's parity equal to the grid's
+        first_it = (r + c) & 1
+        p = O.Problem([W, W], uw, lw)
+        p.h.currentIteration = first_it if scheme == eh.SCHEME_REDBLACK else 0
+        lib = O.oracle()
+        if math == eh.MATH_TOL:
+            assert lib.oracle_tol_run(ct.byref(p.h), K, scheme) == 0
+        elif scheme == eh.SCHEME_JACOBI:
+            assert lib.oracle_jacobi_run(ct.byref(p.h), K) == 0
+        else:
+            for _ in range(K):
+                lib.oracle_update(ct.byref(p.h))
+        want = p.u.reshape(W, W)
+        lo_r = 0 if r == 0 else K
+        hi_r = W if r + W == n else W - K
+        lo_c = 0 if c == 0 else K
+        hi_c = W if c + W == n else W - K
+        a = got[r + lo_r:r + hi_r, c + lo_c:c + hi_c]
+        b = want[lo_r:hi_r, lo_c:hi_c]
+        assert np.array_equal(a, b), "window at (%d, %d): %d cells differ" % (r, c, int((a != b).sum()))
