@@ -12,9 +12,12 @@ halo rows traded over RCCL (epic_amd/slab.py); the line then also carries a `wea
 `ranks` (what every rank saw: device, backend) and `in_library` (the same grid through EPIC_HIP_DEVICES: one process,
 all GPUs, hipMemcpyPeerAsync halos -- include/epic_hip.h).
 The arithmetic is the library's `tol` mode by default (--math): one exp-class split per cell shared by its neighbours,
-the reference's rounding stages kept, converged fields within 1e-5 max(1,|u|) of the reference's on its seeded grids,
-basic.png and maze.png (1.6e-5 on umass.png) -- tests/test_gpu_tol.py; the bit-exact `precise` mode is timed beside it
-(`kernels.precise`).
+the reference's rounding stages kept.  It is a TOLERANCE mode, and the line says how far it is from the reference: the
+`parity` object holds, per BASELINE config, the measured distance of the converged field from the reference's (fields the
+reference itself converged, tests/golden/; at 8192^2 and 512^3 the library's reference-identical default mode, relaxed in this
+same run) next to the 1e-5 bar -- including the one config that MISSES it (umass.png, 1.6e-5).  The bit-exact `precise` mode
+is timed beside it (`kernels.precise`), and `relax_default` is the whole relaxation as the unchanged ROS plugin gets it
+(no environment: precise + red-black, bit-identical to harmonic_complete_cpu).
 
 Prints ONE JSON line on rank 0.  Extra objects:
   roofline      dominant kernel (sweep2d) vs the HBM roofline: 8 algorithmic bytes per grid cell per sweep
@@ -26,7 +29,11 @@ Prints ONE JSON line on rank 0.  Extra objects:
                 red-black half-sweeps of the same grid.  Rank 0, N = 1 only.  Its `all_cores` entry is the build's own
                 OpenMP form of the same half-sweep on every host core (not the reference, which has no threading).
   relax*        (N = 1) the complete relaxation to epsilon = 1e-6 through harmonic_execute_gpu: iterations, seconds --
-                Jacobi and red-black with the library defaults (activity tracking on), Jacobi also with tracking off.
+                Jacobi and red-black with activity tracking on (the library's automatic mode), Jacobi also with tracking off,
+                and `relax_default` (precise + red-black: the library with no environment).  Two rates each: `recomputed_...`
+                counts the cells the kernels actually recomputed (epic_hip_work_done), `effective_...` counts every unlocked
+                cell once per iteration whether its tile ran or was skipped as unchanged.
+  parity        see above.
 The timed region itself runs with activity tracking OFF: every sweep recomputes every unlocked cell.
 """
 import argparse
@@ -53,10 +60,12 @@ def parse():
     ap.add_argument("--rows-per-task", type=int, default=0)
     ap.add_argument("--cpu-half-sweeps", type=int, default=40, help="bounded CPU sample (about 0.35 s each at 8192^2)")
     ap.add_argument("--math", choices=("precise", "tol", "fast", "traffic"), default="tol",
-                    help="precise = libm-equivalent exp/log (bit-exact parity mode, default); tol = one exp-class split per "
-                         "cell shared by its neighbours (tolerance parity mode); fast = v_exp_f32/v_log_f32")
+                    help="tol (default HERE; the library's own default is precise) = one exp-class split per cell shared by its "
+                         "neighbours: a tolerance mode, see the `parity` object of the line; precise = expf/logf bit-identical to "
+                         "glibc's (the bit-exact mode); fast = v_exp_f32/v_log_f32, no parity claim")
     ap.add_argument("--scheme", choices=("jacobi", "redblack"), default="jacobi",
-                    help="jacobi = ping-pong sweep of every cell (default); redblack = the reference's in-place half-sweeps")
+                    help="jacobi = ping-pong sweep of every cell (default HERE: what BASELINE.json's metric names); redblack = the "
+                         "reference's in-place half-sweeps (the library's own default)")
     ap.add_argument("--halo", type=int, default=0,
                     help="N > 1: ghost rows per side = sweeps between two halo exchanges (0 = by slab height: 8 from 4096 rows per "
                          "GPU up, 16 from 2048, 32 below -- an exchange costs a fixed few tens of microseconds, a sweep of a short "
@@ -77,6 +86,7 @@ def parse():
                          "counts them -- the `relax` legs always run with the library default (ON)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-relax", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity object (maps, 512^2 / 1024^2, 512^3 relaxations)")
     return ap.parse_args()
 
 
@@ -130,6 +140,83 @@ def cpu_baseline(m, u0, locked, half_sweeps, free_by_colour):
             best["allowed_cores"] = allowed
             best["note"] = "best of a few thread counts; the host may cap CPU time below its core count"
             out["all_cores"] = best
+    return out
+
+
+def parity_object(args, E, MODES, relaxed, locked_8192):
+    """How far the converged fields of the TIMED arithmetic and scheme are from the reference's, per BASELINE config, measured
+    in this run: the relaxation runs here on the device through harmonic_complete_gpu / harmonic_execute_gpu, the yard-stick
+    is data -- fields harmonic_complete_cpu itself converged, committed under tests/golden/ (maps; the benchmark's grid family
+    at 512^2 and 1024^2) -- or, where the reference needs hours (8192^2, 512^3), the library's default mode (precise +
+    red-black), which the GPU tests show to be the reference's iteration bit for bit.  bar = 1e-5 max(1, |u|), BASELINE.json."""
+    import numpy as np
+
+    from epic_amd.harmonic import Harmonic
+    from epic_amd.harmonic_map import HarmonicMap
+    from epic_amd.synthetic import synthetic_grid
+
+    bar = 1e-5
+    gdir = os.path.join(ROOT, "tests", "golden")
+
+    def dist(got, want, locked):
+        got, want, locked = np.ravel(got), np.ravel(want), np.ravel(locked)
+        reached = (locked == 0) & (want > -9e5)
+        d = np.abs(got[reached].astype(np.float64) - want[reached])
+        rel = float((d / np.maximum(1.0, np.abs(want[reached]))).max())
+        return {"max_rel": float("%.3e" % rel), "max_abs": float("%.3e" % float(d.max())), "bar": bar, "within_bar": bool(rel <= bar),
+                "others_equal": bool(np.array_equal(got[~reached], want[~reached]))}
+
+    def complete(h, math, scheme):
+        h.epsilon = 1e-6
+        h.numIterationsToStaggerCheck = 100
+        os.environ["EPIC_HIP_MATH"], os.environ["EPIC_HIP_SCHEME"] = math, scheme
+        try:
+            rc = E.harmonic_complete_gpu(h, 1024)
+        finally:
+            del os.environ["EPIC_HIP_MATH"], os.environ["EPIC_HIP_SCHEME"]
+        if rc != 0:
+            raise RuntimeError("harmonic_complete_gpu returned %d" % rc)
+        return h.u_array().ravel().copy(), int(h.currentIteration)
+
+    out = {"mode": {"math": args.math, "scheme": args.scheme}, "bar": "|du| <= 1e-5 max(1, |u|) over reached free cells",
+           "configs": {}}
+    try:
+        maps = np.load(os.path.join(gdir, "maps_converged.npz"))
+        for cfg, name in (("configs[0] maze.yaml", "maze"), ("configs[1] umass.yaml", "umass"), ("tests/maps basic.png", "basic")):
+            h = HarmonicMap().load(os.path.join(gdir, "maps", name + ".png"))
+            got, its = complete(h, args.math, args.scheme)
+            e = dist(got, maps[name + "/converged_1e-06"], h.locked_array())
+            e.update(iterations=its, against="harmonic_complete_cpu's converged field (tests/golden/maps_converged.npz)")
+            out["configs"][cfg] = e
+        synth = np.load(os.path.join(gdir, "synthetic_converged.npz"))
+        for n in (512, 1024):
+            u0, locked = synthetic_grid([n, n])
+            h = Harmonic()
+            h.set_grid([n, n], u0, locked)
+            got, its = complete(h, args.math, args.scheme)
+            e = dist(got, synth["s%d/converged" % n], locked)
+            e.update(iterations=its, against="harmonic_complete_cpu's converged field (tests/golden/synthetic_converged.npz)")
+            out["configs"]["configs[2] family, %dx%d" % (n, n)] = e
+        if "relax" in relaxed and "relax_default" in relaxed:
+            e = dist(relaxed["relax"], relaxed["relax_default"], locked_8192)
+            e.update(against="this run's relax_default (precise + red-black, the reference's iteration bit for bit)")
+            out["configs"]["configs[2] 8192x8192 (the timed grid)"] = e
+        out["configs"]["configs[3] 32768x32768 on 4 / 8 GPUs"] = {"max_rel": None, "note": "not relaxed at N = 1; same arithmetic and kernels, bit-identical across slab counts (tests/test_gpu_multi_device.py)"}
+        if not args.no_extra_legs:
+            g3 = [512, 512, 512]
+            u3, l3 = synthetic_grid(g3)
+            fields = {}
+            for math, scheme in ((args.math, "jacobi"), ("precise", "redblack")):
+                h = Harmonic()
+                h.set_grid(g3, u3, l3)
+                fields[(math, scheme)], _ = complete(h, math, scheme)
+            e = dist(fields[(args.math, "jacobi")], fields[("precise", "redblack")], l3)
+            e.update(against="precise + red-black relaxed in this run (the reference's 3-D iteration bit for bit)")
+            out["configs"]["configs[4] 512x512x512"] = e
+        missed = [k for k, v in out["configs"].items() if v.get("within_bar") is False]
+        out["misses"] = missed
+    except Exception as exc:   # evidence object: never lose the headline line
+        out["error"] = repr(exc)
     return out
 
 
@@ -229,7 +316,7 @@ def main():
             for fn in (E.harmonic_initialize_dimension_size_gpu, E.harmonic_initialize_potential_values_gpu,
                        E.harmonic_initialize_locked_gpu):
                 if fn(h) != 0:
-                    sys.exit("bench.py: %s failed -- no usable GPU" % fn.__name__)
+                    raise RuntimeError("bench.py: %s failed -- no usable GPU" % fn.__name__)
             upload_s = time.perf_counter() - t0
         finally:
             if devices:
@@ -272,22 +359,31 @@ def main():
         traffic = measured_traffic(n, math, scheme + ("_fused" if fused else "")) if single_device_full_grid else None
         kernel = (("jacobi_fused2d_kernel" if scheme == "jacobi" else "rb_tol_fused2d_kernel" if math == "tol" else "rb_fused2d_kernel")
                   if fused else "sweep2d_kernel")
+        hbm_measured = None if traffic is None else traffic / (launch_us * 1e-6) / 1e9
         return {
             "bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "launch_us": round(launch_us, 3),
+            # `frac` prices the ALGORITHMIC bytes (8 B per cell per iteration).  What the kernel really
+            # moves through HBM is `traffic`; that rate against the same peak is this:
+            "hbm_frac_measured": None if hbm_measured is None else round(hbm_measured / HBM_PEAK_GBPS, 4),
+            "hbm_GBps_measured": None if hbm_measured is None else round(hbm_measured, 1),
+            "limiter": "valu" if fused else "valu+hbm",
             "iterations_per_launch": per_pass,
             "bytes_per_launch": int(BYTES_PER_CELL_SWEEP * cells_per_launch * per_pass),
-            "note": "8 B x grid cells x iterations per launch / mean launch-to-launch device time (HIP events on the kernel's "
-                    "stream, over a batch of plain iterations = launches of this kernel only)"
-                    + ("; the fused pass performs two iterations per launch while moving the field through HBM once: traffic "
-                       "is about half of the algorithmic bytes" if fused else "")
-                    + ("; traffic = PMC FETCH_SIZE x2 + WRITE_SIZE per launch of this command, recorded in profiles/hbm_traffic.json"
-                       if traffic is not None else "; traffic: no PMC measurement of this configuration on file"),
+            "note": "frac = 8 B x grid cells x iterations per launch / mean launch-to-launch device time (HIP events on the kernel's "
+                    "stream, over a batch of plain iterations = launches of this kernel only) / 8 TB/s: an ALGORITHMIC-bytes figure"
+                    + ("; the fused pass performs two iterations per launch while moving the field through HBM once, so its real "
+                       "HBM rate (hbm_frac_measured) is about half of frac and the kernel is bound by VALU issue, not by HBM"
+                       if fused else "")
+                    + ("; traffic = PMC FETCH_SIZE x2 + WRITE_SIZE per launch of this command (rocprofv3 --pmc, separate passes), "
+                       "recorded in profiles/hbm_traffic.json with the summaries it comes from -- bench.py cannot run under the "
+                       "profiler itself" if traffic is not None else "; traffic: no PMC measurement of this configuration on file"),
         }
 
     out = {
         "metric": "cell_updates_per_s_log_harmonic_relax_8192sq", "value": None, "unit": "Mcell-updates/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+        "scaling": "none" if world == 1 else "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
     }
 
@@ -347,13 +443,19 @@ def main():
                 "frac": round(BYTES_PER_CELL_SWEEP * cells_per_launch / (single_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
                 "note": "sweep2d_kernel, one iteration per launch (EPIC_HIP_NO_FUSE=1), same arithmetic, same field, same run"}
         assert E.harmonic_uninitialize_gpu(h) == 0
+        relaxed = {}   # converged 8192^2 fields of this run, for the parity object
         if not args.no_relax:
-            # the complete relaxation, exactly as the plugin runs it (harmonic_execute_gpu), from the initial state: with the
-            # benchmarked scheme (library default: activity tracking on), with the other scheme, and with tracking off
+            # the complete relaxation, exactly as the plugin runs it (harmonic_execute_gpu), from the initial state: the
+            # benchmarked arithmetic with each scheme (activity tracking in the library's automatic mode), with tracking off,
+            # and the library as it is with NO environment (precise + red-black: bit-identical to harmonic_complete_cpu)
             other = "redblack" if args.scheme == "jacobi" else "jacobi"
-            for scheme, track in ((args.scheme, 2), (other, 2), (args.scheme, 0)):   # 2 = the library's automatic mode
+            legs = [("relax", args.math, args.scheme, 2), ("relax_" + other, args.math, other, 2),
+                    ("relax_untracked", args.math, args.scheme, 0), ("relax_default", "precise", "redblack", 2)]
+            work = ct.c_double(0.0)
+            for key, math, scheme, track in legs:
                 h.u_array().ravel()[:] = u0
                 assert E.harmonic_update_model_gpu(h) == 0
+                assert E.epic_hip_set_math_mode(h, MODES[math]) == 0
                 assert E.epic_hip_set_scheme(h, 1 if scheme == "redblack" else 0) == 0
                 assert E.epic_hip_set_activity_tracking(h, track) == 0
                 torch.cuda.synchronize()
@@ -362,15 +464,21 @@ def main():
                 dt = time.perf_counter() - t0
                 assert rc == 0, rc
                 its = int(h.currentIteration)
-                key = ("relax" if scheme == args.scheme else "relax_" + scheme) + ("" if track else "_untracked")
+                assert E.epic_hip_work_done(h, ct.byref(work), 0) == 0    # whole-grid iterations' worth of tiles actually run
+                every = updates_in(scheme, its)                             # every unlocked cell (of the colour) once per iteration
                 out[key] = {
-                    "math": args.math, "scheme": scheme, "activity_tracking": bool(track), "epsilon": 1e-6, "iterations": its,
-                    "seconds": round(dt, 3), "delta": float(h.delta),
-                    "Mcell_updates_per_s": round(updates_in(scheme, its) / dt / 1e6, 1),
-                    "note": "harmonic_execute_gpu from the initial state, includes the final D2H of u; cell-updates counted as "
-                            "iterations x unlocked cells of the colour"
-                            + (" (tiles skipped by tracking count as updated: their values are what the update would have "
-                               "produced)" if track else "")}
+                    "math": math, "scheme": scheme, "activity_tracking": bool(track), "epsilon": 1e-6, "iterations": its,
+                    "seconds": round(dt, 3), "delta": float(h.delta), "grid_iterations_run": round(work.value, 1),
+                    "recomputed_Mcell_updates_per_s": round(every * (work.value / its) / dt / 1e6, 1),
+                    "effective_Mcell_updates_per_s": round(every / dt / 1e6, 1),
+                    "note": "harmonic_execute_gpu from the initial state, includes the final D2H of u.  recomputed = cells the "
+                            "kernels recomputed (iterations x unlocked cells of the colour x the share of tiles that ran, "
+                            "epic_hip_work_done); effective = the same with every tile counted, i.e. the rate an untracked "
+                            "solver would need for this time-to-solution -- tiles skipped by activity tracking hold exactly the "
+                            "values the update would have produced"}
+                if key in ("relax", "relax_default"):
+                    relaxed[key] = h.u_array().ravel().copy()
+            assert E.epic_hip_set_math_mode(h, MODES[args.math]) == 0
         abi_release(h)
         if not args.no_extra_legs and args.math != "precise":
             # the bit-exact mode on the same workload, same box, same run: what the tol arithmetic buys
@@ -398,6 +506,8 @@ def main():
                               "frac": round(BYTES_PER_CELL_SWEEP * 512 ** 3 / (us3 * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
                               "kernel": "sweep3d_kernel", "developed_sweeps": 1600, "sweeps": 300}
             del u3, l3
+        if not args.no_parity:
+            out["parity"] = parity_object(args, E, MODES, relaxed, locked)
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(grid, u0, locked, args.cpu_half_sweeps, free_by_colour)
         print(json.dumps(out), flush=True)
@@ -447,7 +557,7 @@ def main():
     out.update({
         "value": round(r["free"] * sweeps / r["wall"] / 1e6, 1),
         "ms_per_step": round(r["wall"] * 1e3 / args.steps, 4),
-        "scaling": "weak" if weak_first or world == 1 else "strong",
+        "scaling": "none" if world == 1 else "weak" if weak_first else "strong",
         "config": {
             "workload": ("synthetic %dx%d occupancy grid per GPU (%dx%d in all), " % (n, n, n * world, n) if weak_first else
                          "ONE synthetic %dx%d occupancy grid cut into %d row slabs, " % (n, n, world))
