@@ -18,8 +18,12 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <thread>
 #include <vector>
 #include <mutex>
 #include <tuple>
@@ -32,6 +36,87 @@
 using epic::Harmonic;
 
 namespace {
+
+struct DeviceGuard {  // the caller's current device is restored whatever happens in between
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; } }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+struct Crew;  // one host thread per slab (multi-device mode), below
+
+// Work lists of one domain (the whole grid, or one slab of it).  Every iteration lists the tiles its successor has to
+// recompute; tiles whose inputs did not change are never touched (bit-identical results, see kernels_2d.hip).  One device
+// block `wake` holds 3 counter sets (L words each, L = kWakeListCount), the running sum of listed tiles, the queued marks of
+// both directions (tiles words each) and both directions' L lists (ceil(tiles / L) words each); `phase` (mod 6) says which
+// direction (phase & 1) and which counter set (phase % 3) the next launch consumes.  force > 0: the next `force` iterations
+// run every tile.
+struct Track {
+    uint32_t *wake = nullptr;
+    int phase = 0, rpt = 0, force = 2;
+    size_t tiles = 0;
+    static constexpr size_t kL = epic_hip::kWakeListCount, kCS = epic_hip::kWakeCounterStride;
+    uint32_t *counter(int set) const { return wake + kL * kCS * set; }
+    // two words behind the counters: the running sum (64 bits) of the tiles handed to list-driven launches
+    unsigned long long *total() const { return reinterpret_cast<unsigned long long *>(wake + 3 * kL * kCS); }
+    uint32_t *queued(int i) const { return wake + 3 * kL * kCS + 2 + (size_t)i * tiles; }
+    uint32_t *list(int i) const { return wake + 3 * kL * kCS + 2 + 2 * tiles + (size_t)i * kL * epic_hip::sweep_2d_list_cap(tiles); }
+    static size_t words(size_t tiles) { return 3 * kL * kCS + 2 + 2 * tiles + 2 * kL * epic_hip::sweep_2d_list_cap(tiles); }
+    static size_t zeroed_words(size_t tiles) { return 3 * kL * kCS + 2 + 2 * tiles; }  // counters, sum and marks; lists need no init
+    void release()
+    {
+        if (wake) (void)hipFree(wake);
+        wake = nullptr;
+        tiles = 0;
+    }
+    // The lists of the next launch of this domain over `tiles_now` tiles of `rpt_now` rows (re-allocated, on `stream`'s device,
+    // when the tiling has changed: *changed says so).  All null when the block cannot be had: the launch then runs untracked.
+    epic_hip::Activity next(size_t tiles_now, int rpt_now, hipStream_t stream, bool *changed)
+    {
+        epic_hip::Activity act = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (tiles_now != tiles || rpt_now != rpt) {
+            if (changed) *changed = true;
+            release();
+            if (hipMalloc((void **)&wake, words(tiles_now) * sizeof(uint32_t)) == hipSuccess &&
+                hipMemsetAsync(wake, 0, zeroed_words(tiles_now) * sizeof(uint32_t), stream) == hipSuccess) {
+                tiles = tiles_now;
+                rpt = rpt_now;
+                phase = 0;
+                force = 2;
+            } else {
+                (void)hipGetLastError();
+                release();
+            }
+        }
+        if (tiles) {
+            const int li = phase & 1, ci = phase % 3;
+            act.list_in = force > 0 ? nullptr : list(li);
+            act.count_in = counter(ci);
+            act.list_out = list(li ^ 1);
+            act.count_out = counter((ci + 1) % 3);
+            act.count_zero = counter((ci + 2) % 3);
+            act.queued_in = queued(li);
+            act.queued_out = queued(li ^ 1);
+            act.total = total();
+        }
+        return act;
+    }
+    void advance()   // after a successful launch with lists
+    {
+        phase = (phase + 1) % 6;
+        if (force > 0) force--;
+    }
+    // the lists the NEXT launch will consume, in the *_out fields (for launch_wake_tile_range)
+    epic_hip::Activity upcoming() const
+    {
+        epic_hip::Activity act = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (tiles) {
+            act.list_out = list(phase & 1);
+            act.count_out = counter(phase % 3);
+            act.queued_out = queued(phase & 1);
+        }
+        return act;
+    }
+};
 
 struct Ctx {
     int n = 0;
@@ -54,48 +139,41 @@ struct Ctx {
     struct Replay { hipGraphExec_t exec; int cur_flip; double work; };  // cur_flip: whether the sequence ends in the other buffer; work: what it adds to work_full
     std::map<std::tuple<unsigned, int, int, int, int, int, int>, Replay> graphs;
     bool graphs_broken = false;    // a capture / instantiate / launch failed once: batches run eagerly from then on
-    // Activity tracking: every iteration lists the tiles its successor has to recompute; tiles whose inputs did
-    // not change are never touched (bit-identical results, see kernels_2d.hip).  One device block `wake` holds 3 counter
-    // sets (L words each, L = kWakeListCount), the queued marks of both directions (act_tiles words each) and both
-    // directions' L lists (ceil(act_tiles / L) words each); `phase` (mod 6) says which direction (phase & 1) and which
-    // counter set (phase % 3) the next launch consumes.  force > 0: the next `force` iterations run every tile.
+    // Activity tracking (struct Track above): one set of work lists for the grid, or one per slab in multi-device mode.
     int track_mode = 2;            // 0 off, 1 on, 2 automatic (on for grids above 4 Mcell): EPIC_HIP_TRACK / epic_hip_set_activity_tracking
     bool track = false;            // the mode resolved for the current dimensions (resolve_tracking)
-    uint32_t *wake = nullptr;
-    int phase = 0, act_rpt = 0, force = 2;
-    size_t act_tiles = 0;
-    static constexpr size_t kL = epic_hip::kWakeListCount, kCS = epic_hip::kWakeCounterStride;
-    uint32_t *wake_counter(int set) const { return wake + kL * kCS * set; }
-    uint32_t *wake_list(int i) const { return wake + 3 * kL * kCS + 2 + 2 * act_tiles + (size_t)i * kL * epic_hip::sweep_2d_list_cap(act_tiles); }
-    // two words behind the counters: the running sum (64 bits) of the tiles handed to list-driven launches
-    unsigned long long *wake_total() const { return reinterpret_cast<unsigned long long *>(wake + 3 * kL * kCS); }
-    uint32_t *wake_queued(int i) const { return wake + 3 * kL * kCS + 2 + (size_t)i * act_tiles; }
-    static size_t wake_words(size_t tiles) { return 3 * kL * kCS + 2 + 2 * tiles + 2 * kL * epic_hip::sweep_2d_list_cap(tiles); }
-    static size_t wake_zeroed_words(size_t tiles) { return 3 * kL * kCS + 2 + 2 * tiles; }  // counters, sum and marks; lists need no init
+    Track trk;
+    static constexpr size_t kL = Track::kL, kCS = Track::kCS;
     // Work accounting (epic_hip_work_done): whole-grid iterations' worth of cells recomputed since the last reset.  Launches
     // that run every tile count 1 (a fused pass 2) on the host; list-driven launches add their tile counts on the device.
     double work_full = 0.0;
     bool redblack = true;          // scheme: true = the reference's in-place red-black half-sweeps (default: with the precise math that is
                                    // harmonic_complete_cpu bit for bit), false = Jacobi ping-pong (EPIC_HIP_SCHEME=jacobi / epic_hip_set_scheme)
-    // Multi-device mode (EPIC_HIP_DEVICES=0,1,... ; 2-D grids): the rows are cut into one slab per listed device, every
-    // interior side carries `halo` ghost rows that are swept like owned rows and traded every `halo` iterations (see the
-    // "several devices in one process" section below).  buf / maskw / d_delta / stream above then stay unused.
+    // Multi-device mode (EPIC_HIP_DEVICES=0,1,...): the grid is cut along its slowest axis -- rows of a 2-D grid, planes of a
+    // 3-D one: "units" -- into one slab per listed device, every interior side carries `halo` ghost units that are swept like
+    // owned ones and traded every `halo` iterations (see the "several devices in one process" section below).  buf / maskw /
+    // d_delta / stream / trk above then stay unused.
     struct Slab {
         int dev = 0;                 // HIP device ordinal (the list may name a device more than once)
-        int lo = 0, hi = 0;          // owned global rows [lo, hi)
-        int g_top = 0, g_bot = 0;    // ghost rows above / below
-        int rows = 0;                // local rows, ghosts included
+        int lo = 0, hi = 0;          // owned global units [lo, hi)
+        int g_top = 0, g_bot = 0;    // ghost units above / below
+        int rows = 0;                // local units, ghosts included
         float *buf[2] = {nullptr, nullptr};
         uint32_t *maskw = nullptr;
         unsigned *d_delta = nullptr;
         float *h_delta = nullptr;    // pinned
-        hipStream_t stream = nullptr, comm = nullptr;   // interior sweeps / boundary bands + halo copies
-        hipEvent_t ev_prev = nullptr, ev_band = nullptr, ev_comm = nullptr;
+        hipStream_t stream = nullptr, comm = nullptr;   // sweeps / boundary bands + halo copies
+        hipEvent_t ev_prev = nullptr, ev_band = nullptr, ev_comm = nullptr, ev_stage = nullptr;
+        Track trk;                   // this slab's work lists
+        bool peer_up = true;         // the seam to the slab above: direct device-to-device copies (else through `bounce`)
+        float *bounce[2] = {nullptr, nullptr};   // pinned staging of that seam: [0] downwards (into this slab), [1] upwards
         int first() const { return g_top; }              // first owned local row
         int last() const { return rows - 1 - g_bot; }    // last owned local row
         int top() const { return lo - g_top; }           // global row of local row 0
     };
     std::vector<Slab> slabs;
+    int slab_n = 0;                // dimensionality the slabs were laid out for
+    Crew *crew = nullptr;          // one issuing thread per slab (null: the caller's thread issues everything)
     std::vector<int> devices;      // EPIC_HIP_DEVICES as given (validated); fewer than 2 entries: single-device mode
     int halo = 8, since = 0;       // ghost rows per interior side in use; iterations since the last exchange
     int halo_env = 0;              // EPIC_HIP_HALO (0 = not given: chosen by slab height in multi_plan)
@@ -116,6 +194,8 @@ std::mutex g_mu;
 std::unordered_map<Harmonic *, Ctx *> g_ctx;
 
 void resolve_tracking(Ctx *c);
+void force_all(Ctx *c);    // the next two iterations run every tile (after any change of values, masks, mode or tiling)
+bool due_tiles(Ctx *c, unsigned long long *due, unsigned long long *tiles);
 void fold_listed_work(Ctx *c);
 void drop_graphs(Ctx *c);  // captured launch sequences hold the buffer addresses: drop them whenever a buffer goes away
 bool multi_plan(Ctx *c);   // multi-device mode (EPIC_HIP_DEVICES): see "several devices in one process" below
@@ -242,8 +322,7 @@ void drop_ctx_if_empty(Harmonic *h)
     if (c->buf[0] || c->maskw || c->d_m || c->d_delta || multi_holds_anything(c)) return;
     drop_graphs(c);
     if (c->multi()) multi_destroy(c);
-    if (c->wake) (void)hipFree(c->wake);
-    c->wake = nullptr;
+    c->trk.release();
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->h_delta) (void)hipHostFree(c->h_delta);
     delete c;
@@ -254,7 +333,7 @@ void drop_ctx_if_empty(Harmonic *h)
 // are launch-bound either way (3.2-4 us per sweep without, 5-6.7 us with lists, measured), so "automatic" leaves them alone.
 void resolve_tracking(Ctx *c)
 {
-    c->track = !c->multi() && (c->track_mode == 1 || (c->track_mode == 2 && (long long)c->rows * c->pitch > (1ll << 22)));
+    c->track = c->track_mode == 1 || (c->track_mode == 2 && (long long)c->rows * c->pitch > (1ll << 22));
 }
 
 int auto_rows_per_task(const Ctx *c)
@@ -312,42 +391,15 @@ hipError_t enqueue_sweep(Ctx *c, bool check, unsigned iteration)
         const int rpt = c->n == 2 ? auto_rows_per_task(c) : 32;   // the 3-D kernel has a fixed task shape
         const size_t tiles = c->n == 2 ? epic_hip::sweep_2d_tiles(c->rows, c->pitch, rpt)
                                        : epic_hip::sweep_3d_tiles(c->m[0], c->m[1], c->pitch);
-        if (tiles != c->act_tiles || rpt != c->act_rpt) {
-            drop_graphs(c);  // captured sequences hold the old lists (never reached during a capture: force > 0)
+        if (tiles != c->trk.tiles || rpt != c->trk.rpt) {
+            drop_graphs(c);       // captured sequences hold the old lists (never reached during a capture: force > 0)
             fold_listed_work(c);  // the sum kept in the old block
-            if (c->wake) (void)hipFree(c->wake);
-            c->wake = nullptr;
-            c->act_tiles = 0;
-            if (hipMalloc((void **)&c->wake, Ctx::wake_words(tiles) * sizeof(uint32_t)) == hipSuccess &&
-                hipMemsetAsync(c->wake, 0, Ctx::wake_zeroed_words(tiles) * sizeof(uint32_t), c->stream) == hipSuccess) {
-                c->act_tiles = tiles;
-                c->act_rpt = rpt;
-                c->phase = 0;
-                c->force = 2;
-            } else {
-                (void)hipGetLastError();
-                if (c->wake) (void)hipFree(c->wake);
-                c->wake = nullptr;
-            }
         }
-        if (c->act_tiles) {
-            const int li = c->phase & 1, ci = c->phase % 3;
-            act.list_in = c->force > 0 ? nullptr : c->wake_list(li);
-            act.count_in = c->wake_counter(ci);
-            act.list_out = c->wake_list(li ^ 1);
-            act.count_out = c->wake_counter((ci + 1) % 3);
-            act.count_zero = c->wake_counter((ci + 2) % 3);
-            act.queued_in = c->wake_queued(li);
-            act.queued_out = c->wake_queued(li ^ 1);
-            act.total = c->wake_total();
-        }
+        act = c->trk.next(tiles, rpt, c->stream, nullptr);
     }
     if (!act.list_in) c->work_full += 1.0;  // every tile runs (untracked, or a forced iteration of a tracked run)
     auto advance = [&](hipError_t e) {
-        if (e == hipSuccess && act.list_out) {
-            c->phase = (c->phase + 1) % 6;
-            if (c->force > 0) c->force--;
-        }
+        if (e == hipSuccess && act.list_out) c->trk.advance();
         return e;
     };
     if (c->redblack) {
@@ -373,14 +425,23 @@ hipError_t enqueue_sweep(Ctx *c, bool check, unsigned iteration)
 // the stream.
 void fold_listed_work(Ctx *c)
 {
-    if (!c->wake || c->act_tiles == 0) return;
-    unsigned long long t = 0;
-    if (hipStreamSynchronize(c->stream) == hipSuccess &&
-        hipMemcpy(&t, c->wake_total(), sizeof t, hipMemcpyDeviceToHost) == hipSuccess &&
-        hipMemset(c->wake_total(), 0, sizeof t) == hipSuccess)
-        c->work_full += (double)t / (double)c->act_tiles;
-    else
-        (void)hipGetLastError();
+    auto fold = [&](Track &t, hipStream_t stream, double share) {
+        if (!t.wake || t.tiles == 0) return;
+        unsigned long long n = 0;
+        if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(&n, t.total(), sizeof n, hipMemcpyDeviceToHost) == hipSuccess &&
+            hipMemset(t.total(), 0, sizeof n) == hipSuccess)
+            c->work_full += share * (double)n / (double)t.tiles;
+        else
+            (void)hipGetLastError();
+    };
+    if (!c->multi()) {
+        fold(c->trk, c->stream, 1.0);
+        return;
+    }
+    DeviceGuard g;
+    const int units = c->n == 2 ? c->rows : c->m[0];
+    for (auto &sl : c->slabs)   // a slab's lists cover its ghost rows too: weighted by its share of the grid
+        if (hipSetDevice(sl.dev) == hipSuccess) fold(sl.trk, sl.stream, (double)sl.rows / (double)units);
 }
 
 void drop_graphs(Ctx *c)
@@ -415,10 +476,9 @@ bool fuses_tol(const Ctx *c)   // either scheme
 }
 bool fuses_jacobi(const Ctx *c) { return !c->redblack && fuses_tol(c); }
 // red-black, tol math: both colours in one pass (rb_tol_fused2d_kernel); one device only
-bool fuses_rb_tol(const Ctx *c) { return c->redblack && !c->multi() && fuses_tol(c); }
-// ... and whether the NEXT two can: on several devices a pass leaves two more ghost rows stale, so neither of its two
-// iterations may be one that ends with an exchange.
-bool next_two_fuse(const Ctx *c) { return !c->multi() || c->since + 2 < c->halo; }
+bool fuses_rb_tol(const Ctx *c) { return c->redblack && fuses_tol(c); }
+// (on several devices a pass leaves two more ghost units stale, so neither of its two iterations may be one that ends with an
+// exchange: multi_run fuses inside the stretches between exchanges only)
 
 // Rows per task of the fused Jacobi pass (kernels.h: jacobi_fused_auto_rows), per device in multi-device mode.
 int jacobi_fused_rows_per_task(const Ctx *c)
@@ -429,11 +489,12 @@ int jacobi_fused_rows_per_task(const Ctx *c)
     return epic_hip::jacobi_fused_auto_rows((int)rows, c->pitch);
 }
 
-hipError_t multi_sweep_pair(Ctx *c);
+hipError_t multi_run(Ctx *c, unsigned count, unsigned first, bool check_first);
 
 hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
 {
-    static const bool no_fuse = getenv("EPIC_HIP_NO_FUSE") != nullptr;
+    if (c->multi()) return multi_run(c, count, first, false);
+    const bool no_fuse = getenv("EPIC_HIP_NO_FUSE") != nullptr;   // (read per call: the tests switch it)
     // (the fused passes have their own 248-column tiling and no work lists: they are used when tracking is off -- or
     //  bypassed for the batch, harmonic_execute_gpu; rb_fused2d_kernel for the precise / fast arithmetic, the RB instance of
     //  the tol pass for tol)
@@ -444,13 +505,12 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
     // EPIC_HIP_FUSE_MIN_CELLS: grids below it keep the single sweeps (default 4 Mcell; the tests set 0).
     if (!no_fuse && fuses_jacobi(c)) {
         while (i < count) {
-            if (count - i >= 2 && next_two_fuse(c)) {
-                hipError_t e = c->multi() ? multi_sweep_pair(c)
-                                          : epic_hip::launch_jacobi_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows,
-                                                                             c->pitch, jacobi_fused_rows_per_task(c), c->math, c->stream, -1,
-                                                                             c->maskf());
+            if (count - i >= 2) {
+                hipError_t e = epic_hip::launch_jacobi_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch,
+                                                                jacobi_fused_rows_per_task(c), c->math, c->stream, -1, c->maskf());
                 if (e != hipSuccess) return e;
-                if (!c->multi()) { c->cur ^= 1; c->work_full += 2.0; }
+                c->cur ^= 1;
+                c->work_full += 2.0;
                 i += 2;
             } else {
                 hipError_t e = enqueue_sweep(c, false, first + i);
@@ -489,19 +549,19 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
     const bool small = (long long)c->rows * c->pitch <= (1ll << 22);
     const bool no_graph = getenv("EPIC_HIP_NO_GRAPH") != nullptr;  // (read per batch: the tests switch it)
     // a captured sequence bakes in the work-list buffers and list mode: run eagerly until the forced iterations are over
-    if (!small || count < 8 || no_graph || c->multi() || (c->track && (c->force > 0 || c->act_tiles == 0)))
+    if (!small || count < 8 || no_graph || c->multi() || (c->track && (c->trk.force > 0 || c->trk.tiles == 0)))
         return enqueue_plain_run(c, count, first);
     // (the fused-pass switches are read per batch -- EPIC_HIP_NO_FUSE, EPIC_HIP_FUSE_MIN_CELLS, EPIC_HIP_FUSED_ROWS --, so they
     // belong to the key: 0 = single sweeps, otherwise the task height of the pass)
     const int fuse_cfg = fuses_tol(c) ? jacobi_fused_rows_per_task(c) : 0;
-    const auto key = std::make_tuple(count, c->cur + 2 * (c->track ? 1 + c->phase : 0), (int)(first & 1u), c->math,
+    const auto key = std::make_tuple(count, c->cur + 2 * (c->track ? 1 + c->trk.phase : 0), (int)(first & 1u), c->math,
                                      (int)c->redblack, auto_rows_per_task(c), fuse_cfg);
     if (c->graphs_broken) return enqueue_plain_run(c, count, first);
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         // Capture is an optimisation: whatever goes wrong in it (begin, a launch during capture, end, instantiate), the
         // state is put back as it was, the error is cleared, the context stops trying and the batch runs eagerly.
-        const int cur0 = c->cur, phase0 = c->phase, force0 = c->force;
+        const int cur0 = c->cur, phase0 = c->trk.phase, force0 = c->trk.force;
         const double work0 = c->work_full;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
@@ -513,8 +573,8 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
         }
         const int cur_flip = c->cur ^ cur0;  // (a fused pass advances two iterations and changes buffers once)
         c->cur = cur0;  // nothing has run yet
-        c->phase = phase0;
-        c->force = force0;
+        c->trk.phase = phase0;
+        c->trk.force = force0;
         const double work = c->work_full - work0;
         c->work_full = work0;
         if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -535,7 +595,7 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
     }
     c->cur ^= it->second.cur_flip;
     c->work_full += it->second.work;
-    if (c->track) c->phase = (int)((c->phase + count) % 6);
+    if (c->track) c->trk.phase = (int)((c->trk.phase + count) % 6);
     return hipSuccess;
 }
 
@@ -562,7 +622,7 @@ int multi_upload_locked(Harmonic *h, Ctx *c, const char *fn);
 int upload_u(Harmonic *h, Ctx *c, const char *fn)
 {
     if (c->multi()) return multi_upload_u(h, c, fn);
-    c->force = 2;  // new values: no tile may be left out on the strength of the old work lists
+    force_all(c);  // new values: no tile may be left out on the strength of the old work lists
     // padding columns hold the obstacle seed; both buffers, so that whichever is read first is complete
     if (c->pitch != c->cols) {
         for (int b = 0; b < 2; b++)
@@ -585,7 +645,7 @@ int upload_u(Harmonic *h, Ctx *c, const char *fn)
 int upload_locked(Harmonic *h, Ctx *c, const char *fn)
 {
     if (c->multi()) return multi_upload_locked(h, c, fn);
-    c->force = 2;
+    force_all(c);
     const size_t cells = (size_t)c->rows * c->cols;
     uint32_t *tmp = nullptr;
     if (hipMalloc((void **)&tmp, cells * sizeof(uint32_t)) != hipSuccess) {
@@ -617,22 +677,113 @@ int upload_locked(Harmonic *h, Ctx *c, const char *fn)
 // the callers that only ever make that call (the ROS plugin: harmonic_complete_gpu, src/epic_nav_core_plugin.cpp:256)
 // get a whole node by setting one environment variable.  Not in the reference (it has no multi-GPU code).
 //
-// The rows of a 2-D grid are cut into one slab per listed device.  Every interior side of a slab carries G = `halo` ghost
-// rows that are swept like owned rows, with their true masks; the outermost ghost row has nothing beyond it to be computed
-// from, so with every iteration one more ghost row goes stale from the outside in, and after G iterations the neighbours
-// trade their G outermost owned rows (hipMemcpyPeerAsync over xGMI) -- the bytes of one row per iteration in G times
-// fewer, G times larger copies.  On the iteration that ends with an exchange the two boundary bands of a slab are swept
-// first, on a second stream, and copied out while the interior is swept on the compute stream.  Every owned cell sees
-// exactly the values a single-domain iteration would give it: results are bit-identical to the single-device path for
-// any number of slabs and any G (tests/test_gpu_multi_device.py runs the parity suite with EPIC_HIP_DEVICES=0,0,0,0).
-// Red-black: the colour of a local row is the colour of its GLOBAL row (parity shifted by the slab's first global row).
-// Activity tracking is off in this mode (the work lists are per grid, not per slab).
+// The grid is cut along its slowest axis into one slab per listed device: rows of a 2-D grid, planes of a 3-D one ("units"
+// below).  Every interior side of a slab carries G = `halo` ghost units that are swept like owned ones, with their true
+// masks; the outermost ghost unit has nothing beyond it to be computed from, so with every iteration one more ghost unit goes
+// stale from the outside in, and after G iterations the neighbours trade their G outermost owned units -- the bytes of one
+// unit per iteration in G times fewer, G times larger copies.  Every owned cell sees exactly the values a single-domain
+// iteration would give it: fields, max |du| (ghost units are swept but kept out of the convergence test) and iteration
+// counts are bit-identical to the single-device path for any number of slabs and any G (tests/test_gpu_multi_device.py runs
+// the parity suite with EPIC_HIP_DEVICES=0,0,0,0).  Red-black: the colour of a local unit is the colour of its GLOBAL unit
+// (parity shifted by the slab's first global unit).
+//
+// Transport (the product choice): the copy engines, device to device -- hipMemcpyPeerAsync on the RECEIVER's second stream
+// behind the sender's event, peer access enabled where the fabric offers it (xGMI on an MI355X node); where it cannot be
+// enabled the library says so once on stderr and stages the units through pinned host memory itself (two copies and an
+// event; EPIC_HIP_NO_PEER=1 forces that path).  RCCL is not linked: its send / recv pairs would bring a communicator per
+// process and a kernel per message into a library whose callers (one C call from a ROS node) have neither a launcher nor
+// ranks, for messages -- G rows of 32 KiB -- that a copy engine moves without occupying a CU; the one-process-per-GPU form
+// over RCCL lives beside the library (epic_amd/slab.py, what bench.py --gpus N runs).
+//
+// Issue: one host thread per slab (struct Crew).  A single thread issuing N launches of ~3.5 us each is as slow as a
+// 1024-row slab's 14 us sweep at N = 8; the crew's threads each own one device (hipSetDevice once) and are handed whole
+// stretches of iterations -- everything up to the next exchange -- in one hand-over.  EPIC_HIP_THREADS=0: the caller's thread
+// issues everything (A/B, debugging).
+//
+// Activity tracking works per slab (Track, one per slab): a slab's sweep is one list-driven launch over its local tiles;
+// after an exchange the tiles that hold or read the rewritten ghost units are woken for the next launch.
 // ---------------------------------------------------------------------------------------------------------
-struct DeviceGuard {  // the caller's current device is restored whatever happens in between
-    int prev = -1;
-    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; } }
-    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+// One host thread per slab.  run(f) has every thread call f(k) for its slab k and returns the first error once all are
+// back; the threads spin for a short while between hand-overs (a relaxation hands over every few tens of microseconds) and
+// sleep on a condition variable otherwise.
+struct Crew {
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::atomic<unsigned> generation{0};
+    std::atomic<int> pending{0};
+    std::function<hipError_t(int)> job;
+    std::vector<hipError_t> result;
+    bool quit = false;
+
+    void start(const std::vector<int> &devices)
+    {
+        result.assign(devices.size(), hipSuccess);
+        for (size_t k = 0; k < devices.size(); k++)
+            threads.emplace_back([this, k, dev = devices[k]] {
+                (void)hipSetDevice(dev);
+                unsigned seen = 0;
+                for (;;) {
+                    for (int spin = 0; spin < 20000 && generation.load(std::memory_order_acquire) == seen; spin++)
+                        __builtin_ia32_pause();
+                    if (generation.load(std::memory_order_acquire) == seen) {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv_go.wait(lk, [&] { return generation.load(std::memory_order_acquire) != seen; });
+                    }
+                    seen = generation.load(std::memory_order_acquire);
+                    if (quit) return;
+                    result[k] = job((int)k);
+                    if (pending.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                        std::lock_guard<std::mutex> lk(mu);
+                        cv_done.notify_all();
+                    }
+                }
+            });
+    }
+    hipError_t run(std::function<hipError_t(int)> f)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = std::move(f);
+            pending.store((int)threads.size(), std::memory_order_release);
+            generation.fetch_add(1, std::memory_order_acq_rel);
+        }
+        cv_go.notify_all();
+        for (int spin = 0; spin < 20000 && pending.load(std::memory_order_acquire) != 0; spin++) __builtin_ia32_pause();
+        if (pending.load(std::memory_order_acquire) != 0) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_done.wait(lk, [&] { return pending.load(std::memory_order_acquire) == 0; });
+        }
+        for (hipError_t e : result)
+            if (e != hipSuccess) return e;
+        return hipSuccess;
+    }
+    void stop()
+    {
+        if (threads.empty()) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+            generation.fetch_add(1, std::memory_order_acq_rel);
+        }
+        cv_go.notify_all();
+        for (auto &t : threads) t.join();
+        threads.clear();
+    }
 };
+
+// f(k) for every slab k: by the crew's threads, or one after the other on the caller's thread (with its device restored)
+hipError_t for_each_slab(Ctx *c, const std::function<hipError_t(int)> &f)
+{
+    if (c->crew && !c->crew->threads.empty()) return c->crew->run(f);
+    DeviceGuard g;
+    for (int k = 0; k < (int)c->slabs.size(); k++) {
+        hipError_t e = hipSetDevice(c->slabs[k].dev);
+        if (e == hipSuccess) e = f(k);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
 
 void multi_free_u(Ctx *c)
 {
@@ -667,38 +818,44 @@ bool multi_holds_anything(const Ctx *c)
         if (sl.buf[0] || sl.maskw || sl.d_delta) return true;
     return false;
 }
-void multi_destroy(Ctx *c)  // streams, events, pinned words; the slabs themselves
+void multi_destroy(Ctx *c)  // the crew, streams, events, pinned words, work lists; the slabs themselves
 {
     DeviceGuard g;
+    if (c->crew) { c->crew->stop(); delete c->crew; c->crew = nullptr; }
     multi_free_u(c); multi_free_mask(c); multi_free_delta(c);
     for (auto &sl : c->slabs) {
         (void)hipSetDevice(sl.dev);
+        sl.trk.release();
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
         if (sl.comm) (void)hipStreamDestroy(sl.comm);
-        for (hipEvent_t e : {sl.ev_prev, sl.ev_band, sl.ev_comm}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {sl.ev_prev, sl.ev_band, sl.ev_comm, sl.ev_stage}) if (e) (void)hipEventDestroy(e);
         if (sl.h_delta) (void)hipHostFree(sl.h_delta);
+        for (float *&b : sl.bounce) { if (b) (void)hipHostFree(b); b = nullptr; }
     }
     c->slabs.clear();
 }
 
 // Decide the mode for the dimensions now in *c and, in multi-device mode, lay the slabs out (no device memory yet).
-// Single-device mode when fewer than two devices are listed, the grid is not 2-D or it is too small to cut.
+// Single-device mode when fewer than two devices are listed or the grid is too small to cut.
 bool multi_plan(Ctx *c)
 {
     const int want = (int)c->devices.size();
-    const bool multi = want >= 2 && c->n == 2 && c->rows >= 4 * want;
+    const int units = c->n == 2 ? c->rows : c->m[0];
+    const bool multi = want >= 2 && (c->n == 2 || c->n == 3) && units >= 4 * want;
     if (!multi) {
         if (!c->slabs.empty() && !multi_holds_anything(c)) multi_destroy(c);
         return false;
     }
-    if ((int)c->slabs.size() == want && c->slabs.back().hi == c->rows) return true;  // already laid out for these dimensions
+    if ((int)c->slabs.size() == want && c->slabs.back().hi == units && c->slab_n == c->n) return true;  // already laid out for these dimensions
     if (!c->slabs.empty()) multi_destroy(c);
     DeviceGuard g;
-    const int base = c->rows / want, rem = c->rows % want;
+    const int base = units / want, rem = units % want;
     // ghost depth G = iterations between two exchanges: an exchange costs a fixed few tens of microseconds while a sweep of
-    // a short slab takes ~15, and 2 G extra rows per slab are cheap -- 8 from 4096 rows per device up, 16 from 2048, 32 below
-    const int want_halo = c->halo_env > 0 ? c->halo_env : base >= 4096 ? 8 : base >= 2048 ? 16 : 32;
+    // a short slab takes ~15, and 2 G extra rows per slab are cheap -- 8 from 4096 rows per device up, 16 from 2048, 32 below;
+    // a plane of a 3-D grid is a whole sweep's worth of rows: 2 planes
+    const int want_halo = c->halo_env > 0 ? c->halo_env : c->n == 3 ? 2 : base >= 4096 ? 8 : base >= 2048 ? 16 : 32;
     const int halo = std::max(1, std::min(want_halo, base / 2));
+    const bool no_peer = getenv("EPIC_HIP_NO_PEER") != nullptr;
     int lo = 0;
     c->slabs.resize(want);
     for (int k = 0; k < want; k++) {
@@ -716,27 +873,56 @@ bool multi_plan(Ctx *c)
                   hipEventCreateWithFlags(&sl.ev_prev, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&sl.ev_band, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&sl.ev_comm, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&sl.ev_stage, hipEventDisableTiming) == hipSuccess &&
                   hipHostMalloc((void **)&sl.h_delta, 64, hipHostMallocDefault) == hipSuccess;
         if (!ok) {
             (void)hipGetLastError();
             multi_destroy(c);
             return false;
         }
-        for (int j = 0; j < k; j++)  // direct copies between the devices where the fabric allows them
-            if (c->slabs[j].dev != sl.dev) {
-                int can = 0;
-                if (hipDeviceCanAccessPeer(&can, sl.dev, c->slabs[j].dev) == hipSuccess && can) {
-                    (void)hipDeviceEnablePeerAccess(c->slabs[j].dev, 0);
-                    (void)hipSetDevice(c->slabs[j].dev);
-                    (void)hipDeviceEnablePeerAccess(sl.dev, 0);
-                    (void)hipSetDevice(sl.dev);
-                }
-                (void)hipGetLastError();  // "already enabled" is fine
+        // the seam between slab k - 1 and this one: direct copies where the fabric allows them, checked in both directions
+        sl.peer_up = true;
+        if (k > 0) {
+            Ctx::Slab &up = c->slabs[k - 1];
+            bool direct = !no_peer;
+            if (direct && up.dev != sl.dev) {
+                auto enable = [](int from, int to) {   // `from` may address `to`'s memory
+                    int can = 0;
+                    if (hipSetDevice(from) != hipSuccess || hipDeviceCanAccessPeer(&can, from, to) != hipSuccess || !can) {
+                        (void)hipGetLastError();
+                        return false;
+                    }
+                    const hipError_t e = hipDeviceEnablePeerAccess(to, 0);
+                    (void)hipGetLastError();
+                    return e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+                };
+                direct = enable(sl.dev, up.dev) && enable(up.dev, sl.dev);
+                (void)hipSetDevice(sl.dev);
+                if (!direct)
+                    fprintf(stderr, "Warning[epic_hip]: no peer access between devices %d and %d: halo units are staged through pinned host memory.\n",
+                            up.dev, sl.dev);
             }
+            sl.peer_up = direct;
+            if (!direct) {   // one pinned buffer per direction across this seam
+                const size_t bytes = (size_t)halo * (c->n == 2 ? 1 : c->m[1]) * c->pitch * sizeof(float);
+                if (hipHostMalloc((void **)&sl.bounce[0], bytes, hipHostMallocDefault) != hipSuccess ||
+                    hipHostMalloc((void **)&sl.bounce[1], bytes, hipHostMallocDefault) != hipSuccess) {
+                    (void)hipGetLastError();
+                    multi_destroy(c);
+                    return false;
+                }
+            }
+        }
     }
     c->halo = halo;
     c->since = 0;
-    c->track = false;
+    c->slab_n = c->n;
+    const char *te = getenv("EPIC_HIP_THREADS");
+    if (!(te && atoi(te) == 0)) {
+        c->crew = new Crew();
+        c->crew->start(c->devices);
+    }
+    resolve_tracking(c);
     return true;
 }
 
@@ -757,23 +943,28 @@ void multi_sync(Ctx *c)
     }
 }
 
+// geometry of a unit (a row of a 2-D grid, a plane of a 3-D one) on the device and in the caller's arrays
+size_t unit_floats(const Ctx *c) { return (size_t)(c->n == 2 ? 1 : c->m[1]) * c->pitch; }
+size_t unit_rows(const Ctx *c) { return (size_t)(c->n == 2 ? 1 : c->m[1]); }
+
 int multi_upload_u(Harmonic *h, Ctx *c, const char *fn)
 {
     DeviceGuard g;
     for (auto &sl : c->slabs) {
         if (hipSetDevice(sl.dev) != hipSuccess) return EPIC_ERROR_DEVICE_MALLOC;
         for (int b = 0; b < 2; b++)
-            if (epic_hip::launch_fill(sl.buf[b], (size_t)sl.rows * c->pitch, -1e6f, sl.stream) != hipSuccess) {
+            if (epic_hip::launch_fill(sl.buf[b], (size_t)sl.rows * unit_floats(c), -1e6f, sl.stream) != hipSuccess) {
                 report(fn, "Failed to initialise device-side memory for the potential values.");
                 return EPIC_ERROR_KERNEL_EXECUTION;
             }
         if (hipStreamSynchronize(sl.stream) != hipSuccess) return EPIC_ERROR_DEVICE_SYNCHRONIZE;
-        if (hipMemcpy2D(sl.buf[0], (size_t)c->pitch * sizeof(float), h->u + (size_t)sl.top() * c->cols,
-                        (size_t)c->cols * sizeof(float), (size_t)c->cols * sizeof(float), (size_t)sl.rows,
+        if (hipMemcpy2D(sl.buf[0], (size_t)c->pitch * sizeof(float), h->u + (size_t)sl.top() * unit_rows(c) * c->cols,
+                        (size_t)c->cols * sizeof(float), (size_t)c->cols * sizeof(float), (size_t)sl.rows * unit_rows(c),
                         hipMemcpyHostToDevice) != hipSuccess) {
             report(fn, "Failed to copy memory from host to device for the potential values.");
             return EPIC_ERROR_MEMCPY_TO_DEVICE;
         }
+        sl.trk.force = 2;
     }
     c->cur = 0;
     c->since = 0;
@@ -781,12 +972,17 @@ int multi_upload_u(Harmonic *h, Ctx *c, const char *fn)
     return EPIC_SUCCESS;
 }
 
+size_t slab_mask_words(const Ctx *c, const Ctx::Slab &sl)
+{
+    return c->n == 2 ? Ctx::mask_words_both_2d(sl.rows, c->pitch) : epic_hip::mask_words_3d(sl.rows, c->m[1], c->pitch);
+}
+
 int multi_upload_locked(Harmonic *h, Ctx *c, const char *fn)
 {
     DeviceGuard g;
     for (auto &sl : c->slabs) {
         if (hipSetDevice(sl.dev) != hipSuccess) return EPIC_ERROR_DEVICE_MALLOC;
-        const size_t cells = (size_t)sl.rows * c->cols;
+        const size_t cells = (size_t)sl.rows * unit_rows(c) * c->cols;
         uint32_t *tmp = nullptr;
         if (hipMalloc((void **)&tmp, cells * sizeof(uint32_t)) != hipSuccess) {
             (void)hipGetLastError();
@@ -794,123 +990,224 @@ int multi_upload_locked(Harmonic *h, Ctx *c, const char *fn)
             return EPIC_ERROR_DEVICE_MALLOC;
         }
         int rc = EPIC_SUCCESS;
-        if (hipMemcpy(tmp, h->locked + (size_t)sl.top() * c->cols, cells * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+        if (hipMemcpy(tmp, h->locked + (size_t)sl.top() * unit_rows(c) * c->cols, cells * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
             report(fn, "Failed to copy memory from host to device for the locked cells.");
             rc = EPIC_ERROR_MEMCPY_TO_DEVICE;
-        } else if (epic_hip::launch_pack_mask_2d(tmp, sl.rows, c->cols, c->pitch, sl.g_top > 0, sl.g_bot > 0, sl.maskw,
-                                                 sl.stream) != hipSuccess ||
-                   epic_hip::launch_fuse_masks_2d(sl.maskw, sl.rows, c->pitch, c->maskf(sl), sl.stream) != hipSuccess ||
-                   hipStreamSynchronize(sl.stream) != hipSuccess) {
-            report(fn, "Failed to execute the 'pack mask' kernel.");
-            rc = EPIC_ERROR_KERNEL_EXECUTION;
+        } else {
+            // the outermost unit of a local grid is locked either way: the grid's own border, or a ghost unit that has nothing
+            // beyond it to be computed from (2-D: the ghost flags; 3-D: the packer locks the faces of the grid it is given)
+            hipError_t e = c->n == 2 ? epic_hip::launch_pack_mask_2d(tmp, sl.rows, c->cols, c->pitch, sl.g_top > 0, sl.g_bot > 0, sl.maskw, sl.stream)
+                                     : epic_hip::launch_pack_mask_3d(tmp, sl.rows, c->m[1], c->m[2], c->pitch, sl.maskw, sl.stream);
+            if (e == hipSuccess && c->n == 2) e = epic_hip::launch_fuse_masks_2d(sl.maskw, sl.rows, c->pitch, c->maskf(sl), sl.stream);
+            if (e != hipSuccess || hipStreamSynchronize(sl.stream) != hipSuccess) {
+                report(fn, "Failed to execute the 'pack mask' kernel.");
+                rc = EPIC_ERROR_KERNEL_EXECUTION;
+            }
         }
         (void)hipFree(tmp);
         if (rc != EPIC_SUCCESS) return rc;
+        sl.trk.force = 2;
     }
-    // (`since` is left alone: the mask does not refresh the ghost rows of u -- multi_upload_u does, and resets the countdown)
+    // (`since` is left alone: the mask does not refresh the ghost units of u -- multi_upload_u does, and resets the countdown)
     return EPIC_SUCCESS;
 }
 
-// Copy `nrows` rows between two slabs' buffers on `stream` (a stream of the destination's device).
-hipError_t multi_copy_rows(const Ctx *c, const Ctx::Slab &dst, float *dbuf, int drow, const Ctx::Slab &src, const float *sbuf,
-                           int srow, int nrows, hipStream_t stream)
+// `n` units from slab `src` (starting at its local unit `sunit`) into slab `dst` (at `dunit`), on dst's second stream, behind
+// src's event `after`.  Direct where the seam allows it; otherwise through the seam's pinned buffer `bounce`: device -> host on
+// src's second stream, host -> device on dst's, an event in between.
+hipError_t multi_copy_units(const Ctx *c, Ctx::Slab &dst, float *dbuf, int dunit, Ctx::Slab &src, const float *sbuf, int sunit, int n,
+                            hipEvent_t after, bool direct, float *bounce)
 {
-    const size_t bytes = (size_t)nrows * c->pitch * sizeof(float);
-    float *d = dbuf + (size_t)drow * c->pitch;
-    const float *sp = sbuf + (size_t)srow * c->pitch;
-    if (dst.dev == src.dev) return hipMemcpyAsync(d, sp, bytes, hipMemcpyDeviceToDevice, stream);
-    return hipMemcpyPeerAsync(d, dst.dev, sp, src.dev, bytes, stream);
+    const size_t bytes = (size_t)n * unit_floats(c) * sizeof(float);
+    float *d = dbuf + (size_t)dunit * unit_floats(c);
+    const float *sp = sbuf + (size_t)sunit * unit_floats(c);
+    hipError_t e;
+    if (direct) {
+        if ((e = hipSetDevice(dst.dev)) != hipSuccess || (e = hipStreamWaitEvent(dst.comm, after, 0)) != hipSuccess) return e;
+        return dst.dev == src.dev ? hipMemcpyAsync(d, sp, bytes, hipMemcpyDeviceToDevice, dst.comm)
+                                  : hipMemcpyPeerAsync(d, dst.dev, sp, src.dev, bytes, dst.comm);
+    }
+    if ((e = hipSetDevice(src.dev)) != hipSuccess || (e = hipStreamWaitEvent(src.comm, after, 0)) != hipSuccess ||
+        (e = hipMemcpyAsync(bounce, sp, bytes, hipMemcpyDeviceToHost, src.comm)) != hipSuccess ||
+        (e = hipEventRecord(src.ev_stage, src.comm)) != hipSuccess)
+        return e;
+    if ((e = hipSetDevice(dst.dev)) != hipSuccess || (e = hipStreamWaitEvent(dst.comm, src.ev_stage, 0)) != hipSuccess) return e;
+    return hipMemcpyAsync(d, bounce, bytes, hipMemcpyHostToDevice, dst.comm);
 }
 
-// One iteration of the whole grid, enqueued on every slab's streams.
-hipError_t multi_sweep(Ctx *c, bool check, unsigned iteration)
+// units [lo, hi) of one slab, one launch; check units [clo, chi) count for max |du| when d != nullptr
+hipError_t slab_launch(Ctx *c, Ctx::Slab &sl, int lo, int hi, unsigned *d, int clo, int chi, unsigned iteration, hipStream_t st,
+                       const epic_hip::Activity *act)
 {
-    DeviceGuard g;
-    const int rpt = auto_rows_per_task(c);
-    const bool exchange = c->since + 1 >= c->halo;
+    float *src = sl.buf[c->cur], *dst = c->redblack ? src : sl.buf[c->cur ^ 1];
+    const int parity = c->redblack ? (int)((iteration + (unsigned)sl.top()) & 1u) : -1;
+    if (c->n == 2)
+        return epic_hip::launch_sweep_2d(src, dst, sl.maskw, sl.rows, c->pitch, lo, hi, auto_rows_per_task(c), c->math, parity, d, st, act, clo, chi);
+    return epic_hip::launch_sweep_3d(src, dst, sl.maskw, sl.rows, c->m[1], c->pitch, lo, hi, c->math, parity, d, st, act, clo, chi);
+}
+
+size_t slab_tiles(const Ctx *c, const Ctx::Slab &sl, int rpt)
+{
+    return c->n == 2 ? epic_hip::sweep_2d_tiles(sl.rows, c->pitch, rpt) : epic_hip::sweep_3d_tiles(sl.rows, c->m[1], c->pitch);
+}
+
+// Iterations [first, first + count) of the whole grid, enqueued on every slab's streams.  check_first: the first of them is a
+// check iteration (its max |du| lands in the slabs' delta words).  Between two exchanges a slab needs nothing from the others:
+// each crew thread gets the whole stretch at once; the iteration that ends with an exchange takes three hand-overs (sweeps
+// and band events, then every slab pulling its two halos, then the joins).
+hipError_t multi_run(Ctx *c, unsigned count, unsigned first, bool check_first)
+{
     const int G = c->halo;
-    hipError_t e = hipSuccess;
-    auto fail = [&](hipError_t x) { if (e == hipSuccess && x != hipSuccess) e = x; return x != hipSuccess; };
-    for (auto &sl : c->slabs) {
-        if (fail(hipSetDevice(sl.dev))) return e;
-        float *src = sl.buf[c->cur], *dst = c->redblack ? src : sl.buf[c->cur ^ 1];
-        const int parity = c->redblack ? (int)((iteration + (unsigned)sl.top()) & 1u) : -1;
-        unsigned *d = check ? sl.d_delta : nullptr;
-        if (check && fail(hipMemsetAsync(sl.d_delta, 0, sizeof(unsigned), sl.stream))) return e;
-        auto rows = [&](int lo, int hi, unsigned *dd, hipStream_t st) {
-            return epic_hip::launch_sweep_2d(src, dst, sl.maskw, sl.rows, c->pitch, lo, hi, rpt, c->math, parity, dd, st);
-        };
-        if (!exchange) {
-            // ghost rows (still exact deep enough) are swept like any other row; they do not count for max |du|
-            if (check && (sl.g_top || sl.g_bot)) {
-                if (fail(rows(0, sl.first(), nullptr, sl.stream)) || fail(rows(sl.first(), sl.last() + 1, d, sl.stream)) ||
-                    fail(rows(sl.last() + 1, sl.rows, nullptr, sl.stream)))
-                    return e;
-            } else if (fail(rows(0, sl.rows, d, sl.stream))) {
+    const bool tracked = c->track;
+    // pairs of plain iterations as one fused pass, as on one device: Jacobi and red-black with the tol math, red-black with the
+    // precise / fast math (2-D grids from 4 Mcell up, no work lists)
+    const bool fuse_rb = !tracked && c->redblack && c->n == 2 && c->math != 4 && getenv("EPIC_HIP_NO_FUSE") == nullptr &&
+                         (long long)c->rows * c->pitch >= (1ll << 22);
+    const bool fuse = !tracked && (fuses_tol(c) || fuse_rb);
+    const int rpt_track = c->n == 2 ? auto_rows_per_task(c) : 32;
+    unsigned done = 0;
+    while (done < count) {
+        // a stretch without exchange: iterations that keep `since` below G - 1 at their start
+        const unsigned calm = (unsigned)std::max(0, G - 1 - c->since);
+        const unsigned n_calm = std::min(count - done, calm);
+        if (n_calm > 0) {
+            const unsigned it0 = first + done;
+            const bool chk = check_first && done == 0;
+            const int cur0 = c->cur;
+            const int fused_rpt = !fuse ? 0 : fuse_rb ? fused_rows_per_task(c) : jacobi_fused_rows_per_task(c);
+            hipError_t e = for_each_slab(c, [&, it0, chk, cur0, fused_rpt, n_calm](int k) -> hipError_t {
+                Ctx::Slab &sl = c->slabs[k];
+                int cur = cur0;
+                hipError_t e = hipSuccess;
+                for (unsigned i = 0; i < n_calm && e == hipSuccess;) {
+                    const bool check = chk && i == 0;
+                    if (fuse && !check && n_calm - i >= 2) {   // two more ghost units go stale: n_calm leaves room for them
+                        const int parity = c->redblack ? (int)((it0 + i + (unsigned)sl.top()) & 1u) : -1;
+                        e = fuse_rb ? epic_hip::launch_rb_fused_2d(sl.buf[cur], sl.buf[cur ^ 1], sl.maskw, sl.rows, c->pitch, fused_rpt, c->math,
+                                                                   parity, sl.stream)
+                                    : epic_hip::launch_jacobi_fused_2d(sl.buf[cur], sl.buf[cur ^ 1], sl.maskw, sl.rows, c->pitch, fused_rpt,
+                                                                       c->math, sl.stream, parity, c->maskf(sl));
+                        cur ^= 1;
+                        i += 2;
+                        continue;
+                    }
+                    if (check) e = hipMemsetAsync(sl.d_delta, 0, sizeof(unsigned), sl.stream);
+                    epic_hip::Activity act = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+                    if (tracked) act = sl.trk.next(slab_tiles(c, sl, rpt_track), rpt_track, sl.stream, nullptr);
+                    if (e == hipSuccess) {
+                        float *src = sl.buf[cur], *dst = c->redblack ? src : sl.buf[cur ^ 1];
+                        const int parity = c->redblack ? (int)((it0 + i + (unsigned)sl.top()) & 1u) : -1;
+                        unsigned *d = check ? sl.d_delta : nullptr;
+                        // ghost units (still exact deep enough) are swept like any other; they do not count for max |du|
+                        e = c->n == 2 ? epic_hip::launch_sweep_2d(src, dst, sl.maskw, sl.rows, c->pitch, 0, sl.rows, auto_rows_per_task(c), c->math,
+                                                                  parity, d, sl.stream, &act, sl.first(), sl.last() + 1)
+                                      : epic_hip::launch_sweep_3d(src, dst, sl.maskw, sl.rows, c->m[1], c->pitch, 0, sl.rows, c->math, parity, d,
+                                                                  sl.stream, &act, sl.first(), sl.last() + 1);
+                    }
+                    if (e == hipSuccess && act.list_out) sl.trk.advance();
+                    if (!c->redblack) cur ^= 1;   // (a red-black half-sweep is in place; the fused passes above are in -> out either way)
+                    i++;
+                }
+                return e;
+            });
+            if (e != hipSuccess) return e;
+            // host-side bookkeeping of the stretch (the same walk as the threads made)
+            for (unsigned i = 0; i < n_calm;) {
+                const bool check = chk && i == 0;
+                if (fuse && !check && n_calm - i >= 2) { c->cur ^= 1; c->since += 2; c->work_full += tracked ? 0.0 : 2.0; i += 2; continue; }
+                if (!c->redblack) c->cur ^= 1;
+                c->since++;
+                if (!tracked) c->work_full += 1.0;
+                i++;
+            }
+            // (a fused pair never starts with since == G - 2: it would leave the last ghost unit stale before the exchange)
+            done += n_calm;
+            if (done >= count) break;
+        }
+        // the iteration that ends with an exchange
+        const unsigned it = first + done;
+        const bool check = check_first && done == 0;
+        const int cur = c->cur;
+        // 1. sweeps.  Untracked: the outermost G owned units of each interior side first, on the second stream, so that they can
+        //    travel while the interior is swept (the ghost units are not swept: the exchange replaces them).  Tracked: one
+        //    list-driven launch of the whole slab (a launch with work lists covers the whole domain), the copies behind it.
+        hipError_t e = for_each_slab(c, [&, it, check, cur](int k) -> hipError_t {
+            Ctx::Slab &sl = c->slabs[k];
+            hipError_t e = hipSuccess;
+            auto fail = [&](hipError_t x) { if (e == hipSuccess && x != hipSuccess) e = x; return x != hipSuccess; };
+            unsigned *d = check ? sl.d_delta : nullptr;
+            if (check && fail(hipMemsetAsync(sl.d_delta, 0, sizeof(unsigned), sl.stream))) return e;
+            (void)cur;
+            if (tracked) {
+                epic_hip::Activity act = sl.trk.next(slab_tiles(c, sl, rpt_track), rpt_track, sl.stream, nullptr);
+                if (fail(slab_launch(c, sl, 0, sl.rows, d, sl.first(), sl.last() + 1, it, sl.stream, &act))) return e;
+                if (act.list_out) sl.trk.advance();
+                if (fail(hipEventRecord(sl.ev_band, sl.stream))) return e;
                 return e;
             }
-        } else {
-            // the outermost G owned rows of each interior side first, on the second stream; the ghost rows are not swept,
-            // the exchange replaces them
             const int top_hi = sl.g_top ? sl.first() + G : sl.first();
             const int bot_lo = sl.g_bot ? sl.last() + 1 - G : sl.last() + 1;
             if (fail(hipEventRecord(sl.ev_prev, sl.stream)) || fail(hipStreamWaitEvent(sl.comm, sl.ev_prev, 0))) return e;
-            if (sl.g_top && fail(rows(sl.first(), top_hi, d, sl.comm))) return e;
-            if (sl.g_bot && fail(rows(bot_lo, sl.last() + 1, d, sl.comm))) return e;
+            if (sl.g_top && fail(slab_launch(c, sl, sl.first(), top_hi, d, -1, -1, it, sl.comm, nullptr))) return e;
+            if (sl.g_bot && fail(slab_launch(c, sl, bot_lo, sl.last() + 1, d, -1, -1, it, sl.comm, nullptr))) return e;
             if (fail(hipEventRecord(sl.ev_band, sl.comm))) return e;
-            if (fail(rows(top_hi, bot_lo, d, sl.stream))) return e;
-        }
-    }
-    if (exchange) {
-        for (size_t k = 0; k + 1 < c->slabs.size(); k++) {
-            Ctx::Slab &a = c->slabs[k], &b = c->slabs[k + 1];
-            float *da = c->redblack ? a.buf[c->cur] : a.buf[c->cur ^ 1], *db = c->redblack ? b.buf[c->cur] : b.buf[c->cur ^ 1];
-            // a's last G owned rows -> b's top ghost rows (on b's second stream, after a's bands and b's own)
-            if (fail(hipSetDevice(b.dev)) || fail(hipStreamWaitEvent(b.comm, a.ev_band, 0)) ||
-                fail(multi_copy_rows(c, b, db, 0, a, da, a.last() + 1 - G, G, b.comm)))
-                return e;
-            // b's first G owned rows -> a's bottom ghost rows
-            if (fail(hipSetDevice(a.dev)) || fail(hipStreamWaitEvent(a.comm, b.ev_band, 0)) ||
-                fail(multi_copy_rows(c, a, da, a.rows - G, b, db, b.first(), G, a.comm)))
-                return e;
-        }
-        for (auto &sl : c->slabs)
-            if (fail(hipSetDevice(sl.dev)) || fail(hipEventRecord(sl.ev_comm, sl.comm))) return e;
-        // the next iteration of a slab starts when its own bands and incoming copies are done AND the neighbours have read
-        // the rows they copy out of it
-        for (size_t k = 0; k < c->slabs.size(); k++) {
+            if (fail(slab_launch(c, sl, top_hi, bot_lo, d, -1, -1, it, sl.stream, nullptr))) return e;
+            return e;
+        });
+        if (e != hipSuccess) return e;
+        // 2. every slab pulls its two halos (the neighbours' band events exist now) and records "my second stream is done"
+        e = for_each_slab(c, [&, cur](int k) -> hipError_t {
             Ctx::Slab &sl = c->slabs[k];
-            if (fail(hipSetDevice(sl.dev)) || fail(hipStreamWaitEvent(sl.stream, sl.ev_comm, 0))) return e;
-            if (k > 0 && fail(hipStreamWaitEvent(sl.stream, c->slabs[k - 1].ev_comm, 0))) return e;
-            if (k + 1 < c->slabs.size() && fail(hipStreamWaitEvent(sl.stream, c->slabs[k + 1].ev_comm, 0))) return e;
-        }
+            const int out = c->redblack ? cur : cur ^ 1;
+            // (with work lists the whole slab was swept in one launch, ghost units included: the copies land behind it)
+            hipError_t e = tracked ? hipStreamWaitEvent(sl.comm, sl.ev_band, 0) : hipSuccess;
+            if (e == hipSuccess && k > 0) {   // the upper neighbour's last G owned units -> my top ghost units
+                Ctx::Slab &up = c->slabs[k - 1];
+                e = multi_copy_units(c, sl, sl.buf[out], 0, up, up.buf[out], up.last() + 1 - G, G, up.ev_band, sl.peer_up, sl.bounce[0]);
+            }
+            if (e == hipSuccess && k + 1 < (int)c->slabs.size()) {   // the lower neighbour's first G owned units -> my bottom ghost units
+                Ctx::Slab &dn = c->slabs[k + 1];
+                e = multi_copy_units(c, sl, sl.buf[out], sl.rows - G, dn, dn.buf[out], dn.first(), G, dn.ev_band, dn.peer_up, dn.bounce[1]);
+            }
+            if (e == hipSuccess) e = hipSetDevice(sl.dev);
+            if (e == hipSuccess) e = hipEventRecord(sl.ev_comm, sl.comm);
+            return e;
+        });
+        if (e != hipSuccess) return e;
+        // 3. a slab's next iteration starts when its own bands and incoming copies are done AND the neighbours have read the
+        //    units they copy out of it; with work lists, the tiles that hold or read the rewritten ghost units are woken
+        e = for_each_slab(c, [&](int k) -> hipError_t {
+            Ctx::Slab &sl = c->slabs[k];
+            hipError_t e = hipStreamWaitEvent(sl.stream, sl.ev_comm, 0);
+            if (e == hipSuccess && k > 0) e = hipStreamWaitEvent(sl.stream, c->slabs[k - 1].ev_comm, 0);
+            if (e == hipSuccess && k + 1 < (int)c->slabs.size()) e = hipStreamWaitEvent(sl.stream, c->slabs[k + 1].ev_comm, 0);
+            if (e == hipSuccess && tracked && sl.trk.tiles && sl.trk.force == 0) {
+                const epic_hip::Activity next = sl.trk.upcoming();
+                const int per_unit = c->n == 2 ? 0 : (int)(sl.trk.tiles / (size_t)sl.rows);   // 3-D: tiles per plane
+                auto wake_units = [&](int lo, int hi) {   // tiles that hold units [lo, hi)
+                    lo = std::max(lo, 0);
+                    hi = std::min(hi, sl.rows);
+                    if (hi <= lo) return hipSuccess;
+                    const int nstrips = c->pitch / 256;
+                    const int t_lo = c->n == 2 ? (lo / sl.trk.rpt) * nstrips : lo * per_unit;
+                    const int t_hi = c->n == 2 ? ((hi - 1) / sl.trk.rpt + 1) * nstrips : hi * per_unit;
+                    return epic_hip::launch_wake_tile_range(&next, sl.trk.tiles, t_lo, t_hi, sl.stream);
+                };
+                if (sl.g_top) e = wake_units(0, G + 1);
+                if (e == hipSuccess && sl.g_bot) e = wake_units(sl.rows - G - 1, sl.rows);
+            }
+            return e;
+        });
+        if (e != hipSuccess) return e;
+        if (!c->redblack) c->cur ^= 1;
         c->since = 0;
-    } else {
-        c->since++;
+        if (!tracked) c->work_full += 1.0;
+        done++;
     }
-    if (!c->redblack) c->cur ^= 1;
-    c->work_full += 1.0;
     return hipSuccess;
 }
 
-// Two plain Jacobi iterations of every slab as one fused pass (tol math; jacobi_fused2d_kernel), no exchange: the caller
-// has checked next_two_fuse().  Ghost rows are swept like owned rows, two more of them are stale afterwards.
-hipError_t multi_sweep_pair(Ctx *c)
-{
-    DeviceGuard g;
-    const int rpt = jacobi_fused_rows_per_task(c);
-    for (auto &sl : c->slabs) {
-        hipError_t e = hipSetDevice(sl.dev);
-        if (e == hipSuccess)
-            e = epic_hip::launch_jacobi_fused_2d(sl.buf[c->cur], sl.buf[c->cur ^ 1], sl.maskw, sl.rows, c->pitch, rpt, c->math, sl.stream, -1,
-                                                 c->maskf(sl));
-        if (e != hipSuccess) return e;
-    }
-    c->since += 2;
-    c->cur ^= 1;
-    c->work_full += 2.0;
-    return hipSuccess;
-}
+hipError_t multi_sweep(Ctx *c, bool check, unsigned iteration) { return multi_run(c, 1, iteration, check); }
 
 int multi_read_delta(Harmonic *h, Ctx *c, const char *fn)
 {
@@ -941,9 +1238,9 @@ int multi_get_values(Harmonic *h, Ctx *c, const char *fn)
     multi_sync(c);
     for (auto &sl : c->slabs) {
         if (hipSetDevice(sl.dev) != hipSuccess ||
-            hipMemcpy2D(h->u + (size_t)sl.lo * c->cols, (size_t)c->cols * sizeof(float),
-                        sl.buf[c->cur] + (size_t)sl.first() * c->pitch, (size_t)c->pitch * sizeof(float),
-                        (size_t)c->cols * sizeof(float), (size_t)(sl.hi - sl.lo), hipMemcpyDeviceToHost) != hipSuccess) {
+            hipMemcpy2D(h->u + (size_t)sl.lo * unit_rows(c) * c->cols, (size_t)c->cols * sizeof(float),
+                        sl.buf[c->cur] + (size_t)sl.first() * unit_floats(c), (size_t)c->pitch * sizeof(float),
+                        (size_t)c->cols * sizeof(float), (size_t)(sl.hi - sl.lo) * unit_rows(c), hipMemcpyDeviceToHost) != hipSuccess) {
             report(fn, "Failed to copy memory from device to host for the potential values.");
             return EPIC_ERROR_MEMCPY_TO_HOST;
         }
@@ -960,6 +1257,7 @@ int multi_set_cells(Ctx *c, unsigned k, const unsigned *v, const unsigned *types
     int rc = EPIC_SUCCESS;
     for (auto &sl : c->slabs) {
         unsigned *d_v = nullptr, *d_types = nullptr;
+        sl.trk.force = 2;
         if (hipSetDevice(sl.dev) != hipSuccess || hipMalloc((void **)&d_v, 2 * (size_t)k * sizeof(unsigned)) != hipSuccess ||
             hipMalloc((void **)&d_types, (size_t)k * sizeof(unsigned)) != hipSuccess) {
             (void)hipGetLastError();
@@ -981,6 +1279,36 @@ int multi_set_cells(Ctx *c, unsigned k, const unsigned *v, const unsigned *types
         if (rc != EPIC_SUCCESS) break;
     }
     return rc;
+}
+
+void force_all(Ctx *c)
+{
+    c->trk.force = 2;
+    for (auto &sl : c->slabs) sl.trk.force = 2;
+}
+
+// tiles due in the next iteration / tiles in all, summed over the domains (false: no lists in use)
+bool due_tiles(Ctx *c, unsigned long long *due, unsigned long long *tiles)
+{
+    *due = *tiles = 0;
+    auto one = [&](const Track &t) {
+        if (t.tiles == 0) return false;
+        uint32_t counts[Ctx::kL * Ctx::kCS];
+        if (hipMemcpy(counts, t.counter(t.phase % 3), sizeof(counts), hipMemcpyDeviceToHost) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        unsigned long long d = 0;
+        for (size_t i = 0; i < Ctx::kL; i++) d += counts[i * Ctx::kCS];
+        *due += t.force > 0 ? t.tiles : d;
+        *tiles += t.tiles;
+        return true;
+    };
+    if (!c->multi()) return one(c->trk);
+    DeviceGuard g;
+    for (auto &sl : c->slabs)
+        if (hipSetDevice(sl.dev) != hipSuccess || hipStreamSynchronize(sl.stream) != hipSuccess || !one(sl.trk)) return false;
+    return true;
 }
 
 }  // namespace
@@ -1070,7 +1398,7 @@ int harmonic_initialize_potential_values_gpu(Harmonic *harmonic)  // harmonic_mo
         for (auto &sl : c->slabs)
             for (int b = 0; b < 2; b++)
                 if (hipSetDevice(sl.dev) != hipSuccess ||
-                    hipMalloc((void **)&sl.buf[b], (size_t)sl.rows * c->pitch * sizeof(float)) != hipSuccess) {
+                    hipMalloc((void **)&sl.buf[b], (size_t)sl.rows * unit_floats(c) * sizeof(float)) != hipSuccess) {
                     (void)hipGetLastError();
                     report(fn, "Failed to allocate device-side memory for the potential values.");
                     multi_free_u(c);
@@ -1145,7 +1473,7 @@ int harmonic_initialize_locked_gpu(Harmonic *harmonic)  // harmonic_model_gpu.cu
             DeviceGuard g;
             for (auto &sl : c->slabs)
                 if (hipSetDevice(sl.dev) != hipSuccess ||
-                    hipMalloc((void **)&sl.maskw, sizeof(uint32_t) * Ctx::mask_words_both_2d(sl.rows, c->pitch)) != hipSuccess) {
+                    hipMalloc((void **)&sl.maskw, sizeof(uint32_t) * slab_mask_words(c, sl)) != hipSuccess) {
                     (void)hipGetLastError();
                     report(fn, "Failed to allocate device-side memory for the locked cells.");
                     multi_free_mask(c);
@@ -1333,20 +1661,14 @@ int harmonic_get_potential_values_gpu(Harmonic *harmonic)  // harmonic_gpu.cu:41
 // harmonic_execute_gpu: should the plain batch that follows a check run without the work lists?  (see the call site)
 static bool bypass_lists_for_batch(Ctx *c)
 {
-    // (c->force > 0 is fine: a forced iteration runs every tile but still lists the tiles it changed)
-    if (!c->track || c->track_mode != 2 || c->act_tiles == 0 || c->multi()) return false;
-    if (c->n != 2) return false;
+    // (a forced iteration runs every tile but still lists the tiles it changed)
+    if (!c->track || c->track_mode != 2 || c->n != 2) return false;
     const char *e = getenv("EPIC_HIP_TRACK_SWITCH");   // share of due tiles above which lists are bypassed (tests: 0 / 2)
     const double limit = e ? atof(e) : 0.8;
-    // the counter set the next launch would consume was filled by the check iteration that has just been read back
-    uint32_t counts[Ctx::kL * Ctx::kCS];
-    if (hipMemcpy(counts, c->wake_counter(c->phase % 3), sizeof(counts), hipMemcpyDeviceToHost) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
-    unsigned long long due = 0;
-    for (size_t i = 0; i < Ctx::kL; i++) due += counts[i * Ctx::kCS];
-    return (double)due > limit * (double)c->act_tiles;
+    // the counter sets the next launches would consume were filled by the check iteration that has just been read back
+    unsigned long long due = 0, tiles = 0;
+    if (!due_tiles(c, &due, &tiles) || tiles == 0) return false;
+    return (double)due > limit * (double)tiles;
 }
 
 int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmonic_gpu.cu:226-304
@@ -1402,7 +1724,7 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
         Ctx *c;
         bool done = false;
         float last_check = -1.0f;  // no check yet
-        ~Handover() { if (done) { c->redblack = false; c->force = 2; } }
+        ~Handover() { if (done) { c->redblack = false; force_all(c); } }
     } handover{c};   // (the context outlives this function: it still holds the field and the mask)
     const unsigned stagger = harmonic->numIterationsToStaggerCheck;
     result = EPIC_SUCCESS;
@@ -1416,7 +1738,7 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
             if (!c->redblack && result == EPIC_SUCCESS && harmonic->delta < 1.0f && handover.last_check >= 0.0f &&
                 harmonic->delta >= handover.last_check) {
                 c->redblack = true;
-                c->force = 2;
+                force_all(c);
                 handover.done = true;
             }
             handover.last_check = harmonic->delta;
@@ -1435,7 +1757,7 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
             const bool bypass = bypass_lists_for_batch(c);
             if (bypass) c->track = false;
             const hipError_t be = enqueue_plain_batch(c, batch, harmonic->currentIteration);
-            if (bypass) { c->track = true; c->force = 2; }
+            if (bypass) { c->track = true; force_all(c); }
             if (be != hipSuccess) {
                 report(fn, "Failed to perform the Jacobi update step.");
                 return EPIC_ERROR_KERNEL_EXECUTION;
@@ -1500,7 +1822,7 @@ int harmonic_utilities_set_cells_2d_gpu(Harmonic *harmonic, unsigned int numThre
     if (c->multi()) return multi_set_cells(c, k, v, types, fn);
     unsigned *d_v = nullptr, *d_types = nullptr;
     int rc = EPIC_SUCCESS;
-    c->force = 2;  // cells and mask bits change under the work lists
+    force_all(c);  // cells and mask bits change under the work lists
     if (hipMalloc((void **)&d_v, 2 * (size_t)k * sizeof(unsigned)) != hipSuccess ||
         hipMalloc((void **)&d_types, (size_t)k * sizeof(unsigned)) != hipSuccess) {
         (void)hipGetLastError();
@@ -1651,8 +1973,8 @@ int epic_hip_iterations_per_pass(Harmonic *harmonic)
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
     if (!c) return 0;
     if (fuses_jacobi(c) || fuses_rb_tol(c)) return 2;
-    static const bool no_fuse = getenv("EPIC_HIP_NO_FUSE") != nullptr;
-    const bool rb_fused = c->redblack && c->n == 2 && !no_fuse && !c->track && !c->multi() && c->math != 4 &&
+    const bool no_fuse = getenv("EPIC_HIP_NO_FUSE") != nullptr;   // (read per call: the tests switch it)
+    const bool rb_fused = c->redblack && c->n == 2 && !no_fuse && !c->track && c->math != 4 &&
                           (long long)c->rows * c->pitch >= (1ll << 22);
     return rb_fused ? 2 : 1;
 }
@@ -1662,7 +1984,7 @@ int epic_hip_set_rows_per_task(Harmonic *harmonic, unsigned int rows_per_task)
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
     if (!c || rows_per_task > 65536) return EPIC_ERROR_INVALID_DATA;
     c->rows_per_task = (int)rows_per_task;
-    c->force = 2;
+    force_all(c);
     return EPIC_SUCCESS;
 }
 
@@ -1671,7 +1993,7 @@ int epic_hip_set_math_mode(Harmonic *harmonic, int mode)
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
     if (!c || mode < 0 || mode > 4 || mode == 3) return EPIC_ERROR_INVALID_DATA;  // 2 = traffic-only diagnostic (2-D), 4 = tol; 3 was round 1's df32
     c->math = mode;
-    c->force = 2;
+    force_all(c);
     return EPIC_SUCCESS;
 }
 
@@ -1680,7 +2002,7 @@ int epic_hip_set_scheme(Harmonic *harmonic, int scheme)
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
     if (!c || (scheme != 0 && scheme != 1)) return EPIC_ERROR_INVALID_DATA;
     c->redblack = scheme == 1;
-    c->force = 2;
+    force_all(c);
     return EPIC_SUCCESS;
 }
 
@@ -1690,7 +2012,7 @@ int epic_hip_set_activity_tracking(Harmonic *harmonic, int on)
     if (!c || on < 0 || on > 2) return EPIC_ERROR_INVALID_DATA;
     c->track_mode = on;
     resolve_tracking(c);
-    c->force = 2;
+    force_all(c);
     return EPIC_SUCCESS;
 }
 
@@ -1791,18 +2113,15 @@ int epic_hip_activity_stats2(Harmonic *harmonic, unsigned long long *active_tile
     if (!c || !active_tiles || !tiles) return EPIC_ERROR_INVALID_DATA;
     *active_tiles = *tiles = 0;
     if (due_tiles) *due_tiles = 0;
-    if (!c->track || c->act_tiles == 0) return EPIC_SUCCESS;
-    // the counter set the next launch will consume was filled by the latest one: the tiles it woke
-    std::vector<uint32_t> counts(Ctx::kL * Ctx::kCS);
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return EPIC_ERROR_DEVICE_SYNCHRONIZE;
-    if (hipMemcpy(counts.data(), c->wake_counter(c->phase % 3), counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
-        return EPIC_ERROR_MEMCPY_TO_HOST;
-    unsigned long long pair[2] = {0, 0};
-    for (size_t i = 0; i < Ctx::kL; i++) pair[0] += counts[i * Ctx::kCS];
-    pair[1] = pair[0];
-    *active_tiles = c->force > 0 ? c->act_tiles : pair[1];
-    if (due_tiles) *due_tiles = c->force > 0 ? c->act_tiles : pair[0];
-    *tiles = c->act_tiles;
+    if (!c->track) return EPIC_SUCCESS;
+    // the counter sets the next launches will consume were filled by the latest ones: the tiles they woke (summed over the
+    // slabs in multi-device mode; a forced iteration runs every tile)
+    if (!c->multi() && hipStreamSynchronize(c->stream) != hipSuccess) return EPIC_ERROR_DEVICE_SYNCHRONIZE;
+    unsigned long long due = 0, all = 0;
+    if (!::due_tiles(c, &due, &all)) return EPIC_SUCCESS;
+    *active_tiles = due;
+    if (due_tiles) *due_tiles = due;
+    *tiles = all;
     return EPIC_SUCCESS;
 }
 
@@ -1834,8 +2153,8 @@ int epic_hip_get_layout(Harmonic *harmonic, unsigned int *pitch, size_t *u_bytes
     if (c->multi()) {  // per-device state, ghost rows included, summed
         size_t ub = 0, mb = 0;
         for (const auto &sl : c->slabs) {
-            ub += (size_t)sl.rows * c->pitch * sizeof(float);
-            mb += sizeof(uint32_t) * Ctx::mask_words_both_2d(sl.rows, c->pitch);
+            ub += (size_t)sl.rows * unit_floats(c) * sizeof(float);
+            mb += sizeof(uint32_t) * slab_mask_words(c, sl);
         }
         if (u_bytes) *u_bytes = ub;
         if (mask_bytes) *mask_bytes = mb;

@@ -48,9 +48,13 @@ inline int sweep_2d_list_blocks(size_t tiles, int resident_blocks)
 // blocks of 256 threads of `kernel` the current device holds at a time (cached per kernel)
 int resident_blocks_of(const void *kernel);
 // parity < 0: Jacobi (in != out); parity 0 / 1: red-black half-sweep of that colour, in place (in == out).
+// check_begin / check_end: with delta_bits, only these rows count for max |du| (default: the rows swept) -- a slab sweeps its
+// ghost rows in the same launch but must not let them into the convergence test.
 hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int row_begin,
                            int row_end, int rows_per_task, int math, int parity, unsigned *delta_bits,
-                           hipStream_t stream, const Activity *act = nullptr);
+                           hipStream_t stream, const Activity *act = nullptr, int check_begin = -1, int check_end = -1);
+// Wake tiles [t_lo, t_hi) for the launch that will consume the lists given as next_as_out->list_out / count_out / queued_out.
+hipError_t launch_wake_tile_range(const Activity *next_as_out, size_t tiles, int t_lo, int t_hi, hipStream_t stream);
 // two red-black iterations fused into one in -> out pass (first colour = parity); see kernels_2d.hip
 hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
                               int math, int parity, hipStream_t stream);
@@ -135,7 +139,7 @@ __host__ __device__ inline unsigned mask_bit_2d(unsigned c) { return (c >> 2) & 
 // ---- 3-D (kernels_3d.hip) -------------------------------------------------------------------
 hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, int m0, int m1, int pitch,
                            int plane_begin, int plane_end, int math, int parity, unsigned *delta_bits,
-                           hipStream_t stream, const Activity *act = nullptr);
+                           hipStream_t stream, const Activity *act = nullptr, int check_begin = -1, int check_end = -1);
 // tiles of the 3-D sweep: one per (x0-plane, 32-row x1-chunk, 256-column x2-strip)
 inline size_t sweep_3d_tiles(int m0, int m1, int pitch)
 {

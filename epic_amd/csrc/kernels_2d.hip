@@ -77,6 +77,7 @@ struct Sweep2dArgs {
     WakeArgs wake;
     int nchunks;
     int nblocks;            // logical blocks (ceil(ntasks / 4)): a launch may hold fewer workgroups, which then walk them (tol math)
+    int check_lo, check_hi; // CHECK: only rows [check_lo, check_hi) count for max |du| (a slab's ghost rows are swept but do not)
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (b % 8 labels the XCD group).  Give each group a
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (SweepOcc<CHECK, MATH, RB, 
             o.z = sel(h.m2, c.z, o.z);
             o.w = sel(h.m3, c.w, o.w);
         }
-        if (CHECK) {
+        if (CHECK && r >= a.check_lo && r < a.check_hi) {  // scalar condition
             dmax = max2(dmax, fabsf(c.x - o.x));
             dmax = max2(dmax, fabsf(c.y - o.y));
             dmax = max2(dmax, fabsf(c.z - o.z));
@@ -927,7 +928,7 @@ void launch_sweep_2d_track(int math, int nblocks, hipStream_t stream, const Swee
 // parity < 0: Jacobi sweep in -> out.  parity = 0 / 1: red-black half-sweep in place (in == out required).
 hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int row_begin,
                            int row_end, int rows_per_task, int math, int parity, unsigned *delta_bits,
-                           hipStream_t stream, const Activity *act)
+                           hipStream_t stream, const Activity *act, int check_begin, int check_end)
 {
     if (row_end <= row_begin) return hipSuccess;
     if (pitch <= 0 || (pitch % 256) != 0 || rows <= 0 || row_begin < 0 || row_end > rows || rows_per_task <= 0)
@@ -959,6 +960,8 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, i
     a.wake = wake_args(whole ? act : nullptr, (size_t)a.ntasks);
     int nblocks = (a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock;
     a.nblocks = nblocks;
+    a.check_lo = check_begin < 0 ? row_begin : check_begin;
+    a.check_hi = check_begin < 0 ? row_end : check_end;
     if (parity < 0) {
         if (delta_bits) launch_sweep_2d_track<true, false>(math, nblocks, stream, a);
         else launch_sweep_2d_track<false, false>(math, nblocks, stream, a);
@@ -984,6 +987,7 @@ hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw
     a.out = out;
     a.maskw = maskw;
     a.maskf = nullptr;
+    a.check_lo = a.check_hi = 0;
     a.delta_bits = nullptr;
     a.rows = rows;
     a.pitch = pitch;
@@ -1001,6 +1005,23 @@ hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw
     if (math == kMathFast) hipLaunchKernelGGL((rb_fused2d_kernel<kMathFast>), grid, block, 0, stream, a);
     else if (math == kMathTraffic) hipLaunchKernelGGL((rb_fused2d_kernel<kMathTraffic>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((rb_fused2d_kernel<kMathPrecise>), grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+
+// wake the tiles [t_lo, t_hi) for the launch that will consume `next` (its list_in / count_in / queued_in, given here as the
+// *_out fields): a halo exchange has rewritten rows they hold or read
+__global__ void wake_tile_range_kernel(WakeArgs w, int t_lo, int t_hi)
+{
+    const int t = t_lo + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    wake_push(w, t, t < t_hi);
+}
+
+hipError_t launch_wake_tile_range(const Activity *next_as_out, size_t tiles, int t_lo, int t_hi, hipStream_t stream)
+{
+    if (!next_as_out || !next_as_out->list_out || t_hi <= t_lo) return hipSuccess;
+    WakeArgs w = wake_args(next_as_out, tiles);
+    w.list_in = nullptr;
+    hipLaunchKernelGGL(wake_tile_range_kernel, dim3((unsigned)((t_hi - t_lo + 255) / 256)), dim3(256), 0, stream, w, t_lo, t_hi);
     return hipGetLastError();
 }
 
@@ -1026,6 +1047,7 @@ hipError_t launch_jacobi_fused_2d(const float *in, float *out, const uint32_t *m
     a.out = out;
     a.maskw = maskw;
     a.maskf = nullptr;
+    a.check_lo = a.check_hi = 0;
     a.delta_bits = nullptr;
     a.rows = rows;
     a.pitch = pitch;

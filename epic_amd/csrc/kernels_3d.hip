@@ -41,6 +41,7 @@ struct Sweep3dArgs {
     int plane_begin, plane_end;
     int nstrips, nchunks, nplane_groups;
     int nblocks;  // logical blocks: nstrips * nchunks * nplane_groups (a tol launch holds fewer workgroups, which walk them)
+    int check_lo, check_hi;  // CHECK: only planes [check_lo, check_hi) count for max |du| (a slab's ghost planes do not)
     int parity;  // red-black scheme only: currentIteration & 1
     WakeArgs wake;  // TRACK kernels, whole-grid launches only
 };
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB
             o.z = sel(h.m2, c.z, cell_update_3d<MATH>(pa.z, pb.z, up.z, dn.z, c.y, c.w, lds));
             o.w = sel(h.m3, c.w, cell_update_3d<MATH>(pa.w, pb.w, up.w, dn.w, c.z, rt, lds));
         }
-        if (CHECK) {
+        if (CHECK && x0 >= a.check_lo && x0 < a.check_hi) {  // scalar condition
             dmax = max2(dmax, fabsf(c.x - o.x));
             dmax = max2(dmax, fabsf(c.y - o.y));
             dmax = max2(dmax, fabsf(c.z - o.z));
@@ -347,7 +348,7 @@ void launch_sweep_3d_math(int math, dim3 grid, dim3 block, hipStream_t stream, c
 // parity < 0: Jacobi (in != out); parity 0 / 1: red-black half-sweep in place (in == out).
 hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, int m0, int m1, int pitch,
                            int plane_begin, int plane_end, int math, int parity, unsigned *delta_bits,
-                           hipStream_t stream, const Activity *act)
+                           hipStream_t stream, const Activity *act, int check_begin, int check_end)
 {
     if (plane_end <= plane_begin) return hipSuccess;
     if (pitch <= 0 || (pitch % 256) != 0 || m0 <= 0 || m1 <= 0 || plane_begin < 0 || plane_end > m0)
@@ -371,6 +372,8 @@ hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, i
     const long long nblocks = (long long)a.nstrips * a.nchunks * a.nplane_groups;
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
     a.nblocks = (int)nblocks;
+    a.check_lo = check_begin < 0 ? plane_begin : check_begin;
+    a.check_hi = check_begin < 0 ? plane_end : check_end;
     a.parity = parity < 0 ? 0 : (parity & 1);
     const bool whole = plane_begin == 0 && plane_end == m0;
     const size_t tiles = sweep_3d_tiles(m0, m1, pitch);

@@ -142,13 +142,16 @@ def grid_512_cubed():
     return m, u0, locked
 
 
-@pytest.mark.parametrize("math,scheme,track", [(eh.MATH_TOL, eh.SCHEME_JACOBI, 0), (eh.MATH_TOL, eh.SCHEME_JACOBI, 1),
-                                               (eh.MATH_TOL, eh.SCHEME_REDBLACK, 0), (eh.MATH_PRECISE, eh.SCHEME_JACOBI, 0),
-                                               (eh.MATH_PRECISE, eh.SCHEME_REDBLACK, 0)])
-def test_512_cubed_whole_field_equals_the_checker(grid_512_cubed, math, scheme, track):
+@pytest.mark.parametrize("math,scheme,track,devices", [
+    (eh.MATH_TOL, eh.SCHEME_JACOBI, 0, None), (eh.MATH_TOL, eh.SCHEME_JACOBI, 1, None), (eh.MATH_TOL, eh.SCHEME_REDBLACK, 0, None),
+    (eh.MATH_PRECISE, eh.SCHEME_JACOBI, 0, None), (eh.MATH_PRECISE, eh.SCHEME_REDBLACK, 0, None),
+    (eh.MATH_TOL, eh.SCHEME_JACOBI, 0, "0,0,0,0"),          # four slabs of 128 planes, two ghost planes a side
+    (eh.MATH_PRECISE, eh.SCHEME_REDBLACK, 0, "0,0,0,0"),
+])
+def test_512_cubed_whole_field_equals_the_checker(grid_512_cubed, math, scheme, track, devices):
     m, u0, locked = grid_512_cubed
     K = 4
-    got, gdelta = run_gpu(m, u0, locked, K, math, scheme, track)
+    got, gdelta = run_gpu(m, u0, locked, K, math, scheme, track, devices)
     want, wdelta = run_checker(m, u0, locked, K, math, scheme)
     assert gdelta == wdelta, (gdelta, wdelta)
     if not np.array_equal(got, want):
