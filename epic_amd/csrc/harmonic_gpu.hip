@@ -195,7 +195,7 @@ std::unordered_map<Harmonic *, Ctx *> g_ctx;
 
 void resolve_tracking(Ctx *c);
 void force_all(Ctx *c);    // the next two iterations run every tile (after any change of values, masks, mode or tiling)
-bool due_tiles(Ctx *c, unsigned long long *due, unsigned long long *tiles);
+bool due_tiles(Ctx *c, unsigned long long *due, unsigned long long *tiles, bool forced_runs_all);
 void fold_listed_work(Ctx *c);
 void drop_graphs(Ctx *c);  // captured launch sequences hold the buffer addresses: drop them whenever a buffer goes away
 bool multi_plan(Ctx *c);   // multi-device mode (EPIC_HIP_DEVICES): see "several devices in one process" below
@@ -531,7 +531,7 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
     }
     while (fuse && count - i >= 2) {
         hipError_t e = epic_hip::launch_rb_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch,
-                                                    fused_rows_per_task(c), c->math, (int)((first + i) & 1u), c->stream);
+                                                    fused_rows_per_task(c), c->math, (int)((first + i) & 1u), c->stream, c->maskf());
         if (e != hipSuccess) return e;
         c->cur ^= 1;
         c->work_full += 2.0;
@@ -1084,7 +1084,7 @@ hipError_t multi_run(Ctx *c, unsigned count, unsigned first, bool check_first)
                     if (fuse && !check && n_calm - i >= 2) {   // two more ghost units go stale: n_calm leaves room for them
                         const int parity = c->redblack ? (int)((it0 + i + (unsigned)sl.top()) & 1u) : -1;
                         e = fuse_rb ? epic_hip::launch_rb_fused_2d(sl.buf[cur], sl.buf[cur ^ 1], sl.maskw, sl.rows, c->pitch, fused_rpt, c->math,
-                                                                   parity, sl.stream)
+                                                                   parity, sl.stream, c->maskf(sl))
                                     : epic_hip::launch_jacobi_fused_2d(sl.buf[cur], sl.buf[cur ^ 1], sl.maskw, sl.rows, c->pitch, fused_rpt,
                                                                        c->math, sl.stream, parity, c->maskf(sl));
                         cur ^= 1;
@@ -1287,8 +1287,10 @@ void force_all(Ctx *c)
     for (auto &sl : c->slabs) sl.trk.force = 2;
 }
 
-// tiles due in the next iteration / tiles in all, summed over the domains (false: no lists in use)
-bool due_tiles(Ctx *c, unsigned long long *due, unsigned long long *tiles)
+// tiles listed for the next iteration / tiles in all, summed over the domains (false: no lists in use).  forced_runs_all: a
+// domain whose next iteration is forced counts as all its tiles (what WILL run); otherwise the count is what the latest
+// iteration listed (what its successor NEEDS: a forced iteration still lists the tiles it changed).
+bool due_tiles(Ctx *c, unsigned long long *due, unsigned long long *tiles, bool forced_runs_all)
 {
     *due = *tiles = 0;
     auto one = [&](const Track &t) {
@@ -1300,7 +1302,7 @@ bool due_tiles(Ctx *c, unsigned long long *due, unsigned long long *tiles)
         }
         unsigned long long d = 0;
         for (size_t i = 0; i < Ctx::kL; i++) d += counts[i * Ctx::kCS];
-        *due += t.force > 0 ? t.tiles : d;
+        *due += (forced_runs_all && t.force > 0) ? t.tiles : d;
         *tiles += t.tiles;
         return true;
     };
@@ -1667,7 +1669,7 @@ static bool bypass_lists_for_batch(Ctx *c)
     const double limit = e ? atof(e) : 0.8;
     // the counter sets the next launches would consume were filled by the check iteration that has just been read back
     unsigned long long due = 0, tiles = 0;
-    if (!due_tiles(c, &due, &tiles) || tiles == 0) return false;
+    if (!due_tiles(c, &due, &tiles, false) || tiles == 0) return false;
     return (double)due > limit * (double)tiles;
 }
 
@@ -2118,7 +2120,7 @@ int epic_hip_activity_stats2(Harmonic *harmonic, unsigned long long *active_tile
     // slabs in multi-device mode; a forced iteration runs every tile)
     if (!c->multi() && hipStreamSynchronize(c->stream) != hipSuccess) return EPIC_ERROR_DEVICE_SYNCHRONIZE;
     unsigned long long due = 0, all = 0;
-    if (!::due_tiles(c, &due, &all)) return EPIC_SUCCESS;
+    if (!::due_tiles(c, &due, &all, true)) return EPIC_SUCCESS;
     *active_tiles = due;
     if (due_tiles) *due_tiles = due;
     *tiles = all;

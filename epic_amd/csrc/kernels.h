@@ -57,7 +57,7 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, i
 hipError_t launch_wake_tile_range(const Activity *next_as_out, size_t tiles, int t_lo, int t_hi, hipStream_t stream);
 // two red-black iterations fused into one in -> out pass (first colour = parity); see kernels_2d.hip
 hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
-                              int math, int parity, hipStream_t stream);
+                              int math, int parity, hipStream_t stream, const uint32_t *maskf = nullptr);
 // Two iterations in one pass (tol math only): in = u_k, out = u_{k+2}; in != out.  parity < 0: Jacobi; 0 / 1: the reference's
 // red-black scheme, parity = the first iteration's number & 1 (both colours are swept, the first one first).
 // maskf (may be null): the masks in the fused layout below -- saves the pass a funnel shift of two mask words per row.

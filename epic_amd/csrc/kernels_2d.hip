@@ -446,7 +446,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (SweepOcc<CHECK, MATH, RB, 
 // (and, with the precise math, to two iterations of the reference CPU solver).
 constexpr int kFusedOut = 248;  // owned columns per wave
 
-template <int MATH>
+template <int MATH, bool FMASK>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Sweep2dArgs a)
 {
     __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];
@@ -489,21 +489,32 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
     // the stored masks are cut at multiples of 64 quads): a funnel shift of two neighbouring words, all scalar.
     // Lanes outside the row (lane 0 of strip 0, lanes past the last column) get arbitrary bits: nothing they compute
     // is stored or reaches an unlocked cell.
+    // In two phases, as in tol_fused_pass below: the words are FETCHED a step before they are CUT (no scalar-memory round trip
+    // in the middle of a step); FMASK: the library's second copy of the masks, already cut for this mapping (kernels.h).
     typedef const __attribute__((address_space(4))) uint64_t cu64;
     struct RowMask { lmask m0, m1, m2, m3; };
+    struct RowMaskRaw { lmask lo0, lo1, lo2, lo3, hi0, hi1, hi2, hi3; };
     const int nstd = a.pitch >> 8;
     const int g0 = strip * (kFusedOut / kColsPerLane) - 1;
     const int sw = max(g0, 0) >> 6, sh = max(g0, 0) & 63, sw1 = min(sw + 1, nstd - 1);
-    auto row_mask = [&](int r) -> RowMask {
+    auto mask_fetch = [&](int r) -> RowMaskRaw {
         r = min(max(r, 0), rlast);
+        if (FMASK) {
+            cu64 *mk = (cu64 *)a.maskf + ((size_t)r * a.nstrips + strip) * 4;
+            return RowMaskRaw{mk[0], mk[1], mk[2], mk[3], 0, 0, 0, 0};
+        }
         cu64 *lo = (cu64 *)a.maskw + ((size_t)r * nstd + sw) * 4, *hi = (cu64 *)a.maskw + ((size_t)r * nstd + sw1) * 4;
-        auto cut = [&](int j) -> lmask {
-            lmask m = lo[j];
-            if (sh) m = (m >> sh) | (hi[j] << (64 - sh));
+        return RowMaskRaw{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    auto mask_cut = [&](const RowMaskRaw &w) -> RowMask {
+        if (FMASK) return RowMask{w.lo0, w.lo1, w.lo2, w.lo3};
+        auto cut = [&](lmask lo, lmask hi) -> lmask {   // (lo >> sh) | (hi << (64 - sh)), branch-free for sh = 0
+            const lmask m = (lo >> sh) | ((hi << 1) << (63 - sh));
             return g0 < 0 ? m << 1 : m;
         };
-        return RowMask{cut(0), cut(1), cut(2), cut(3)};
+        return RowMask{cut(w.lo0, w.hi0), cut(w.lo1, w.hi1), cut(w.lo2, w.hi2), cut(w.lo3, w.hi3)};
     };
+    auto row_mask = [&](int r) -> RowMask { return mask_cut(mask_fetch(r)); };
     // One colour of one row.  second = false: colour A (iteration it), true: colour B (iteration it + 1).
     auto stage = [&](int r, bool second, const float4 &up, const float4 &c, const float4 &dn, const RowMask &k) -> float4 {
         float4 o = c;
@@ -527,17 +538,18 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
     // prologue: colour A of rows r0-1 and r0 (old neighbours only: the other colour has not moved yet)
     const float4 om2 = ld(r0 - 2), om1 = ld(r0 - 1), o0 = ld(r0);
     float4 oa = ld(r0 + 1), ob = ld(r0 + 2), oc;  // old rows r+1, r+2, r+3
-    RowMask kcur = row_mask(r0);
+    RowMask kcur = row_mask(r0), knext = row_mask(r0 + 1);
     float4 ma = stage(r0 - 1, false, om2, om1, o0, row_mask(r0 - 1)), mb = stage(r0, false, om1, o0, oa, kcur), mc;
     // One row r: `mp`, `mq` = colour A of rows r-1, r; `o1`, `o2` = old rows r+1, r+2.  Leaves colour A of row r+1 in
     // `mr` and old row r+3 in `o3`.  The three A rows and the three old rows rotate through fixed registers (the loop
     // is unrolled by three), so nothing is moved.
     auto step = [&](int r, const float4 &mp, const float4 &mq, float4 &mr, const float4 &o1, const float4 &o2, float4 &o3) {
         o3 = ld(r + 3);
-        const RowMask knext = row_mask(r + 1);
+        const RowMaskRaw kraw = mask_fetch(r + 2);             // cut at the end of the step
         mr = stage(r + 1, false, mq, o1, o2, knext);           // colour A of row r+1: up = row r (its B cells still old)
         const float4 x = stage(r, true, mp, mq, mr, kcur);    // colour B of row r from the fresh A cells around it
         kcur = knext;
+        knext = mask_cut(kraw);
         store_row(rout, x.x, x.y, x.z, x.w, store_off, row_off(r));  // non-temporal, as in the plain sweep
     };
     int r = r0;
@@ -974,7 +986,7 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, i
 
 // Two consecutive red-black iterations (first one = `parity`) in one pass, in -> out (in != out).
 hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
-                              int math, int parity, hipStream_t stream)
+                              int math, int parity, hipStream_t stream, const uint32_t *maskf)
 {
     if (pitch <= 0 || (pitch % 256) != 0 || rows <= 0 || rows_per_task <= 0 || in == out) return hipErrorInvalidValue;
     if (math != kMathPrecise && math != kMathFast && math != kMathTraffic) return hipErrorInvalidValue;  // (tol: in-place half-sweeps)
@@ -1002,9 +1014,11 @@ hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw
     a.wake = wake_args(nullptr, 0);
     a.nblocks = (a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3 grid(a.nblocks), block(kWave * kWavesPerBlock);
-    if (math == kMathFast) hipLaunchKernelGGL((rb_fused2d_kernel<kMathFast>), grid, block, 0, stream, a);
-    else if (math == kMathTraffic) hipLaunchKernelGGL((rb_fused2d_kernel<kMathTraffic>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((rb_fused2d_kernel<kMathPrecise>), grid, block, 0, stream, a);
+    a.maskf = maskf;
+    void (*kernel)(Sweep2dArgs) = math == kMathFast      ? (maskf ? rb_fused2d_kernel<kMathFast, true> : rb_fused2d_kernel<kMathFast, false>)
+                                  : math == kMathTraffic ? (maskf ? rb_fused2d_kernel<kMathTraffic, true> : rb_fused2d_kernel<kMathTraffic, false>)
+                                                         : (maskf ? rb_fused2d_kernel<kMathPrecise, true> : rb_fused2d_kernel<kMathPrecise, false>);
+    hipLaunchKernelGGL(kernel, grid, block, 0, stream, a);
     return hipGetLastError();
 }
 
