@@ -118,17 +118,20 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB
     // the lane part of the address in a VGPR that never changes and the row / strip part in an SGPR; the strip-edge
     // values of the centre row and the four lane masks of the row (kernels.h) come through scalar loads.
     const int rlo = max(r0 - 4, 0);
-    auto rsrc = [&](const float *p) { return raw_buffer(p + (size_t)rlo * pitch); };
+    // ONE descriptor for the three planes a wave reads, based at the lowest of them: the plane rides on the scalar offset (the
+    // launcher keeps three planes within the 2 GiB a descriptor spans) -- eight SGPRs less than a descriptor per plane, in a
+    // kernel that spills scalars
+    const int xa = max(x0 - 1, 0), xb = min(x0 + 1, a.m0 - 1);
     const float *pc = a.in + (size_t)x0 * plane;
-    const __amdgpu_buffer_rsrc_t rc = rsrc(pc), ra = rsrc(a.in + (size_t)max(x0 - 1, 0) * plane),
-                                 rb = rsrc(a.in + (size_t)min(x0 + 1, a.m0 - 1) * plane),
-                                 rout = rsrc(a.out + (size_t)x0 * plane);
+    const __amdgpu_buffer_rsrc_t rin = raw_buffer(a.in + (size_t)xa * plane + (size_t)rlo * pitch),
+                                 rout = raw_buffer(a.out + (size_t)x0 * plane + (size_t)rlo * pitch);
+    const unsigned rc = (unsigned)((size_t)(x0 - xa) * plane * sizeof(float)), ra = 0u, rb = (unsigned)((size_t)(xb - xa) * plane * sizeof(float));
     const unsigned lane16 = (unsigned)lane * 16u;
     typedef unsigned vu4 __attribute__((ext_vector_type(4)));
     auto row_off = [&](int r) -> unsigned { return (unsigned)((r - rlo) * a.pitch + col0) * 4u; };  // r already clamped
-    auto ld = [&](const __amdgpu_buffer_rsrc_t &p, int r) -> float4 {
+    auto ld = [&](unsigned plane_off, int r) -> float4 {
         r = min(max(r, 0), rlast);
-        const vu4 q = __builtin_amdgcn_raw_buffer_load_b128(p, lane16, row_off(r), 0);
+        const vu4 q = __builtin_amdgcn_raw_buffer_load_b128(rin, lane16, plane_off + row_off(r), 0);
         return make_float4(u2f(q.x), u2f(q.y), u2f(q.z), u2f(q.w));
     };
     typedef const __attribute__((address_space(4))) float cfloat;
@@ -355,7 +358,8 @@ hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, i
         return hipErrorInvalidValue;
     if ((parity >= 0) != (in == out)) return hipErrorInvalidValue;
     if (math != kMathPrecise && math != kMathFast && math != kMathTol) return hipErrorInvalidValue;  // no df32 / traffic build in 3-D
-    if ((long long)pitch * 4 * (kRowsPerTask + 12) > 0x7fffffffLL) return hipErrorInvalidValue;  // 32-bit row offsets
+    // 32-bit byte offsets from one descriptor: a task's rows of three consecutive planes
+    if ((long long)pitch * 4 * (kRowsPerTask + 12) + 2LL * m1 * pitch * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
     Sweep3dArgs a;
     a.in = in;
     a.out = out;
