@@ -6,9 +6,9 @@
 //
 // Layout: u[x0][x1][x2] with x2 contiguous and padded to `pitch` (multiple of 256 floats).  A wave owns 256 x2-columns
 // (4 per lane, one dwordx4) of one x0-plane and marches along x1, keeping rows x1-1 / x1 / x1+1 of its plane in
-// registers; x2 neighbours are full-wave DPP shifts; the rows of planes x0-1 and x0+1 are loaded per step.  The four
-// waves of a workgroup sweep four consecutive planes of the same (x1-chunk, strip), so those extra rows are the
-// sibling waves' centre rows and are served by the CU's L1 / the XCD's L2 rather than HBM.
+// registers; x2 neighbours are full-wave DPP shifts; the rows of planes x0-1 and x0+1 are loaded per step.  The eight
+// waves of a workgroup sweep eight consecutive planes of the same (x1-chunk, strip), so those extra rows are mostly the
+// sibling waves' centre rows and are served by the CU's L1 / the XCD's L2 rather than HBM (ten planes loaded for eight).
 // Mask: 1 bit per cell as lane masks (kernels.h), fetched with one scalar load per row.
 // Optional activity tracking (wake.h): a tile is one task -- 32 x1-rows x 256 x2-columns of one x0-plane; it reads its
 // own cells, the adjacent column / row of its four in-plane neighbours and the whole tile of the planes x0 - 1 and x0 + 1.
@@ -25,9 +25,9 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kStripCols = 256;
-#ifndef EPIC_SWEEP3D_BLOCK_WAVES
-#define EPIC_SWEEP3D_BLOCK_WAVES 4
-#endif
+#ifndef EPIC_SWEEP3D_BLOCK_WAVES  // build knob (A/B).  8 planes per workgroup load 10 (1.25x) where 4 load 6 (1.5x); at the 4 waves per
+#define EPIC_SWEEP3D_BLOCK_WAVES 8  // SIMD the tol kernels run at, two such workgroups fill a CU: 291 us per 512^3 sweep against 293.5
+#endif                            // (4) and 302 (16), same box (round 2, at 5 waves per SIMD, measured 8 slower than 4)
 constexpr int kWavesPerBlock = EPIC_SWEEP3D_BLOCK_WAVES;  // = consecutive planes per workgroup
 static_assert(kWave * kWavesPerBlock >= kWakeLists, "one thread per work list resets the counters");
 constexpr int kRowsPerTask = 32;
@@ -239,29 +239,32 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB
         store_row(rout, o.x, o.y, o.z, o.w, lane16, row_off(r));  // non-temporal: 389.7 -> 384.4 us per 512^3 sweep
     };
 
-    // Register rings rotated by hand (no moves between a load and its use): the plane's own rows run two rows ahead
-    // over four registers, the rows of the neighbouring planes and the scalar row sides one row ahead over two.
+    // Register rings rotated by hand (no moves between a load and its use): the plane's own rows and the rows of the
+    // neighbouring planes run two rows ahead over four register sets, the scalar row sides one row ahead over two.
     const int nrows = r1 - r0, nfull = nrows & ~3;
     auto split = [&](const float4 &q) { return TOL ? tol_split4(q) : Split4{}; };
     if (nfull > 0) {
         float4 q0 = ld(rc, r0 - 1), q1 = ld(rc, r0), q2 = ld(rc, r0 + 1), q3;
-        float4 aa = ld(ra, r0), ba = ld(rb, r0), ab, bb;
         RowSide sa = side(r0), sb;
         Split4 s0 = split(q0), s1 = split(q1), s2 = {}, s3 = {};
+        // (the neighbouring planes' rows run two rows ahead as well, over four register sets each: 289 -> 285 us at 512^3 against one
+        //  row ahead, same box -- the kernel waits for memory almost half of its time, profiles/r03_sq_counters_3d_tol.txt)
+        float4 pa4[4], pb4[4];
+        pa4[0] = ld(ra, r0); pb4[0] = ld(rb, r0); pa4[1] = ld(ra, r0 + 1); pb4[1] = ld(rb, r0 + 1);
         for (int i = 0; i < nfull; i += 4) {
             const int r = r0 + i;
-            q3 = ld(rc, r + 2); ab = ld(ra, r + 1); bb = ld(rb, r + 1); sb = side(r + 1);
+            q3 = ld(rc, r + 2); pa4[2] = ld(ra, r + 2); pb4[2] = ld(rb, r + 2); sb = side(r + 1);
             s2 = split(q2);
-            row_step(r, q0, q1, q2, aa, ba, sa, s0, s1, s2);
-            q0 = ld(rc, r + 3); aa = ld(ra, r + 2); ba = ld(rb, r + 2); sa = side(r + 2);
+            row_step(r, q0, q1, q2, pa4[0], pb4[0], sa, s0, s1, s2);
+            q0 = ld(rc, r + 3); pa4[3] = ld(ra, r + 3); pb4[3] = ld(rb, r + 3); sa = side(r + 2);
             s3 = split(q3);
-            row_step(r + 1, q1, q2, q3, ab, bb, sb, s1, s2, s3);
-            q1 = ld(rc, r + 4); ab = ld(ra, r + 3); bb = ld(rb, r + 3); sb = side(r + 3);
+            row_step(r + 1, q1, q2, q3, pa4[1], pb4[1], sb, s1, s2, s3);
+            q1 = ld(rc, r + 4); pa4[0] = ld(ra, r + 4); pb4[0] = ld(rb, r + 4); sb = side(r + 3);
             s0 = split(q0);
-            row_step(r + 2, q2, q3, q0, aa, ba, sa, s2, s3, s0);
-            q2 = ld(rc, r + 5); aa = ld(ra, r + 4); ba = ld(rb, r + 4); sa = side(r + 4);
+            row_step(r + 2, q2, q3, q0, pa4[2], pb4[2], sa, s2, s3, s0);
+            q2 = ld(rc, r + 5); pa4[1] = ld(ra, r + 5); pb4[1] = ld(rb, r + 5); sa = side(r + 4);
             s1 = split(q1);
-            row_step(r + 3, q3, q0, q1, ab, bb, sb, s3, s0, s1);
+            row_step(r + 3, q3, q0, q1, pa4[3], pb4[3], sb, s3, s0, s1);
         }
     }
     for (int r = r0 + nfull; r < r1; ++r) {  // ragged tail

@@ -1,13 +1,15 @@
 #!/bin/bash
 # Profiles kept under profiles/ for a round (run on the GPU box through gpurun; TAG = r01, r02, ...):
-#   bash tools/profile_round.sh r02
+#   bash tools/profile_round.sh r03
 # rocprofv3 passes, each with the program itself after `--` (python3 <script>), counters in their own runs:
 #   1. --kernel-trace --stats of the bench.py command (default math = tol, untracked Jacobi, developed field: pairs of
 #      iterations as jacobi_fused2d_kernel, the check and the odd iteration as sweep2d_kernel) and of
 #      the same with --math precise; of the 512^3 sweeps (tools/bench_config.py, developed field), tol and precise
 #   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes: 2-D tol, 3-D tol, 3-D precise
 #   3. --pmc SQ counters: 2-D tol, 2-D precise, 3-D tol, 3-D precise
-TAG=${1:-r02}
+#   4. --kernel-trace --stats of whole relaxations with activity tracking (tools/time_relax.py): tol Jacobi, and the library
+#      default (precise, red-black) -- the list-driven kernels and the bypassed batches
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -20,6 +22,9 @@ run stats_tol_jacobi      rocprofv3 --kernel-trace --stats --output-format csv -
 run stats_precise_jacobi  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_precise_jacobi" -- python3 $B --steps 5 --warmup 1 --math precise
 run stats_3d_tol          rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_3d_tol" -- python3 $C --math tol --sweeps 300
 run stats_3d_precise      rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_3d_precise" -- python3 $C --math precise --sweeps 300
+R="$ROOT/tools/time_relax.py --track 2"
+run stats_relax_tol      rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_relax_tol" -- python3 $R --math tol --scheme jacobi
+run stats_relax_default  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_relax_default" -- python3 $R --math precise --scheme redblack
 run fetch_tol   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_tol_jacobi" -- python3 $B --steps 1 --warmup 1 --develop 200
 run write_tol   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write_tol_jacobi" -- python3 $B --steps 1 --warmup 1 --develop 200
 run fetch_3d_tol   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_3d_tol" -- python3 $C --math tol --sweeps 100
@@ -36,6 +41,8 @@ $S stats "$OUT/stats_tol_jacobi" > "$OUT/${TAG}_kernel_stats_tol_jacobi.txt"
 $S stats "$OUT/stats_precise_jacobi" > "$OUT/${TAG}_kernel_stats_precise_jacobi.txt"
 $S stats "$OUT/stats_3d_tol" > "$OUT/${TAG}_kernel_stats_3d_tol.txt"
 $S stats "$OUT/stats_3d_precise" > "$OUT/${TAG}_kernel_stats_3d_precise.txt"
+$S stats "$OUT/stats_relax_tol" > "$OUT/${TAG}_kernel_stats_relax_tol_tracked.txt"
+$S stats "$OUT/stats_relax_default" > "$OUT/${TAG}_kernel_stats_relax_default.txt"
 PROFILE_KERNEL=jacobi_fused2d $S pmc "$OUT/fetch_tol_jacobi" "$OUT/write_tol_jacobi" > "$OUT/${TAG}_hbm_traffic_tol_jacobi_fused.txt"
 PROFILE_KERNEL=sweep2d $S pmc "$OUT/fetch_tol_jacobi" "$OUT/write_tol_jacobi" > "$OUT/${TAG}_hbm_traffic_tol_jacobi.txt"
 $S pmc "$OUT/fetch_3d_tol" "$OUT/write_3d_tol" > "$OUT/${TAG}_hbm_traffic_3d_tol.txt"
