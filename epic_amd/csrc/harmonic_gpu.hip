@@ -2231,6 +2231,45 @@ int epic_hip_sweep2_2d(const float *d_in, float *d_out, const uint32_t *d_maskw,
                : EPIC_ERROR_KERNEL_EXECUTION;
 }
 
+size_t epic_hip_mask_words_fused_2d(unsigned int rows, unsigned int pitch) { return epic_hip::mask_words_fused_2d((int)rows, (int)pitch); }
+
+int epic_hip_fuse_masks_2d(const uint32_t *d_maskw, unsigned int rows, unsigned int pitch, uint32_t *d_maskf, void *stream)
+{
+    if (!d_maskw || !d_maskf || rows < 3 || pitch == 0 || pitch % 256 != 0) return EPIC_ERROR_INVALID_DATA;
+    return epic_hip::launch_fuse_masks_2d(d_maskw, (int)rows, (int)pitch, d_maskf, (hipStream_t)stream) == hipSuccess
+               ? EPIC_SUCCESS
+               : EPIC_ERROR_KERNEL_EXECUTION;
+}
+
+int epic_hip_sweeps_2d(float *d_a, float *d_b, const uint32_t *d_maskw, const uint32_t *d_maskf, unsigned int rows,
+                       unsigned int pitch, unsigned int n, unsigned int rows_per_task, unsigned int rows_per_pair, int math_mode,
+                       int *flips, void *stream)
+{
+    if (!d_a || !d_b || d_a == d_b || !d_maskw || rows < 3 || pitch == 0 || pitch % 256 != 0) return EPIC_ERROR_INVALID_DATA;
+    if (math_mode < 0 || math_mode > 4 || math_mode == 3) return EPIC_ERROR_INVALID_DATA;
+    if (rows_per_task == 0) rows_per_task = 32;
+    if (rows_per_pair == 0) rows_per_pair = (unsigned)epic_hip::jacobi_fused_auto_rows((int)rows, (int)pitch);
+    const bool pairs = math_mode == 4 && getenv("EPIC_HIP_NO_FUSE") == nullptr;
+    float *buf[2] = {d_a, d_b};
+    int cur = 0;
+    for (unsigned i = 0; i < n;) {
+        hipError_t e;
+        if (pairs && n - i >= 2) {
+            e = epic_hip::launch_jacobi_fused_2d(buf[cur], buf[cur ^ 1], d_maskw, (int)rows, (int)pitch, (int)rows_per_pair, math_mode,
+                                                 (hipStream_t)stream, -1, d_maskf);
+            i += 2;
+        } else {
+            e = epic_hip::launch_sweep_2d(buf[cur], buf[cur ^ 1], d_maskw, (int)rows, (int)pitch, 0, (int)rows, (int)rows_per_task,
+                                          math_mode, -1, nullptr, (hipStream_t)stream);
+            i += 1;
+        }
+        if (e != hipSuccess) return EPIC_ERROR_KERNEL_EXECUTION;
+        cur ^= 1;
+    }
+    if (flips) *flips = cur;
+    return EPIC_SUCCESS;
+}
+
 int epic_hip_sweep_rb_2d(float *d_u, const uint32_t *d_maskw, unsigned int rows, unsigned int pitch, unsigned int row_begin,
                          unsigned int row_end, unsigned int rows_per_task, int math_mode, int parity,
                          uint32_t *d_delta_bits, void *stream)

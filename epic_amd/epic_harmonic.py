@@ -142,6 +142,9 @@ _SIGNATURES = {
     "epic_hip_sweep_2d": (ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_uint,
                           ct.c_uint, ct.c_int, ct.c_void_p, ct.c_void_p),
     "epic_hip_sweep2_2d": (ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_int, ct.c_void_p),
+    "epic_hip_fuse_masks_2d": (ct.c_void_p, ct.c_uint, ct.c_uint, ct.c_void_p, ct.c_void_p),
+    "epic_hip_sweeps_2d": (ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_uint,
+                           ct.c_int, ct.POINTER(ct.c_int), ct.c_void_p),
     "epic_hip_sweep_rb_2d": (ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_int,
                              ct.c_int, ct.c_void_p, ct.c_void_p),
 }
@@ -157,6 +160,8 @@ _epic.epic_hip_version.argtypes = ()
 _epic.epic_hip_version.restype = ct.c_char_p
 _epic.epic_hip_mask_words_2d.argtypes = (ct.c_uint, ct.c_uint)
 _epic.epic_hip_mask_words_2d.restype = ct.c_size_t
+_epic.epic_hip_mask_words_fused_2d.argtypes = (ct.c_uint, ct.c_uint)
+_epic.epic_hip_mask_words_fused_2d.restype = ct.c_size_t
 _epic.epic_hip_pitch_for_cols.argtypes = (ct.c_uint,)
 _epic.epic_hip_pitch_for_cols.restype = ct.c_uint
 

@@ -81,6 +81,7 @@ class HipBackend:
         if math not in modes:
             raise ValueError("epic_amd.slab: unknown math mode %r (one of %s)" % (math, ", ".join(sorted(modes))))
         self.math = modes[math]
+        self.maskf = None   # the masks in the fused passes' layout, made by pack_mask
 
     def pitch_for(self, cols):
         return int(self.E.epic_hip_pitch_for_cols(cols))
@@ -93,6 +94,13 @@ class HipBackend:
                                           maskw.data_ptr(), torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             raise RuntimeError("epic_hip_pack_mask_2d failed: %d" % rc)
+        # the same masks cut for the fused passes' lane mapping (include/epic_hip.h: epic_hip_fuse_masks_2d)
+        words = int(self.E.epic_hip_mask_words_fused_2d(rows, pitch))
+        if self.maskf is None or self.maskf.numel() != words or self.maskf.device != maskw.device:
+            self.maskf = torch.empty(words, dtype=torch.int32, device=maskw.device)
+        rc = self.E.epic_hip_fuse_masks_2d(maskw.data_ptr(), rows, pitch, self.maskf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("epic_hip_fuse_masks_2d failed: %d" % rc)
 
     def sweep(self, src, dst, maskw, rows, pitch, row_begin, row_end, delta_bits):
         if row_end <= row_begin:
@@ -115,6 +123,18 @@ class HipBackend:
                                        self.math, torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             raise RuntimeError("epic_hip_sweep2_2d failed: %d" % rc)
+
+    def sweeps(self, a, b, maskw, rows, pitch, n):
+        """n plain Jacobi sweeps of all local rows in ONE library call (pairs as fused passes with the tol math), the field
+        starting in `a`; returns the number of buffer changes (odd: the result is in `b`)."""
+        flips = ct.c_int(0)
+        rc = self.E.epic_hip_sweeps_2d(a.data_ptr(), b.data_ptr(), maskw.data_ptr(),
+                                       self.maskf.data_ptr() if self.maskf is not None else None, rows, pitch, int(n),
+                                       self.rows_per_task, self.rows_per_pair, self.math, ct.byref(flips),
+                                       torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("epic_hip_sweeps_2d failed: %d" % rc)
+        return flips.value
 
     def sweep_rb(self, u, maskw, rows, pitch, row_begin, row_end, parity, delta_bits):
         """One in-place red-black half-sweep of local rows [row_begin, row_end): cells with (row + col + parity) odd."""
@@ -363,6 +383,18 @@ class SlabSolver:
         """The next iteration -- or the next two as one pass where that is possible and neither is a check iteration --
         of at most `budget`; returns (iterations done, whether the last one was a check)."""
         check = self.iteration % self.stagger == 0
+        if not check and not self.redblack and hasattr(self.backend, "sweeps") and os.environ.get("EPIC_SLAB_ONE_BY_ONE") is None:
+            # the whole stretch of plain iterations up to the next check, or to the iteration that ends with an exchange, in ONE
+            # call into the library: the interpreter's per-call cost is paid once per stretch, not once per launch
+            n = min(int(budget), self.stagger - self.iteration % self.stagger)
+            if self.world > 1:
+                n = min(n, self.halo - 1 - self.since)
+            if n >= 2:
+                flips = self.backend.sweeps(self.buf[self.cur], self.buf[self.cur ^ 1], self.maskw, self.rows, self.pitch, n)
+                self.cur ^= flips & 1
+                self.since += n
+                self.iteration += n
+                return n, False
         if not check and budget >= 2 and (self.iteration + 1) % self.stagger != 0 and self.can_pair():
             self.sweep_pair()
             return 2, False

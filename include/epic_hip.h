@@ -150,6 +150,19 @@ int epic_hip_sweep_2d(const float *d_in, float *d_out, const uint32_t *d_maskw, 
  * rows_per_task = 0: the library's choice for this size. */
 int epic_hip_sweep2_2d(const float *d_in, float *d_out, const uint32_t *d_maskw, unsigned int rows, unsigned int pitch,
                        unsigned int rows_per_task, int math_mode, void *stream);
+/* The masks a second time, cut for the fused passes' lane -> column mapping (strips of 248 columns): epic_hip_sweep2_2d and
+ * epic_hip_sweeps_2d take them as d_maskf and then skip a funnel shift of two mask words per row and wave (NULL: they shift).
+ * epic_hip_mask_words_fused_2d(rows, pitch) uint32 words; derive after every epic_hip_pack_mask_2d. */
+size_t epic_hip_mask_words_fused_2d(unsigned int rows, unsigned int pitch);
+int epic_hip_fuse_masks_2d(const uint32_t *d_maskw, unsigned int rows, unsigned int pitch, uint32_t *d_maskf, void *stream);
+/* `n` plain Jacobi sweeps of the whole local grid in ONE call (a driver in an interpreted language pays its per-call cost
+ * once per stretch between two halo exchanges instead of once per launch): the field starts in d_a, the sweeps ping-pong
+ * between d_a and d_b, *flips receives the number of buffer changes (odd: the result is in d_b).  tol math (math_mode 4):
+ * pairs of sweeps run as fused passes (rows_per_pair = 0: the library's choice), a last odd sweep singly; other modes: n single
+ * sweeps.  Bit-identical to n calls of epic_hip_sweep_2d. */
+int epic_hip_sweeps_2d(float *d_a, float *d_b, const uint32_t *d_maskw, const uint32_t *d_maskf, unsigned int rows,
+                       unsigned int pitch, unsigned int n, unsigned int rows_per_task, unsigned int rows_per_pair, int math_mode,
+                       int *flips, void *stream);
 /* The same for the reference's red-black scheme: one in-place half-sweep of rows [row_begin, row_end) of d_u, updating
  * the unlocked cells with (local row + column + parity) odd (libepic/src/harmonic/harmonic_cpu.cpp:46-51 with
  * parity = currentIteration; a slab whose local row 0 is global row `top` passes (currentIteration + top) & 1). */

@@ -14,7 +14,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="$ROOT/bench.py --no-cpu --no-relax --no-extra-legs"
+B="$ROOT/bench.py --no-cpu --no-relax --no-extra-legs --no-parity"
 C="$ROOT/tools/bench_config.py --grid 512 512 512 --develop 1500"
 SQ="SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE"
 run() { name=$1; shift; "$@" > "$OUT/$name.log" 2>&1; echo "[$name] rc=$?"; }
