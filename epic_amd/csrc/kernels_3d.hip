@@ -6,9 +6,10 @@
 //
 // Layout: u[x0][x1][x2] with x2 contiguous and padded to `pitch` (multiple of 256 floats).  A wave owns 256 x2-columns
 // (4 per lane, one dwordx4) of one x0-plane and marches along x1, keeping rows x1-1 / x1 / x1+1 of its plane in
-// registers; x2 neighbours are full-wave DPP shifts; the rows of planes x0-1 and x0+1 are loaded per step.  The eight
-// waves of a workgroup sweep eight consecutive planes of the same (x1-chunk, strip), so those extra rows are mostly the
-// sibling waves' centre rows and are served by the CU's L1 / the XCD's L2 rather than HBM (ten planes loaded for eight).
+// registers; x2 neighbours are full-wave DPP shifts; the rows of planes x0-1 and x0+1 are loaded per step.  The four
+// waves of a workgroup sweep four consecutive planes of the same (x1-chunk, strip), so those extra rows are mostly the
+// sibling waves' centre rows and are served by the CU's L1 / the XCD's L2 rather than HBM (six planes loaded for four:
+// 1.41x the algorithmic reads measured, against the 1.5x of no reuse between workgroups at all).
 // Mask: 1 bit per cell as lane masks (kernels.h), fetched with one scalar load per row.
 // Optional activity tracking (wake.h): a tile is one task -- 32 x1-rows x 256 x2-columns of one x0-plane; it reads its
 // own cells, the adjacent column / row of its four in-plane neighbours and the whole tile of the planes x0 - 1 and x0 + 1.
@@ -25,9 +26,9 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kStripCols = 256;
-#ifndef EPIC_SWEEP3D_BLOCK_WAVES  // build knob (A/B).  8 planes per workgroup load 10 (1.25x) where 4 load 6 (1.5x); at the 4 waves per
-#define EPIC_SWEEP3D_BLOCK_WAVES 8  // SIMD the tol kernels run at, two such workgroups fill a CU: 291 us per 512^3 sweep against 293.5
-#endif                            // (4) and 302 (16), same box (round 2, at 5 waves per SIMD, measured 8 slower than 4)
+#ifndef EPIC_SWEEP3D_BLOCK_WAVES  // build knob (A/B).  On paper 8 planes per workgroup load 10 (1.25x) where 4 load 6 (1.5x); measured
+#define EPIC_SWEEP3D_BLOCK_WAVES 4  // (PMC FETCH_SIZE, 512^3 tol, same box, profiles/r03_experiments.txt) 4 planes read 755 MB per sweep
+#endif                            // and 8 planes 883 MB for 1 % of time (295.7 / 292.7 us; 16 planes: 302 us): 4 stays
 constexpr int kWavesPerBlock = EPIC_SWEEP3D_BLOCK_WAVES;  // = consecutive planes per workgroup
 static_assert(kWave * kWavesPerBlock >= kWakeLists, "one thread per work list resets the counters");
 constexpr int kRowsPerTask = 32;
@@ -247,8 +248,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB
         float4 q0 = ld(rc, r0 - 1), q1 = ld(rc, r0), q2 = ld(rc, r0 + 1), q3;
         RowSide sa = side(r0), sb;
         Split4 s0 = split(q0), s1 = split(q1), s2 = {}, s3 = {};
-        // (the neighbouring planes' rows run two rows ahead as well, over four register sets each: 289 -> 285 us at 512^3 against one
-        //  row ahead, same box -- the kernel waits for memory almost half of its time, profiles/r03_sq_counters_3d_tol.txt)
+        // (the neighbouring planes' rows run two rows ahead as well, over four register sets each: 300.8 -> 295.7 us at 512^3 against
+        //  one row ahead, same box, 747 -> 755 MB read -- the kernel waits for memory almost half of its time,
+        //  profiles/r03_sq_counters_3d_tol.txt)
         float4 pa4[4], pb4[4];
         pa4[0] = ld(ra, r0); pb4[0] = ld(rb, r0); pa4[1] = ld(ra, r0 + 1); pb4[1] = ld(rb, r0 + 1);
         for (int i = 0; i < nfull; i += 4) {
