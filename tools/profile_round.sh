@@ -9,7 +9,9 @@
 #   3. --pmc SQ counters: 2-D tol, 2-D precise, 3-D tol, 3-D precise
 #   4. --kernel-trace --stats of whole relaxations with activity tracking (tools/time_relax.py): tol Jacobi, and the library
 #      default (precise, red-black) -- the list-driven kernels and the bypassed batches
+#   bash tools/profile_round.sh r03 3d      only the passes whose name contains "3d" (after a change to the 3-D kernel)
 TAG=${1:-r03}
+ONLY=${2:-}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -17,7 +19,7 @@ cd /tmp && export TMPDIR=/tmp
 B="$ROOT/bench.py --no-cpu --no-relax --no-extra-legs --no-parity"
 C="$ROOT/tools/bench_config.py --grid 512 512 512 --develop 1500"
 SQ="SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE"
-run() { name=$1; shift; "$@" > "$OUT/$name.log" 2>&1; echo "[$name] rc=$?"; }
+run() { name=$1; shift; case "$name" in *"$ONLY"*) ;; *) return 0;; esac; "$@" > "$OUT/$name.log" 2>&1; echo "[$name] rc=$?"; }
 run stats_tol_jacobi      rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_tol_jacobi" -- python3 $B --steps 5 --warmup 1
 run stats_precise_jacobi  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_precise_jacobi" -- python3 $B --steps 5 --warmup 1 --math precise
 run stats_3d_tol          rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_3d_tol" -- python3 $C --math tol --sweeps 300
@@ -36,7 +38,9 @@ run sq_precise  rocprofv3 --pmc $SQ --output-format csv -d "$OUT/sq_precise_jaco
 run sq_3d_tol      rocprofv3 --pmc $SQ --output-format csv -d "$OUT/sq_3d_tol" -- python3 $C --math tol --sweeps 100
 run sq_3d_precise  rocprofv3 --pmc $SQ --output-format csv -d "$OUT/sq_3d_precise" -- python3 $C --math precise --sweeps 100
 cd "$ROOT"
-S="python3 tools/summarize_profile.py"
+S="sum1"
+sum1() { for a in "$@"; do case "$a" in "$OUT"/*) [ -d "$a" ] || { echo "(pass not run in this call)"; return 0; };; esac; done; python3 tools/summarize_profile.py "$@"; }
+keep() { [ -s "$1" ] && ! grep -q "pass not run in this call" "$1" || rm -f "$1"; }
 $S stats "$OUT/stats_tol_jacobi" > "$OUT/${TAG}_kernel_stats_tol_jacobi.txt"
 $S stats "$OUT/stats_precise_jacobi" > "$OUT/${TAG}_kernel_stats_precise_jacobi.txt"
 $S stats "$OUT/stats_3d_tol" > "$OUT/${TAG}_kernel_stats_3d_tol.txt"
@@ -52,8 +56,9 @@ PROFILE_KERNEL=sweep2d $S sq "$OUT/sq_tol_jacobi" 67108864 > "$OUT/${TAG}_sq_cou
 $S sq "$OUT/sq_precise_jacobi" 67108864 > "$OUT/${TAG}_sq_counters_precise.txt" 2>&1
 $S sq "$OUT/sq_3d_tol" 134217728 > "$OUT/${TAG}_sq_counters_3d_tol.txt" 2>&1
 $S sq "$OUT/sq_3d_precise" 134217728 > "$OUT/${TAG}_sq_counters_3d_precise.txt" 2>&1
+for f in "$OUT"/${TAG}_*.txt; do keep "$f"; done
 # only the summaries travel back in full; the raw CSVs of the long runs are large
 find "$OUT" -name "*kernel_trace.csv" -size +8M -delete
 find "$OUT" -name "*counter_collection.csv" -size +8M -delete
-tail -n 2 "$OUT"/stats_tol_jacobi.log | cut -c1-1500
+[ -f "$OUT"/stats_tol_jacobi.log ] && tail -n 2 "$OUT"/stats_tol_jacobi.log | cut -c1-1500
 cat "$OUT"/${TAG}_*.txt
