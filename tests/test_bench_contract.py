@@ -7,7 +7,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = ["profiles/r02_bench_line_n1.json", "profiles/r02_bench_line_n2_gloo_one_gpu.json"]
+LINES = ["profiles/r03_bench_line_n1.json", "profiles/r03_bench_line_n2_gloo_one_gpu.json"]
 
 
 def load(rel):
@@ -31,6 +31,7 @@ def test_line_has_the_contract_keys(rel):
     assert d["unit"] in baseline["metric"] and "8192" in d["metric"] and "8192" in baseline["metric"]
     assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["scaling"] == "none" if d["n_gpus"] == 1 else d["scaling"] in ("strong", "weak")   # N > 1: the same grid cut into row slabs
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
@@ -50,7 +51,13 @@ def test_single_gpu_line_roofline_is_the_fused_pass_and_has_a_cpu_baseline():
     assert r["kernel"] == "jacobi_fused2d_kernel" and r["iterations_per_launch"] == 2
     assert r["bytes_per_launch"] == 2 * 8 * 8192 * 8192
     assert r["traffic"] is not None and r["traffic"] < r["bytes_per_launch"]      # the field moves once for two iterations
-    assert 0.55 < r["frac"] < 0.80
+    assert 0.60 < r["frac"] < 0.85
+    # the algorithmic figure never travels without the measured one: HBM bytes per launch (PMC) / launch duration / peak
+    assert abs(r["hbm_GBps_measured"] - r["traffic"] / (r["launch_us"] * 1e-6) / 1e9) < 0.01 * r["hbm_GBps_measured"]
+    assert abs(r["hbm_frac_measured"] - r["hbm_GBps_measured"] / r["peak"]) < 1e-3 and r["hbm_frac_measured"] < r["frac"]
+    assert r["limiter"] == "valu"
+    traffic = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    assert r["traffic"] == traffic["8192_tol_jacobi_fused"]
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
@@ -58,3 +65,47 @@ def test_single_gpu_line_roofline_is_the_fused_pass_and_has_a_cpu_baseline():
     # 100 iterations per step at not less than the kernel's rate
     assert d["ms_per_step"] * 1e3 >= 49 * r["launch_us"]
     assert d["kernels"]["single_sweep"]["launch_us"] > r["launch_us"] / 2        # what the fusion buys is visible in the line
+
+
+def test_relaxation_legs_separate_recomputed_from_effective_rates():
+    d = load(LINES[0])
+    free = d["config"]["free_cells"] if "free_cells" in d["config"] else None
+    for leg in ("relax", "relax_redblack", "relax_untracked", "relax_default"):
+        x = d[leg]
+        for key in ("math", "scheme", "activity_tracking", "iterations", "seconds", "delta", "grid_iterations_run",
+                    "recomputed_Mcell_updates_per_s", "effective_Mcell_updates_per_s"):
+            assert key in x, (leg, key)
+        assert "Mcell_updates_per_s" not in x            # round 2's single key counted skipped tiles as updated
+        assert x["recomputed_Mcell_updates_per_s"] <= x["effective_Mcell_updates_per_s"] * 1.0001
+        assert x["grid_iterations_run"] <= x["iterations"] + 1e-6
+        # recomputed / effective = the share of the grid's iterations that actually ran
+        share = x["grid_iterations_run"] / x["iterations"]
+        assert abs(x["recomputed_Mcell_updates_per_s"] / x["effective_Mcell_updates_per_s"] - share) < 0.01
+        if not x["activity_tracking"]:
+            assert x["grid_iterations_run"] == x["iterations"]
+    # nothing recomputes faster than the kernel that does the recomputing: the timed steps' rate bounds the tracked legs'
+    assert d["relax"]["recomputed_Mcell_updates_per_s"] <= d["value"] * 1.05
+    # the library's default configuration (no environment) is the reference's own iteration and is timed in the line
+    assert d["relax_default"]["math"] == "precise" and d["relax_default"]["scheme"] == "redblack"
+    assert d["relax_default"]["seconds"] < d["relax_untracked"]["seconds"]
+    del free
+
+
+def test_parity_object_names_every_baseline_config_and_its_misses():
+    d = load(LINES[0])
+    p = d["parity"]
+    assert p["mode"] == {"math": d["config"]["math"], "scheme": d["config"]["scheme"]}
+    assert "1e-5" in p["bar"]
+    cfgs = p["configs"]
+    for want in ("configs[0]", "configs[1]", "configs[2] family, 512x512", "configs[2] family, 1024x1024",
+                 "configs[2] 8192x8192", "configs[3]", "configs[4]"):
+        assert any(k.startswith(want) for k in cfgs), want
+    measured = {k: v for k, v in cfgs.items() if v.get("max_rel") is not None}
+    assert len(measured) >= 6
+    for k, v in measured.items():
+        assert v["within_bar"] == (v["max_rel"] <= 1e-5) and v["others_equal"] is True, k
+    # a miss is listed, not averaged away: the tol mode ends 1.6e-5 from the reference on umass.yaml, and the line says so
+    assert p["misses"] == sorted(k for k, v in measured.items() if not v["within_bar"])
+    assert p["misses"] == ["configs[1] umass.yaml"]
+    assert 1e-5 < cfgs["configs[1] umass.yaml"]["max_rel"] < 2e-5
+    assert cfgs["configs[2] 8192x8192 (the timed grid)"]["max_rel"] < 2e-6
