@@ -8,7 +8,7 @@
 //     t  = mx + ln(s)                                        f32
 //     u  = (float)((double)t - ln(2n))                       f64 subtract, one rounding
 //
-// Two implementations of e() and ln(), chosen per kernel instantiation (template MATH):
+// Implementations of e() and ln(), chosen per kernel instantiation (template MATH):
 //
 //  kMathPrecise (default)  The reference calls libm's expf/logf (std::exp/std::log on float).  libm is a
 //      third-party dependency that is not under /root/reference: GNU libc 2.35 (Ubuntu 22.04 image), whose
@@ -22,6 +22,10 @@
 //      of the 256x256 reference map by 2e-5 (relative) -- outside the 1e-5 parity bar.
 //
 //  kMathFast  v_exp_f32 / v_log_f32 with f32 base changes.  ~2.5x less ALU; for well-conditioned maps only.
+//
+//  kMathTol   (further down: "tol math") does not evaluate e() per neighbour at all: every cell's potential is split once into
+//      e^u = q 2^n and the cells it is a neighbour of share the pair; its logarithm is its own (TolLn: 256 intervals per
+//      binade, exact f32 reduction, table in LDS).  Same rounding stages as above; parity by tolerance, not by bits.
 //
 // Compile with -ffp-contract=off so no step is fused behind our back (explicit fma() where wanted).
 #pragma once

@@ -475,7 +475,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
     // Stores: the halo lanes (and lanes past the last column) must not write.  A branch around the store would do -- and did,
     // until the ISA showed what it costs: with a store that may or may not have been issued the compiler can no longer count
     // the memory operations in flight behind the row it is waiting for, waits for vmcnt(0) / vmcnt(1) at the top of every step,
-    // and with that for the acknowledgement of the store issued a moment ago (37 % of all wave cycles parked at s_waitcnt).
+    // and with that for the acknowledgement of the store issued a moment ago (share of wave cycles at s_waitcnt 0.37 -> 0.28 with
+    // this change alone, about 1 % of the time: profiles/r03_experiments.txt item 3a).
     // Instead every lane stores, the lanes that own nothing at an offset beyond the descriptor's range, where the hardware
     // drops the write (raw buffers check voffset against num_records = 2 GiB): one store per step, exact counts.
     const unsigned store_off = owner ? lane_off : 0x80000000u;
@@ -616,7 +617,8 @@ __device__ __forceinline__ void tol_fused_pass(const Sweep2dArgs &a, TolLnEntry 
     // Stores: the halo lanes (and lanes past the last column) must not write.  A branch around the store would do -- and did,
     // until the ISA showed what it costs: with a store that may or may not have been issued the compiler can no longer count
     // the memory operations in flight behind the row it is waiting for, waits for vmcnt(0) / vmcnt(1) at the top of every step,
-    // and with that for the acknowledgement of the store issued a moment ago (37 % of all wave cycles parked at s_waitcnt).
+    // and with that for the acknowledgement of the store issued a moment ago (share of wave cycles at s_waitcnt 0.37 -> 0.28 with
+    // this change alone, about 1 % of the time: profiles/r03_experiments.txt item 3a).
     // Instead every lane stores, the lanes that own nothing at an offset beyond the descriptor's range, where the hardware
     // drops the write (raw buffers check voffset against num_records = 2 GiB): one store per step, exact counts.
     const unsigned store_off = owner ? lane_off : 0x80000000u;

@@ -28,7 +28,7 @@ const char *epic_hip_version(void);
 int epic_hip_device_count(void);
 
 /* ---- batches on an initialised Harmonic (device state created by harmonic_initialize_*_gpu) ----------
- * Enqueue `sweeps` Jacobi sweeps without a host round-trip; currentIteration advances by `sweeps`.
+ * Enqueue `sweeps` iterations of the selected scheme without a host round-trip; currentIteration advances by `sweeps`.
  * If check_last != 0 the last sweep also reduces max|du| and the call synchronises, stores it in
  * harmonic->delta and returns EPIC_SUCCESS_AND_CONVERGED when delta < epsilon (needs harmonic_initialize_gpu).
  * Otherwise it returns after enqueueing (ordering points: any *_and_check, get_potential_values, update_model,
@@ -45,7 +45,7 @@ int epic_hip_timed_sweeps_gpu(EpicHarmonicT *harmonic, unsigned int sweeps, unsi
 /* How many iterations one kernel launch of a batch of PLAIN (unchecked) iterations advances in the current configuration:
  * 2 where pairs of iterations run as one fused pass over the data -- Jacobi with the tol math (two sweeps, 4 B of HBM
  * traffic per cell-update instead of 8) and red-black with any math (both colours), 2-D grids of at least
- * 4 Mcell on one device with activity tracking off; results are bit-identical to single iterations, an odd iteration and
+ * 4 Mcell with activity tracking off (per device in multi-device mode, between exchanges); results are bit-identical to single iterations, an odd iteration and
  * every check iteration run singly -- 1 otherwise, 0 without device state.  EPIC_HIP_NO_FUSE=1 switches the fusion off. */
 int epic_hip_iterations_per_pass(EpicHarmonicT *harmonic);
 
@@ -55,7 +55,8 @@ int epic_hip_set_rows_per_task(EpicHarmonicT *harmonic, unsigned int rows_per_ta
 /* Arithmetic of the sweep kernels (also EPIC_HIP_MATH=precise|tol|fast in the environment at initialisation):
  *   0 precise (default)  exp/log bit-identical to the host libm's expf/logf, evaluated in f64 -- the bit-exact parity mode;
  *   4 tol                one exp-class split e^u = q 2^n per CELL (packed f32 polynomial), shared by the cells it is a
- *                        neighbour of, one f64 log per cell; every rounding stage of the reference kept.  2-D and 3-D,
+ *                        neighbour of, one table-driven log per cell (256 intervals per binade, exact f32 reduction,
+ *                        2^-33 accurate); every rounding stage of the reference kept.  2-D and 3-D,
  *                        Jacobi and red-black.  Jacobi stops by the reference's own test; converged fields within
  *                        1e-5 max(1, |u|) of the reference's on its seeded grids, basic.png and maze.png, 1.6e-5 on the
  *                        ill-conditioned umass.png.  ~1.35x faster per sweep than precise, ~1.5x where pairs of
@@ -116,15 +117,17 @@ int epic_hip_eval_math(const float *d_in, float *d_out, size_t n, int which, voi
 
 /* ---- several GPUs behind the unchanged ABI ------------------------------------------------------------------------
  * EPIC_HIP_DEVICES=0,1,2,3 in the environment when a Harmonic's device state is created makes every harmonic_*_gpu entry
- * point work on ONE 2-D grid cut into one row slab per listed device, in this process: harmonic_complete_gpu(&h, 1024) --
+ * point work on ONE grid cut along its slowest axis into one slab per listed device (rows in 2-D, planes in 3-D), in this process: harmonic_complete_gpu(&h, 1024) --
  * the ROS plugin's only call, /root/reference/src/epic_nav_core_plugin.cpp:256 -- then uses the whole node.  The reference
  * has nothing like it (libepic/src/harmonic/harmonic_gpu.cu:168-201 drives one device).  A device may be listed more than
  * once ("0,0,0,0": four slabs on one GPU).  EPIC_HIP_HALO=G (default by slab height: 8 from 4096 rows per device up, 16 from
- * 2048, 32 below): ghost rows per interior side, traded every G
- * iterations with hipMemcpyPeerAsync; results are bit-identical to the single-device path for every list and every G.
- * 3-D grids, grids with fewer than 4 rows per listed device and an unusable list fall back to one device.  Activity
- * tracking is off and the device streamline walk unavailable in this mode.
- * epic_hip_device_layout: which device holds which rows -- returns the number of slabs (1 in single-device mode) and
+ * 2048, 32 below): ghost units per interior side, traded every G
+ * iterations with hipMemcpyPeerAsync -- or, where peer access between two listed devices cannot be enabled (reported once on
+ * stderr; EPIC_HIP_NO_PEER=1 forces it), through pinned host memory; results are bit-identical to the single-device path for
+ * every list and every G.  One host thread per slab issues its launches (EPIC_HIP_THREADS=0: the calling thread does);
+ * activity tracking works per slab.  Grids with fewer than 4 units per listed device and an unusable list fall back to one
+ * device; path requests walk on the host in this mode.
+ * epic_hip_device_layout: which device holds which units (rows of a 2-D grid, planes of a 3-D one) -- returns the number of slabs (1 in single-device mode) and
  * fills at most `cap` entries of each non-NULL array (owned rows [row_begin, row_end); ghost rows per interior side). */
 int epic_hip_device_layout(EpicHarmonicT *harmonic, int cap, int *devices, unsigned int *row_begin, unsigned int *row_end,
                            unsigned int *ghost_rows);
