@@ -15,6 +15,7 @@
 // own cells, the adjacent column / row of its four in-plane neighbours and the whole tile of the planes x0 - 1 and x0 + 1.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "cell_update.h"
 #include "kernels.h"
@@ -44,8 +45,70 @@ struct Sweep3dArgs {
     int nblocks;  // logical blocks: nstrips * nchunks * nplane_groups (a tol launch holds fewer workgroups, which walk them)
     int check_lo, check_hi;  // CHECK: only planes [check_lo, check_hi) count for max |du| (a slab's ghost planes do not)
     int parity;  // red-black scheme only: currentIteration & 1
+    int rows;    // sweep3d_pair_kernel: x1-rows per task
     WakeArgs wake;  // TRACK kernels, whole-grid launches only
 };
+
+// One x2-row of one plane with the tol math: c / up / dn = rows x1, x1 - 1, x1 + 1 of the plane, pa / pb = row x1 of the planes
+// x0 - 1 and x0 + 1, s* their splits, hl / hr the two strip-edge cells of the row, m0..m3 its lane masks.  RB: only the cells of
+// one colour are recomputed (even_cols: the lane's .x and .z).  The cells go through the three phases of cell_update.h two at
+// a time: the table reads of one pair are in flight while the other pair is worked on.
+template <bool RB>
+__device__ __forceinline__ float4 tol_row_3d(const float4 &pa, const float4 &pb, const float4 &up, const float4 &c, const float4 &dn,
+                                             const Split4 &sa, const Split4 &sb, const Split4 &su, const Split4 &sc, const Split4 &sd,
+                                             float hl, float hr, lmask m0, lmask m1, lmask m2, lmask m3, bool even_cols,
+                                             const TolLnEntry *tl)
+{
+    const float lf = wave_from_left(c.w, hl);
+    const float rt = wave_from_right(c.x, hr);
+#ifdef EPIC_EXP3D_NOEDGESPLIT  // timing experiment only (wrong results)
+    const Split2 hs = Split2{v2f{sc.qx, sc.qw}, v2f{u2f(sc.nx), u2f(sc.nw)}};
+#else
+    const Split2 hs = tol_split2(v2f{hl, hr});  // the two strip-edge cells of the row
+#endif
+    const float ql = wave_from_left(sc.qw, hs.q.x), qr = wave_from_right(sc.qx, hs.q.y);
+    const uint32_t nl = f2u(wave_from_left(u2f(sc.nw), hs.zm.x)), nr = f2u(wave_from_right(u2f(sc.nx), hs.zm.y));
+    float4 o = c;
+    auto pre_xz = [&] {
+        return tol_pre2_3d(TolNb6{pa.x, pb.x, up.x, dn.x, lf, c.y, sa.qx, sb.qx, su.qx, sd.qx, ql, sc.qy, sa.nx, sb.nx, su.nx, sd.nx, nl, sc.ny},
+                           TolNb6{pa.z, pb.z, up.z, dn.z, c.y, c.w, sa.qz, sb.qz, su.qz, sd.qz, sc.qy, sc.qw, sa.nz, sb.nz, su.nz, sd.nz, sc.ny, sc.nw});
+    };
+    auto pre_yw = [&] {
+        return tol_pre2_3d(TolNb6{pa.y, pb.y, up.y, dn.y, c.x, c.z, sa.qy, sb.qy, su.qy, sd.qy, sc.qx, sc.qz, sa.ny, sb.ny, su.ny, sd.ny, sc.nx, sc.nz},
+                           TolNb6{pa.w, pb.w, up.w, dn.w, c.z, rt, sa.qw, sb.qw, su.qw, sd.qw, sc.qz, qr, sa.nw, sb.nw, su.nw, sd.nw, sc.nz, nr});
+    };
+    float nx, ny, nz, nw;
+    TolLnRaw ea, eb;
+    if (!RB) {
+        const TolPre2 pxz = pre_xz();
+        TolLnPair f0 = tol_ln_issue<5>(pxz, tl);
+        const TolPre2 pyw = pre_yw();
+        TolLnPair f1 = tol_ln_issue<5>(pyw, tl);
+        tol_ln_wait<2>(f0, ea, eb);
+        tol_post2(pxz, ea, eb, kLn6, nx, nz);
+        o.x = sel(m0, c.x, nx);
+        o.z = sel(m2, c.z, nz);
+        tol_ln_wait<0>(f1, ea, eb);
+        tol_post2(pyw, ea, eb, kLn6, ny, nw);
+        o.y = sel(m1, c.y, ny);
+        o.w = sel(m3, c.w, nw);
+    } else if (even_cols) {
+        const TolPre2 pxz = pre_xz();
+        TolLnPair f0 = tol_ln_issue<5>(pxz, tl);
+        tol_ln_wait<0>(f0, ea, eb);
+        tol_post2(pxz, ea, eb, kLn6, nx, nz);
+        o.x = sel(m0, c.x, nx);
+        o.z = sel(m2, c.z, nz);
+    } else {
+        const TolPre2 pyw = pre_yw();
+        TolLnPair f1 = tol_ln_issue<5>(pyw, tl);
+        tol_ln_wait<0>(f1, ea, eb);
+        tol_post2(pyw, ea, eb, kLn6, ny, nw);
+        o.y = sel(m1, c.y, ny);
+        o.w = sel(m3, c.w, nw);
+    }
+    return o;
+}
 
 // RB = true: the reference's 3-D red-black half-sweep in place (in == out): cells with (x0 + x1 + x2 + currentIteration)
 // even are recomputed (harmonic_cpu.cpp:89-102), all six neighbours have the other colour.
@@ -131,6 +194,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB
     typedef unsigned vu4 __attribute__((ext_vector_type(4)));
     auto row_off = [&](int r) -> unsigned { return (unsigned)((r - rlo) * a.pitch + col0) * 4u; };  // r already clamped
     auto ld = [&](unsigned plane_off, int r) -> float4 {
+#ifdef EPIC_EXP3D_NONB  // timing experiment only (wrong results): the neighbouring planes' rows are the plane's own (a third of the loads)
+        plane_off = rc;
+#endif
         r = min(max(r, 0), rlast);
         const vu4 q = __builtin_amdgcn_raw_buffer_load_b128(rin, lane16, plane_off + row_off(r), 0);
         return make_float4(u2f(q.x), u2f(q.y), u2f(q.z), u2f(q.w));
@@ -143,7 +209,12 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB
         r = min(max(r, 0), rlast);
         cfloat *row = (cfloat *)(pc + (size_t)r * pitch);
         cu64 *mk = (cu64 *)a.maskw + (((size_t)x0 * a.m1 + r) * a.nstrips + strip) * 4;
+#ifdef EPIC_EXP3D_NOSIDE  // timing experiment only (wrong results): no scalar loads per row
+        (void)row; (void)mk;
+        return RowSide{-3.0f, -4.0f, 0, 0, 0, 0};
+#else
         return RowSide{row[hcol_l], row[hcol_r], mk[0], mk[1], mk[2], mk[3]};
+#endif
     };
 
     lmask chg_any = 0, chg_x = 0, chg_w = 0, chg_top = 0, chg_bot = 0;  // lane masks, as in the 2-D kernel
@@ -153,56 +224,17 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB
     // rows of the two neighbouring planes are split where they are used)
     auto row_step = [&](int r, const float4 &up, const float4 &c, const float4 &dn, const float4 &pa, const float4 &pb,
                         const RowSide &h, const Split4 &su, const Split4 &sc, const Split4 &sd) {
-        const float lf = wave_from_left(c.w, h.l);
-        const float rt = wave_from_right(c.x, h.r);
         float4 o;
+        const float lf = TOL ? 0.0f : wave_from_left(c.w, h.l);
+        const float rt = TOL ? 0.0f : wave_from_right(c.x, h.r);
         if (TOL) {
+#ifdef EPIC_EXP3D_NOSPLITNB  // timing experiment only (wrong results): the neighbouring planes' rows are not split
+            const Split4 sa = su, sb = sd;
+#else
             const Split4 sa = tol_split4(pa), sb = tol_split4(pb);
-            const Split2 hs = tol_split2(v2f{h.l, h.r});  // the two strip-edge cells of the row
-            const float ql = wave_from_left(sc.qw, hs.q.x), qr = wave_from_right(sc.qx, hs.q.y);
-            const uint32_t nl = f2u(wave_from_left(u2f(sc.nw), hs.zm.x)), nr = f2u(wave_from_right(u2f(sc.nx), hs.zm.y));
-            o = c;
-            const bool even_cols = !RB || ((x0 + r + a.parity) & 1) == 0, odd_cols = !RB || !even_cols;  // scalar
-            // the cells this iteration updates, two at a time in the three phases of cell_update.h: the table reads of one pair are
-            // in flight while the other pair is worked on
-            auto pre_xz = [&] {
-                return tol_pre2_3d(TolNb6{pa.x, pb.x, up.x, dn.x, lf, c.y, sa.qx, sb.qx, su.qx, sd.qx, ql, sc.qy, sa.nx, sb.nx, su.nx, sd.nx, nl, sc.ny},
-                                   TolNb6{pa.z, pb.z, up.z, dn.z, c.y, c.w, sa.qz, sb.qz, su.qz, sd.qz, sc.qy, sc.qw, sa.nz, sb.nz, su.nz, sd.nz, sc.ny, sc.nw});
-            };
-            auto pre_yw = [&] {
-                return tol_pre2_3d(TolNb6{pa.y, pb.y, up.y, dn.y, c.x, c.z, sa.qy, sb.qy, su.qy, sd.qy, sc.qx, sc.qz, sa.ny, sb.ny, su.ny, sd.ny, sc.nx, sc.nz},
-                                   TolNb6{pa.w, pb.w, up.w, dn.w, c.z, rt, sa.qw, sb.qw, su.qw, sd.qw, sc.qz, qr, sa.nw, sb.nw, su.nw, sd.nw, sc.nz, nr});
-            };
-            float nx, ny, nz, nw;
-            TolLnRaw ea, eb;
-            if (!RB) {
-                const TolPre2 pxz = pre_xz();
-                TolLnPair f0 = tol_ln_issue<5>(pxz, tl);
-                const TolPre2 pyw = pre_yw();
-                TolLnPair f1 = tol_ln_issue<5>(pyw, tl);
-                tol_ln_wait<2>(f0, ea, eb);
-                tol_post2(pxz, ea, eb, kLn6, nx, nz);
-                o.x = sel(h.m0, c.x, nx);
-                o.z = sel(h.m2, c.z, nz);
-                tol_ln_wait<0>(f1, ea, eb);
-                tol_post2(pyw, ea, eb, kLn6, ny, nw);
-                o.y = sel(h.m1, c.y, ny);
-                o.w = sel(h.m3, c.w, nw);
-            } else if (even_cols) {
-                const TolPre2 pxz = pre_xz();
-                TolLnPair f0 = tol_ln_issue<5>(pxz, tl);
-                tol_ln_wait<0>(f0, ea, eb);
-                tol_post2(pxz, ea, eb, kLn6, nx, nz);
-                o.x = sel(h.m0, c.x, nx);
-                o.z = sel(h.m2, c.z, nz);
-            } else {
-                const TolPre2 pyw = pre_yw();
-                TolLnPair f1 = tol_ln_issue<5>(pyw, tl);
-                tol_ln_wait<0>(f1, ea, eb);
-                tol_post2(pyw, ea, eb, kLn6, ny, nw);
-                o.y = sel(h.m1, c.y, ny);
-                o.w = sel(h.m3, c.w, nw);
-            }
+#endif
+            const bool even_cols = !RB || ((x0 + r + a.parity) & 1) == 0;  // scalar
+            o = tol_row_3d<RB>(pa, pb, up, c, dn, sa, sb, su, sc, sd, h.l, h.r, h.m0, h.m1, h.m2, h.m3, even_cols, tl);
         } else if (RB) {
             o = c;
             if (((x0 + r + a.parity) & 1) == 0) {  // scalar: even x2 columns (.x, .z) are this row's active cells
@@ -305,6 +337,163 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Two planes per wave (tol math, launches without work lists).  In sweep3d_kernel every row is loaded and split by three
+// waves: its own and those of the planes on either side.  Timing-only builds of that kernel priced the two halves of this
+// (512^3, same box, profiles/r03_experiments.txt item 8): without the neighbouring planes' LOADS 292 -> 235 us, without
+// their SPLITS 292 -> 247 us -- the sweep is bound by both at once.  Here a wave owns the planes x0 and x0 + 1 of its strip
+// and marches both along x1: each is the other's neighbour, so of the four rows a step needs from outside the wave's own
+// window two are already in registers with their splits.  Per updated row: 2 rows loaded and split instead of 3 (51.6 VALU
+// instructions per cell against 56.8).  177-189 registers, two waves per SIMD (three -- 168 registers and a few spills -- time
+// the same); the four waves of a workgroup hold eight consecutive planes.  512^3, same box: 295 -> 270-273 us per sweep.
+// The loads and stores of this march alone (-DEPIC_EXP3D_TRAFFIC) take 217-225 us whatever the occupancy and the
+// prefetch depth: the floor of the pattern.  Build knobs below: measured alternatives (profiles/r03_experiments.txt item 8).
+// Same arithmetic on the same inputs as sweep3d_kernel: bit-identical results (tests/test_gpu_full_configs.py and the
+// whole 3-D parity suite run through it; EPIC_HIP_3D_PAIR=0 selects the one-plane kernel).
+#ifndef EPIC_PAIR_MIN_BLOCKS
+#define EPIC_PAIR_MIN_BLOCKS 2
+#endif
+#ifndef EPIC_PAIR_OUTER_AHEAD
+#define EPIC_PAIR_OUTER_AHEAD 2
+#endif
+#ifndef EPIC_PAIR_BARRIER_ROWS
+#define EPIC_PAIR_BARRIER_ROWS 0
+#endif
+#ifndef EPIC_PAIR_BLOCK_WAVES
+#define EPIC_PAIR_BLOCK_WAVES 4
+#endif
+constexpr int kPairWaves = EPIC_PAIR_BLOCK_WAVES;  // waves per workgroup = pairs of consecutive planes
+constexpr int kPairMinBlocks = EPIC_PAIR_MIN_BLOCKS;
+constexpr int kPairRows = 64;  // x1-rows per task (512^3: 32 rows 273.5 us, 64: 269.7, 128: 268.5, 256: 323 -- too few tasks)
+constexpr int kPairOuterAhead = EPIC_PAIR_OUTER_AHEAD;  // rows the outer planes' loads run ahead of their use (1 or 2)
+template <bool CHECK, bool RB>
+__global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pair_kernel(Sweep3dArgs a)
+{
+    __shared__ __attribute__((aligned(16))) char math_lds_bytes[TolLn<5>::kLdsBytes];
+    const TolLnEntry *const tl = reinterpret_cast<const TolLnEntry *>(math_lds_bytes);
+    TolLn<5>::stage(reinterpret_cast<TolLnEntry *>(math_lds_bytes));
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float dmax = 0.0f;
+    typedef unsigned vu4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) float cfloat;
+    typedef const __attribute__((address_space(4))) uint64_t cu64;
+    struct RowSide { float l, r; lmask m0, m1, m2, m3; };
+
+    for (int vb = blockIdx.x; vb < a.nblocks; vb += gridDim.x) {
+        int b = vb;
+        const int strip = b % a.nstrips;
+        b /= a.nstrips;
+        const int chunk = b % a.nchunks;
+        const int xA_raw = a.plane_begin + ((b / a.nchunks) * kPairWaves + wave) * 2;
+#if EPIC_PAIR_BARRIER_ROWS == 0
+        if (xA_raw >= a.plane_end) continue;             // wave-uniform: the spare waves of the last plane group
+#endif
+        const bool has_a = xA_raw < a.plane_end;         // (with barriers the spare waves march along, on the last plane, and store nothing)
+        const int xA = has_a ? xA_raw : a.plane_end - 1;
+        const bool has_b = xA_raw + 1 < a.plane_end;     // an odd plane count: the last wave's second plane is swept and dropped
+        const int xB = min(xA + 1, a.m0 - 1);
+        const int r0 = chunk * a.rows;
+        const int r1 = min(r0 + a.rows, a.m1);
+        const int col0 = strip * kStripCols;
+        const size_t pitch = (size_t)a.pitch;
+        const size_t plane = (size_t)a.m1 * pitch;
+        const int rlast = a.m1 - 1;
+        const int rlo = max(r0 - 4, 0);
+        // one descriptor for the four planes the wave reads, based at the lowest (the launcher keeps them within its 2 GiB)
+        const int xa = max(xA - 1, 0), xb = min(xA + 2, a.m0 - 1);
+        const __amdgpu_buffer_rsrc_t rin = raw_buffer(a.in + (size_t)xa * plane + (size_t)rlo * pitch),
+                                     rout = raw_buffer(a.out + (size_t)xA * plane + (size_t)rlo * pitch);
+        const unsigned plane_bytes = (unsigned)(plane * sizeof(float));
+        const unsigned oa = 0u, ocA = (unsigned)(xA - xa) * plane_bytes, ocB = (unsigned)(xB - xa) * plane_bytes,
+                       ob = (unsigned)(xb - xa) * plane_bytes;
+        const unsigned lane16 = (unsigned)lane * 16u;
+        const unsigned laneA = has_a ? lane16 : 0x80000000u;  // beyond the descriptor's range: the hardware drops the store
+        const unsigned laneB = has_b ? lane16 : 0x80000000u;
+        auto row_off = [&](int r) -> unsigned { return (unsigned)((r - rlo) * a.pitch + col0) * 4u; };  // r already clamped
+        auto ld = [&](unsigned plane_off, int r) -> float4 {
+            r = min(max(r, 0), rlast);
+            const vu4 q = __builtin_amdgcn_raw_buffer_load_b128(rin, lane16, plane_off + row_off(r), 0);
+            return make_float4(u2f(q.x), u2f(q.y), u2f(q.z), u2f(q.w));
+        };
+        const int hcol_l = max(col0 - 1, 0), hcol_r = min(col0 + kStripCols, a.pitch - 1);
+        auto side = [&](int x, int r) -> RowSide {
+            r = min(max(r, 0), rlast);
+            cfloat *row = (cfloat *)(a.in + (size_t)x * plane + (size_t)r * pitch);
+            cu64 *mk = (cu64 *)a.maskw + (((size_t)x * a.m1 + r) * a.nstrips + strip) * 4;
+            return RowSide{row[hcol_l], row[hcol_r], mk[0], mk[1], mk[2], mk[3]};
+        };
+        const bool chkA = CHECK && has_a && xA >= a.check_lo && xA < a.check_hi, chkB = CHECK && has_b && xB >= a.check_lo && xB < a.check_hi;
+        auto fold = [&](const float4 &c, const float4 &o) {
+            dmax = max2(dmax, fabsf(c.x - o.x));
+            dmax = max2(dmax, fabsf(c.y - o.y));
+            dmax = max2(dmax, fabsf(c.z - o.z));
+            dmax = max2(dmax, fabsf(c.w - o.w));
+        };
+
+        // rings, rotated through constant indices of fully unrolled steps (no moves): the two planes' rows 2 ahead over four
+        // sets (rows j - 1, j, j + 1 in use, j + 2 in flight), their splits likewise, the outer planes' rows 2 ahead
+        float4 qA[4], qB[4], pa[4], pb[4];
+        Split4 sA[4], sB[4];
+        RowSide hA[2], hB[2];
+        // slot of row r0 + j: j & 3 (sides: j & 1); row r0 - 1 sits in slot 3
+        qA[3] = ld(ocA, r0 - 1); qB[3] = ld(ocB, r0 - 1);
+        qA[0] = ld(ocA, r0); qB[0] = ld(ocB, r0);
+        qA[1] = ld(ocA, r0 + 1); qB[1] = ld(ocB, r0 + 1);
+        pa[0] = ld(oa, r0); pb[0] = ld(ob, r0);
+        if (kPairOuterAhead > 1) { pa[1] = ld(oa, r0 + 1); pb[1] = ld(ob, r0 + 1); }
+        hA[0] = side(xA, r0); hB[0] = side(xB, r0);
+        sA[3] = tol_split4(qA[3]); sB[3] = tol_split4(qB[3]);
+        sA[0] = tol_split4(qA[0]); sB[0] = tol_split4(qB[0]);
+
+        auto step = [&](int r, const int k) {  // k = (r - r0) & 3, a constant in every expansion
+            const int km = (k + 3) & 3, kp = (k + 1) & 3, kn = (k + 2) & 3;
+            const int ko = (k + kPairOuterAhead) & 3;
+            qA[kn] = ld(ocA, r + 2); qB[kn] = ld(ocB, r + 2); pa[ko] = ld(oa, r + kPairOuterAhead); pb[ko] = ld(ob, r + kPairOuterAhead);
+            hA[kp & 1] = side(xA, r + 1); hB[kp & 1] = side(xB, r + 1);
+            sA[kp] = tol_split4(qA[kp]); sB[kp] = tol_split4(qB[kp]);
+            const Split4 so_a = tol_split4(pa[k]), so_b = tol_split4(pb[k]);
+            const bool evenA = !RB || ((xA + r + a.parity) & 1) == 0;  // scalar; plane B has the other colour pattern
+            const RowSide &ha = hA[k & 1], &hb = hB[k & 1];
+#ifdef EPIC_EXP3D_TRAFFIC  // timing experiment only (wrong results): the loads and stores of the sweep, no arithmetic
+            auto mx4 = [](const float4 &x, const float4 &y) { return make_float4(max2(x.x, y.x), max2(x.y, y.y), max2(x.z, y.z), max2(x.w, y.w)); };
+            const float4 oA = mx4(mx4(qA[km], qA[kp]), mx4(pa[k], qB[k])), oB = mx4(mx4(qB[km], qB[kp]), mx4(pb[k], qA[k]));
+            (void)so_a; (void)so_b; (void)evenA; (void)ha; (void)hb;
+#else
+            const float4 oA = tol_row_3d<RB>(pa[k], qB[k], qA[km], qA[k], qA[kp], so_a, sB[k], sA[km], sA[k], sA[kp], ha.l, ha.r,
+                                             ha.m0, ha.m1, ha.m2, ha.m3, evenA, tl);
+            const float4 oB = tol_row_3d<RB>(qA[k], pb[k], qB[km], qB[k], qB[kp], sA[k], so_b, sB[km], sB[k], sB[kp], hb.l, hb.r,
+                                             hb.m0, hb.m1, hb.m2, hb.m3, !evenA, tl);
+#endif
+            if (chkA) fold(qA[k], oA);
+            if (chkB) fold(qB[k], oB);
+            store_row(rout, oA.x, oA.y, oA.z, oA.w, laneA, row_off(r));
+            store_row(rout, oB.x, oB.y, oB.z, oB.w, laneB, plane_bytes + row_off(r));
+        };
+        const int nrows = r1 - r0, nfull = nrows & ~3;
+        for (int i = 0; i < nfull; i += 4) {
+#if EPIC_PAIR_BARRIER_ROWS > 0  // experiment: the waves of a workgroup kept within a few rows of each other (they share planes through the caches)
+            if ((i & (EPIC_PAIR_BARRIER_ROWS - 1)) == 0) __builtin_amdgcn_s_barrier();
+#endif
+            step(r0 + i, 0);
+            step(r0 + i + 1, 1);
+            step(r0 + i + 2, 2);
+            step(r0 + i + 3, 3);
+        }
+        // ragged tail: up to three more rows, the same steps behind scalar tests (the rings are in phase: nfull % 4 == 0)
+        if (nrows - nfull > 0) step(r0 + nfull, 0);
+        if (nrows - nfull > 1) step(r0 + nfull + 1, 1);
+        if (nrows - nfull > 2) step(r0 + nfull + 2, 2);
+    }
+
+    if (CHECK) {
+        dmax = wave_max(dmax);
+        if (lane == 0 && dmax > 0.0f &&
+            __float_as_uint(dmax) > __hip_atomic_load(a.delta_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(a.delta_bits, __float_as_uint(dmax));
+    }
+}
+
 // uint32-per-cell mask (m0 x m1 x m2, unpitched) -> lane masks (kernels.h: per x2-row and strip four 64-bit words);
 // faces and padding locked.  One wave per (row, strip), four ballots.
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void pack_mask_3d_kernel(const uint32_t *locked, int m0, int m1, int m2,
@@ -351,6 +540,28 @@ void launch_sweep_3d_math(int math, dim3 grid, dim3 block, hipStream_t stream, c
     if (a.wake.list_out) launch_sweep_3d_track<CHECK, RB, true>(math, grid, block, stream, a, tiles);
     else launch_sweep_3d_track<CHECK, RB, false>(math, grid, block, stream, a, tiles);
 }
+template <bool CHECK, bool RB> void launch_sweep_3d_pair(dim3 block, hipStream_t stream, const Sweep3dArgs &a)
+{
+    auto kernel = sweep3d_pair_kernel<CHECK, RB>;
+    // resident workgroups walk the logical blocks (each stages the 20 KiB table once)
+    const int res = resident_blocks_of((const void *)kernel);
+    const dim3 grid((unsigned)(res > 0 && a.nblocks > res ? res : a.nblocks));
+    hipLaunchKernelGGL(kernel, grid, block, 0, stream, a);
+}
+// EPIC_HIP_3D_PAIR=0: the one-plane-per-wave kernel for every launch (A/B, tests); read per launch, the tests switch it
+bool sweep_3d_pair_enabled()
+{
+    const char *e = getenv("EPIC_HIP_3D_PAIR");
+    return !(e && e[0] == '0');
+}
+// x1-rows per task of the pair kernel (EPIC_HIP_3D_PAIR_ROWS overrides)
+int sweep_3d_pair_rows(int m1)
+{
+    const char *e = getenv("EPIC_HIP_3D_PAIR_ROWS");
+    const int v = e ? atoi(e) : 0;
+    if (v > 0) return v < 4 ? 4 : v > 4096 ? 4096 : v;
+    return m1 < kPairRows ? m1 : kPairRows;
+}
 }  // namespace
 
 // parity < 0: Jacobi (in != out); parity 0 / 1: red-black half-sweep in place (in == out).
@@ -387,6 +598,23 @@ hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, i
     const bool whole = plane_begin == 0 && plane_end == m0;
     const size_t tiles = sweep_3d_tiles(m0, m1, pitch);
     a.wake = wake_args(whole ? act : nullptr, tiles);
+    a.rows = kRowsPerTask;
+    if (math == kMathTol && !a.wake.list_out && !a.wake.list_in && sweep_3d_pair_enabled()) {  // two planes per wave (no work lists)
+        a.rows = sweep_3d_pair_rows(m1);
+        if ((long long)pitch * 4 * (a.rows + 12) + 3LL * m1 * pitch * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
+        a.nchunks = (m1 + a.rows - 1) / a.rows;
+        a.nplane_groups = (plane_end - plane_begin + 2 * kPairWaves - 1) / (2 * kPairWaves);
+        a.nblocks = a.nstrips * a.nchunks * a.nplane_groups;
+        const dim3 block(kWave * kPairWaves);
+        if (parity < 0) {
+            if (delta_bits) launch_sweep_3d_pair<true, false>(block, stream, a);
+            else launch_sweep_3d_pair<false, false>(block, stream, a);
+        } else {
+            if (delta_bits) launch_sweep_3d_pair<true, true>(block, stream, a);
+            else launch_sweep_3d_pair<false, true>(block, stream, a);
+        }
+        return hipGetLastError();
+    }
     const dim3 grid((unsigned)nblocks), block(kWave * kWavesPerBlock);   // (list-driven launches: resized in launch_sweep_3d_track)
     if (parity < 0) {
         if (delta_bits) launch_sweep_3d_math<true, false>(math, grid, block, stream, a, tiles);

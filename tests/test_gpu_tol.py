@@ -108,6 +108,35 @@ def test_tol_iterations_equal_the_checker_bit_for_bit(m, seed, dens, rpt, scheme
             assert gdelta == wdelta
 
 
+PAIR_GRIDS = [([5, 9, 40], 21, 0.05), ([6, 33, 300], 22, 0.08), ([7, 70, 520], 23, 0.05), ([16, 131, 256], 24, 0.05),
+              ([9, 64, 64], 25, 0.10), ([3, 3, 3], 26, 0.0), ([4, 140, 70], 27, 0.05)]
+
+
+@pytest.mark.parametrize("m,seed,dens", PAIR_GRIDS)
+@pytest.mark.parametrize("scheme", [eh.SCHEME_JACOBI, eh.SCHEME_REDBLACK])
+def test_3d_two_planes_per_wave_equals_the_checker_and_the_one_plane_kernel(m, seed, dens, scheme, monkeypatch):
+    """sweep3d_pair_kernel (tol math, no work lists): a wave sweeps two consecutive planes, each the other's neighbour.  Even and
+    odd plane counts (the last wave's second plane is swept and dropped), task heights that leave 0 to 3 rows for the tail,
+    more than one strip, plain and check iterations, both schemes -- against oracle/tol_checker.c and, bit for bit, against
+    the one-plane kernel (EPIC_HIP_3D_PAIR=0)."""
+    u0, locked = with_extra_goals(m, seed, dens)
+    for rows in (0, 4, 7, 33):
+        if rows:
+            monkeypatch.setenv("EPIC_HIP_3D_PAIR_ROWS", str(rows))
+        else:
+            monkeypatch.delenv("EPIC_HIP_3D_PAIR_ROWS", raising=False)
+        for k in (1, 2, 5, 24):
+            want, wdelta = checker_iterations(m, u0, locked, k, scheme)
+            monkeypatch.delenv("EPIC_HIP_3D_PAIR", raising=False)
+            got, gdelta = gpu_iterations(m, u0, locked, k, scheme, 0)
+            assert np.array_equal(got, want), f"{m} scheme {scheme} after {k} iterations, {rows} rows per task"
+            assert gdelta == wdelta
+            if rows == 0:
+                monkeypatch.setenv("EPIC_HIP_3D_PAIR", "0")
+                one, odelta = gpu_iterations(m, u0, locked, k, scheme, 0)
+                assert np.array_equal(one, got) and odelta == gdelta
+
+
 FUSED_GRIDS = [([16, 16], 1, 0.05), ([23, 37], 4, 0.10), ([3, 3], 6, 0.0), ([3, 70], 6, 0.0), ([70, 3], 6, 0.0),
                ([8, 300], 7, 0.05), ([70, 66], 8, 0.30), ([257, 513], 9, 0.05), ([64, 1030], 10, 0.05), ([96, 249], 6, 0.05),
                ([211, 530], 12, 0.06), ([1200, 3000], 5, 0.05)]

@@ -4,12 +4,12 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 for lib in "$@"; do
   export EPIC_LIB=$ROOT/$lib
-  d=$ROOT/gpurun_out/exp3d_$(echo $lib | tr '/' '_')
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$d" -- python3 $ROOT/tools/bench_config.py --grid 512 512 512 --math tol --develop 300 --sweeps 100 > /dev/null 2>&1
+  d=$ROOT/gpurun_out/exp3d_$(echo $lib | tr '/' '_'); rm -rf "$d"
+  rocprofv3 --pmc ${PMC:-FETCH_SIZE} --output-format csv -d "$d" -- python3 $ROOT/tools/bench_config.py --grid 512 512 512 --math tol --develop 300 --sweeps 100 > /dev/null 2>&1
   rd=$(python3 - "$d" <<'PY'
 import csv,glob,sys,statistics
 f=glob.glob(sys.argv[1]+'/**/*_counter_collection.csv',recursive=True)[0]
-v=[float(r['Counter_Value']) for r in csv.DictReader(open(f)) if r['Counter_Name']=='FETCH_SIZE' and 'sweep3d' in r['Kernel_Name']]
+v=[float(r['Counter_Value']) for r in csv.DictReader(open(f)) if r["Counter_Name"] in ("FETCH_SIZE","WRITE_SIZE") and "sweep3d" in r['Kernel_Name']]
 print('%.1f' % (statistics.mean(v)*1024*2/1e6))
 PY
 )

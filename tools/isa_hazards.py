@@ -20,7 +20,7 @@ import argparse
 import re
 import sys
 
-KERNEL_RE = re.compile(r"^(_Z\w*(sweep2d_kernel|sweep3d_kernel|rb_fused2d_kernel|rb_tol_fused2d_kernel|jacobi_fused2d_kernel)\w*):")
+KERNEL_RE = re.compile(r"^(_Z\w*(sweep2d_kernel|sweep3d_kernel|sweep3d_pair_kernel|rb_fused2d_kernel|rb_tol_fused2d_kernel|jacobi_fused2d_kernel)\w*):")
 
 
 def regs(tok):
