@@ -366,7 +366,10 @@ constexpr int kPairWaves = EPIC_PAIR_BLOCK_WAVES;  // waves per workgroup = pair
 constexpr int kPairMinBlocks = EPIC_PAIR_MIN_BLOCKS;
 constexpr int kPairRows = 64;  // x1-rows per task (512^3: 32 rows 273.5 us, 64: 269.7, 128: 268.5, 256: 323 -- too few tasks)
 constexpr int kPairOuterAhead = EPIC_PAIR_OUTER_AHEAD;  // rows the outer planes' loads run ahead of their use (1 or 2)
-template <bool CHECK, bool RB>
+// X0M = false: the pair is two consecutive PLANES (x0, x0 + 1) and the wave marches along x1 (rows of a task's chunk);
+// X0M = true: the pair is two consecutive ROWS (x1, x1 + 1) of a strip and the wave marches along x0, plane by plane -- all
+// workgroups then move through memory together, plane after plane.  "c" below is the pair axis, "t" the march axis.
+template <bool CHECK, bool RB, bool X0M>
 __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pair_kernel(Sweep3dArgs a)
 {
     __shared__ __attribute__((aligned(16))) char math_lds_bytes[TolLn<5>::kLdsBytes];
@@ -379,51 +382,55 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pa
     typedef const __attribute__((address_space(4))) float cfloat;
     typedef const __attribute__((address_space(4))) uint64_t cu64;
     struct RowSide { float l, r; lmask m0, m1, m2, m3; };
+    const size_t pitch = (size_t)a.pitch;
+    const size_t plane = (size_t)a.m1 * pitch;
+    const unsigned plane_bytes = (unsigned)(plane * sizeof(float)), row_bytes = (unsigned)(pitch * sizeof(float));
+    const unsigned cstride = X0M ? row_bytes : plane_bytes, tstride = X0M ? plane_bytes : row_bytes;  // bytes per step of either axis
+    const int c_begin = X0M ? 0 : a.plane_begin, c_end = X0M ? a.m1 : a.plane_end, c_max = (X0M ? a.m1 : a.m0) - 1;
+    const int t_begin = X0M ? a.plane_begin : 0, t_end = X0M ? a.plane_end : a.m1, t_max = (X0M ? a.m0 : a.m1) - 1;
 
     for (int vb = blockIdx.x; vb < a.nblocks; vb += gridDim.x) {
         int b = vb;
         const int strip = b % a.nstrips;
         b /= a.nstrips;
         const int chunk = b % a.nchunks;
-        const int xA_raw = a.plane_begin + ((b / a.nchunks) * kPairWaves + wave) * 2;
+        const int cA_raw = c_begin + ((b / a.nchunks) * kPairWaves + wave) * 2;
 #if EPIC_PAIR_BARRIER_ROWS == 0
-        if (xA_raw >= a.plane_end) continue;             // wave-uniform: the spare waves of the last plane group
+        if (cA_raw >= c_end) continue;                   // wave-uniform: the spare waves of the last group
 #endif
-        const bool has_a = xA_raw < a.plane_end;         // (with barriers the spare waves march along, on the last plane, and store nothing)
-        const int xA = has_a ? xA_raw : a.plane_end - 1;
-        const bool has_b = xA_raw + 1 < a.plane_end;     // an odd plane count: the last wave's second plane is swept and dropped
-        const int xB = min(xA + 1, a.m0 - 1);
-        const int r0 = chunk * a.rows;
-        const int r1 = min(r0 + a.rows, a.m1);
+        const bool has_a = cA_raw < c_end;               // (with barriers the spare waves march along and store nothing)
+        const int cA = has_a ? cA_raw : c_end - 1;
+        const bool has_b = cA_raw + 1 < c_end;           // an odd count: the last wave's second plane / row is swept and dropped
+        const int cB = min(cA + 1, c_max);
+        const int t0 = t_begin + chunk * a.rows;
+        const int t1 = min(t0 + a.rows, t_end);
         const int col0 = strip * kStripCols;
-        const size_t pitch = (size_t)a.pitch;
-        const size_t plane = (size_t)a.m1 * pitch;
-        const int rlast = a.m1 - 1;
-        const int rlo = max(r0 - 4, 0);
-        // one descriptor for the four planes the wave reads, based at the lowest (the launcher keeps them within its 2 GiB)
-        const int xa = max(xA - 1, 0), xb = min(xA + 2, a.m0 - 1);
-        const __amdgpu_buffer_rsrc_t rin = raw_buffer(a.in + (size_t)xa * plane + (size_t)rlo * pitch),
-                                     rout = raw_buffer(a.out + (size_t)xA * plane + (size_t)rlo * pitch);
-        const unsigned plane_bytes = (unsigned)(plane * sizeof(float));
-        const unsigned oa = 0u, ocA = (unsigned)(xA - xa) * plane_bytes, ocB = (unsigned)(xB - xa) * plane_bytes,
-                       ob = (unsigned)(xb - xa) * plane_bytes;
+        const int tlo = max(t0 - 4, 0);
+        // one descriptor for everything the wave reads, based at its lowest address (the launcher keeps that within 2 GiB)
+        const int ca = max(cA - 1, 0), cb = min(cA + 2, c_max);
+        const __amdgpu_buffer_rsrc_t rin = raw_buffer(a.in + ((size_t)ca * cstride + (size_t)tlo * tstride) / sizeof(float)),
+                                     rout = raw_buffer(a.out + ((size_t)cA * cstride + (size_t)tlo * tstride) / sizeof(float));
+        const unsigned oa = 0u, ocA = (unsigned)(cA - ca) * cstride, ocB = (unsigned)(cB - ca) * cstride, ob = (unsigned)(cb - ca) * cstride;
         const unsigned lane16 = (unsigned)lane * 16u;
         const unsigned laneA = has_a ? lane16 : 0x80000000u;  // beyond the descriptor's range: the hardware drops the store
         const unsigned laneB = has_b ? lane16 : 0x80000000u;
-        auto row_off = [&](int r) -> unsigned { return (unsigned)((r - rlo) * a.pitch + col0) * 4u; };  // r already clamped
-        auto ld = [&](unsigned plane_off, int r) -> float4 {
-            r = min(max(r, 0), rlast);
-            const vu4 q = __builtin_amdgcn_raw_buffer_load_b128(rin, lane16, plane_off + row_off(r), 0);
+        auto t_off = [&](int t) -> unsigned { return (unsigned)(t - tlo) * tstride + (unsigned)col0 * 4u; };  // t already clamped
+        auto ld = [&](unsigned c_off, int t) -> float4 {
+            t = min(max(t, 0), t_max);
+            const vu4 q = __builtin_amdgcn_raw_buffer_load_b128(rin, lane16, c_off + t_off(t), 0);
             return make_float4(u2f(q.x), u2f(q.y), u2f(q.z), u2f(q.w));
         };
         const int hcol_l = max(col0 - 1, 0), hcol_r = min(col0 + kStripCols, a.pitch - 1);
-        auto side = [&](int x, int r) -> RowSide {
-            r = min(max(r, 0), rlast);
-            cfloat *row = (cfloat *)(a.in + (size_t)x * plane + (size_t)r * pitch);
-            cu64 *mk = (cu64 *)a.maskw + (((size_t)x * a.m1 + r) * a.nstrips + strip) * 4;
+        auto side = [&](int c, int t) -> RowSide {
+            t = min(max(t, 0), t_max);
+            const int x0 = X0M ? t : c, x1 = X0M ? c : t;
+            cfloat *row = (cfloat *)(a.in + (size_t)x0 * plane + (size_t)x1 * pitch);
+            cu64 *mk = (cu64 *)a.maskw + (((size_t)x0 * a.m1 + x1) * a.nstrips + strip) * 4;
             return RowSide{row[hcol_l], row[hcol_r], mk[0], mk[1], mk[2], mk[3]};
         };
-        const bool chkA = CHECK && has_a && xA >= a.check_lo && xA < a.check_hi, chkB = CHECK && has_b && xB >= a.check_lo && xB < a.check_hi;
+        // planes [check_lo, check_hi) count for max |du|: a property of the pair (x1-march) or of the step (x0-march)
+        const bool chkA = CHECK && has_a && (X0M || (cA >= a.check_lo && cA < a.check_hi)),
+                   chkB = CHECK && has_b && (X0M || (cB >= a.check_lo && cB < a.check_hi));
         auto fold = [&](const float4 &c, const float4 &o) {
             dmax = max2(dmax, fabsf(c.x - o.x));
             dmax = max2(dmax, fabsf(c.y - o.y));
@@ -431,59 +438,69 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pa
             dmax = max2(dmax, fabsf(c.w - o.w));
         };
 
-        // rings, rotated through constant indices of fully unrolled steps (no moves): the two planes' rows 2 ahead over four
-        // sets (rows j - 1, j, j + 1 in use, j + 2 in flight), their splits likewise, the outer planes' rows 2 ahead
+        // rings, rotated through constant indices of fully unrolled steps (no moves): the pair's rows 2 ahead over four sets
+        // (steps j - 1, j, j + 1 in use, j + 2 in flight), their splits likewise, the outer rows 2 ahead
         float4 qA[4], qB[4], pa[4], pb[4];
         Split4 sA[4], sB[4];
         RowSide hA[2], hB[2];
-        // slot of row r0 + j: j & 3 (sides: j & 1); row r0 - 1 sits in slot 3
-        qA[3] = ld(ocA, r0 - 1); qB[3] = ld(ocB, r0 - 1);
-        qA[0] = ld(ocA, r0); qB[0] = ld(ocB, r0);
-        qA[1] = ld(ocA, r0 + 1); qB[1] = ld(ocB, r0 + 1);
-        pa[0] = ld(oa, r0); pb[0] = ld(ob, r0);
-        if (kPairOuterAhead > 1) { pa[1] = ld(oa, r0 + 1); pb[1] = ld(ob, r0 + 1); }
-        hA[0] = side(xA, r0); hB[0] = side(xB, r0);
+        // slot of step t0 + j: j & 3 (sides: j & 1); step t0 - 1 sits in slot 3
+        qA[3] = ld(ocA, t0 - 1); qB[3] = ld(ocB, t0 - 1);
+        qA[0] = ld(ocA, t0); qB[0] = ld(ocB, t0);
+        qA[1] = ld(ocA, t0 + 1); qB[1] = ld(ocB, t0 + 1);
+        pa[0] = ld(oa, t0); pb[0] = ld(ob, t0);
+        if (kPairOuterAhead > 1) { pa[1] = ld(oa, t0 + 1); pb[1] = ld(ob, t0 + 1); }
+        hA[0] = side(cA, t0); hB[0] = side(cB, t0);
         sA[3] = tol_split4(qA[3]); sB[3] = tol_split4(qB[3]);
         sA[0] = tol_split4(qA[0]); sB[0] = tol_split4(qB[0]);
 
-        auto step = [&](int r, const int k) {  // k = (r - r0) & 3, a constant in every expansion
+        auto step = [&](int t, const int k) {  // k = (t - t0) & 3, a constant in every expansion
             const int km = (k + 3) & 3, kp = (k + 1) & 3, kn = (k + 2) & 3;
             const int ko = (k + kPairOuterAhead) & 3;
-            qA[kn] = ld(ocA, r + 2); qB[kn] = ld(ocB, r + 2); pa[ko] = ld(oa, r + kPairOuterAhead); pb[ko] = ld(ob, r + kPairOuterAhead);
-            hA[kp & 1] = side(xA, r + 1); hB[kp & 1] = side(xB, r + 1);
+            qA[kn] = ld(ocA, t + 2); qB[kn] = ld(ocB, t + 2); pa[ko] = ld(oa, t + kPairOuterAhead); pb[ko] = ld(ob, t + kPairOuterAhead);
+            hA[kp & 1] = side(cA, t + 1); hB[kp & 1] = side(cB, t + 1);
             sA[kp] = tol_split4(qA[kp]); sB[kp] = tol_split4(qB[kp]);
             const Split4 so_a = tol_split4(pa[k]), so_b = tol_split4(pb[k]);
-            const bool evenA = !RB || ((xA + r + a.parity) & 1) == 0;  // scalar; plane B has the other colour pattern
+            const bool evenA = !RB || ((cA + t + a.parity) & 1) == 0;  // scalar; B has the other colour pattern
             const RowSide &ha = hA[k & 1], &hb = hB[k & 1];
 #ifdef EPIC_EXP3D_TRAFFIC  // timing experiment only (wrong results): the loads and stores of the sweep, no arithmetic
             auto mx4 = [](const float4 &x, const float4 &y) { return make_float4(max2(x.x, y.x), max2(x.y, y.y), max2(x.z, y.z), max2(x.w, y.w)); };
             const float4 oA = mx4(mx4(qA[km], qA[kp]), mx4(pa[k], qB[k])), oB = mx4(mx4(qB[km], qB[kp]), mx4(pb[k], qA[k]));
             (void)so_a; (void)so_b; (void)evenA; (void)ha; (void)hb;
 #else
-            const float4 oA = tol_row_3d<RB>(pa[k], qB[k], qA[km], qA[k], qA[kp], so_a, sB[k], sA[km], sA[k], sA[kp], ha.l, ha.r,
-                                             ha.m0, ha.m1, ha.m2, ha.m3, evenA, tl);
-            const float4 oB = tol_row_3d<RB>(qA[k], pb[k], qB[km], qB[k], qB[kp], sA[k], so_b, sB[km], sB[k], sB[kp], hb.l, hb.r,
-                                             hb.m0, hb.m1, hb.m2, hb.m3, !evenA, tl);
+            // the reference's order of the six neighbours: x0 - 1, x0 + 1, x1 - 1, x1 + 1, (x2 - 1, x2 + 1 inside tol_row_3d)
+            float4 oA, oB;
+            if (!X0M) {  // pair axis = x0, ring = x1
+                oA = tol_row_3d<RB>(pa[k], qB[k], qA[km], qA[k], qA[kp], so_a, sB[k], sA[km], sA[k], sA[kp], ha.l, ha.r,
+                                    ha.m0, ha.m1, ha.m2, ha.m3, evenA, tl);
+                oB = tol_row_3d<RB>(qA[k], pb[k], qB[km], qB[k], qB[kp], sA[k], so_b, sB[km], sB[k], sB[kp], hb.l, hb.r,
+                                    hb.m0, hb.m1, hb.m2, hb.m3, !evenA, tl);
+            } else {     // ring = x0, pair axis = x1
+                oA = tol_row_3d<RB>(qA[km], qA[kp], pa[k], qA[k], qB[k], sA[km], sA[kp], so_a, sA[k], sB[k], ha.l, ha.r,
+                                    ha.m0, ha.m1, ha.m2, ha.m3, evenA, tl);
+                oB = tol_row_3d<RB>(qB[km], qB[kp], qA[k], qB[k], pb[k], sB[km], sB[kp], sA[k], sB[k], so_b, hb.l, hb.r,
+                                    hb.m0, hb.m1, hb.m2, hb.m3, !evenA, tl);
+            }
 #endif
-            if (chkA) fold(qA[k], oA);
-            if (chkB) fold(qB[k], oB);
-            store_row(rout, oA.x, oA.y, oA.z, oA.w, laneA, row_off(r));
-            store_row(rout, oB.x, oB.y, oB.z, oB.w, laneB, plane_bytes + row_off(r));
+            const bool chk_t = !X0M || (t >= a.check_lo && t < a.check_hi);  // scalar
+            if (chkA && chk_t) fold(qA[k], oA);
+            if (chkB && chk_t) fold(qB[k], oB);
+            store_row(rout, oA.x, oA.y, oA.z, oA.w, laneA, t_off(t));
+            store_row(rout, oB.x, oB.y, oB.z, oB.w, laneB, cstride + t_off(t));
         };
-        const int nrows = r1 - r0, nfull = nrows & ~3;
+        const int nsteps = t1 - t0, nfull = nsteps & ~3;
         for (int i = 0; i < nfull; i += 4) {
-#if EPIC_PAIR_BARRIER_ROWS > 0  // experiment: the waves of a workgroup kept within a few rows of each other (they share planes through the caches)
+#if EPIC_PAIR_BARRIER_ROWS > 0  // experiment: the waves of a workgroup kept within a few steps of each other (they share rows through the caches)
             if ((i & (EPIC_PAIR_BARRIER_ROWS - 1)) == 0) __builtin_amdgcn_s_barrier();
 #endif
-            step(r0 + i, 0);
-            step(r0 + i + 1, 1);
-            step(r0 + i + 2, 2);
-            step(r0 + i + 3, 3);
+            step(t0 + i, 0);
+            step(t0 + i + 1, 1);
+            step(t0 + i + 2, 2);
+            step(t0 + i + 3, 3);
         }
-        // ragged tail: up to three more rows, the same steps behind scalar tests (the rings are in phase: nfull % 4 == 0)
-        if (nrows - nfull > 0) step(r0 + nfull, 0);
-        if (nrows - nfull > 1) step(r0 + nfull + 1, 1);
-        if (nrows - nfull > 2) step(r0 + nfull + 2, 2);
+        // ragged tail: up to three more steps behind scalar tests (the rings are in phase: nfull % 4 == 0)
+        if (nsteps - nfull > 0) step(t0 + nfull, 0);
+        if (nsteps - nfull > 1) step(t0 + nfull + 1, 1);
+        if (nsteps - nfull > 2) step(t0 + nfull + 2, 2);
     }
 
     if (CHECK) {
@@ -540,13 +557,24 @@ void launch_sweep_3d_math(int math, dim3 grid, dim3 block, hipStream_t stream, c
     if (a.wake.list_out) launch_sweep_3d_track<CHECK, RB, true>(math, grid, block, stream, a, tiles);
     else launch_sweep_3d_track<CHECK, RB, false>(math, grid, block, stream, a, tiles);
 }
-template <bool CHECK, bool RB> void launch_sweep_3d_pair(dim3 block, hipStream_t stream, const Sweep3dArgs &a)
+template <bool CHECK, bool RB, bool X0M> void launch_sweep_3d_pair_axis(dim3 block, hipStream_t stream, const Sweep3dArgs &a)
 {
-    auto kernel = sweep3d_pair_kernel<CHECK, RB>;
+    auto kernel = sweep3d_pair_kernel<CHECK, RB, X0M>;
     // resident workgroups walk the logical blocks (each stages the 20 KiB table once)
     const int res = resident_blocks_of((const void *)kernel);
     const dim3 grid((unsigned)(res > 0 && a.nblocks > res ? res : a.nblocks));
     hipLaunchKernelGGL(kernel, grid, block, 0, stream, a);
+}
+template <bool CHECK, bool RB> void launch_sweep_3d_pair(dim3 block, hipStream_t stream, const Sweep3dArgs &a, bool x0m)
+{
+    if (x0m) launch_sweep_3d_pair_axis<CHECK, RB, true>(block, stream, a);
+    else launch_sweep_3d_pair_axis<CHECK, RB, false>(block, stream, a);
+}
+// EPIC_HIP_3D_MARCH=x0|x1: the axis the pair kernel marches along (x1: pairs of planes; x0: pairs of rows)
+bool sweep_3d_pair_x0_march()
+{
+    const char *e = getenv("EPIC_HIP_3D_MARCH");
+    return e && e[0] == 'x' && e[1] == '0';
 }
 // EPIC_HIP_3D_PAIR=0: the one-plane-per-wave kernel for every launch (A/B, tests); read per launch, the tests switch it
 bool sweep_3d_pair_enabled()
@@ -600,18 +628,25 @@ hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, i
     a.wake = wake_args(whole ? act : nullptr, tiles);
     a.rows = kRowsPerTask;
     if (math == kMathTol && !a.wake.list_out && !a.wake.list_in && sweep_3d_pair_enabled()) {  // two planes per wave (no work lists)
-        a.rows = sweep_3d_pair_rows(m1);
-        if ((long long)pitch * 4 * (a.rows + 12) + 3LL * m1 * pitch * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
-        a.nchunks = (m1 + a.rows - 1) / a.rows;
-        a.nplane_groups = (plane_end - plane_begin + 2 * kPairWaves - 1) / (2 * kPairWaves);
-        a.nblocks = a.nstrips * a.nchunks * a.nplane_groups;
+        bool x0m = sweep_3d_pair_x0_march();
+        const long long plane_b = (long long)m1 * pitch * 4, row_b = (long long)pitch * 4;
+        a.rows = sweep_3d_pair_rows(x0m ? plane_end - plane_begin : m1);
+        // 32-bit byte offsets from one descriptor: the task's steps along the march axis and four steps of the pair axis
+        if (x0m && plane_b * (a.rows + 12) + 3 * row_b > 0x7fffffffLL) x0m = false, a.rows = sweep_3d_pair_rows(m1);
+        if (!x0m && row_b * (a.rows + 12) + 3 * plane_b > 0x7fffffffLL) return hipErrorInvalidValue;
+        const int march = x0m ? plane_end - plane_begin : m1, pairs = x0m ? m1 : plane_end - plane_begin;
+        a.nchunks = (march + a.rows - 1) / a.rows;
+        a.nplane_groups = (pairs + 2 * kPairWaves - 1) / (2 * kPairWaves);
+        const long long nb = (long long)a.nstrips * a.nchunks * a.nplane_groups;
+        if (nb > 0x7fffffffLL) return hipErrorInvalidValue;
+        a.nblocks = (int)nb;
         const dim3 block(kWave * kPairWaves);
         if (parity < 0) {
-            if (delta_bits) launch_sweep_3d_pair<true, false>(block, stream, a);
-            else launch_sweep_3d_pair<false, false>(block, stream, a);
+            if (delta_bits) launch_sweep_3d_pair<true, false>(block, stream, a, x0m);
+            else launch_sweep_3d_pair<false, false>(block, stream, a, x0m);
         } else {
-            if (delta_bits) launch_sweep_3d_pair<true, true>(block, stream, a);
-            else launch_sweep_3d_pair<false, true>(block, stream, a);
+            if (delta_bits) launch_sweep_3d_pair<true, true>(block, stream, a, x0m);
+            else launch_sweep_3d_pair<false, true>(block, stream, a, x0m);
         }
         return hipGetLastError();
     }

@@ -114,11 +114,14 @@ PAIR_GRIDS = [([5, 9, 40], 21, 0.05), ([6, 33, 300], 22, 0.08), ([7, 70, 520], 2
 
 @pytest.mark.parametrize("m,seed,dens", PAIR_GRIDS)
 @pytest.mark.parametrize("scheme", [eh.SCHEME_JACOBI, eh.SCHEME_REDBLACK])
-def test_3d_two_planes_per_wave_equals_the_checker_and_the_one_plane_kernel(m, seed, dens, scheme, monkeypatch):
+@pytest.mark.parametrize("march", ["x1", "x0"])
+def test_3d_two_planes_per_wave_equals_the_checker_and_the_one_plane_kernel(m, seed, dens, scheme, march, monkeypatch):
     """sweep3d_pair_kernel (tol math, no work lists): a wave sweeps two consecutive planes, each the other's neighbour.  Even and
     odd plane counts (the last wave's second plane is swept and dropped), task heights that leave 0 to 3 rows for the tail,
     more than one strip, plain and check iterations, both schemes -- against oracle/tol_checker.c and, bit for bit, against
-    the one-plane kernel (EPIC_HIP_3D_PAIR=0)."""
+    the one-plane kernel (EPIC_HIP_3D_PAIR=0).  march x0: the same kernel with the axes exchanged -- pairs of rows, marching
+    from plane to plane (EPIC_HIP_3D_MARCH)."""
+    monkeypatch.setenv("EPIC_HIP_3D_MARCH", march)
     u0, locked = with_extra_goals(m, seed, dens)
     for rows in (0, 4, 7, 33):
         if rows:
