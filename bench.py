@@ -22,7 +22,10 @@ is timed beside it (`kernels.precise`), and `relax_default` is the whole relaxat
 Prints ONE JSON line on rank 0.  Extra objects:
   roofline      dominant kernel (sweep2d) vs the HBM roofline: 8 algorithmic bytes per grid cell per sweep
                 (read u once, write u once) / mean launch-to-launch device time, measured with HIP
-                events on the stream the kernels run on (epic_hip_timed_sweeps_gpu).
+                events on the stream the kernels run on (epic_hip_timed_sweeps_gpu).  `traffic` = HBM bytes per launch
+                from the PMC counters, measured in the run itself at N = 1: before this process touches the GPU it runs
+                itself twice as a child under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (one short step each);
+                `traffic_source` says so, or names the recorded fallback (profiles/hbm_traffic.json).
   cpu_baseline  the reference's own harmonic_cpu.cpp compiled by oracle/Makefile (oracle/_ref/libepic_ref.so, kind
                 "reference") or, when that did not travel with the repo, its C restatement (oracle/liboracle.so, kind
                 "port"); 1 thread -- the reference is single-threaded -- timed on this host for a bounded number of
@@ -89,6 +92,9 @@ def parse():
     ap.add_argument("--in-library-child", type=int, default=0,
                     help="(internal) run only the in-library multi-device leg on devices 0..N-1 and print its JSON object: the N > 1 "
                          "run starts it as a child process, so that a fault in that never-yet-run path cannot take the headline line with it")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes of this command before "
+                         "the timed part, N = 1); use the value recorded in profiles/hbm_traffic.json")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity object (maps, 512^2 / 1024^2, 512^3 relaxations)")
     return ap.parse_args()
 
@@ -234,9 +240,64 @@ def measured_traffic(n, math, scheme):
         return None
 
 
+def live_traffic(args):
+    """HBM bytes per launch of every sweep kernel of THIS command, measured now: two child processes, each this same script
+    under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (counters in passes of their own, nothing else traced, the
+    program itself behind `--`: MI355X_MICROARCH.md, HBM section) for one short step on a developed field, before this
+    process has touched the GPU.  Returns ({kernel-name fragment: bytes per launch}, note) -- empty dict when the profiler
+    is not there or a pass fails (the caller then falls back to the recorded value and says so)."""
+    import csv
+    import glob
+    import shutil
+    import statistics
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}, "rocprofv3 not found"
+    out, counts = {}, {}
+    tmp = tempfile.mkdtemp(prefix="epic_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--gpus", "1", "--steps", "1", "--warmup", "1", "--develop", "200", "--size", str(args.size),
+                   "--stagger", str(args.stagger), "--math", args.math, "--scheme", args.scheme,
+                   "--rows-per-task", str(args.rows_per_task), "--no-cpu", "--no-relax", "--no-extra-legs", "--no-parity",
+                   "--no-live-traffic"] + (["--track"] if args.track else [])
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
+            files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {}, "rocprofv3 --pmc %s pass failed (rc %d)" % (counter, r.returncode)
+            per = {}
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] != counter:
+                    continue
+                for key in ("jacobi_fused2d_kernel", "rb_tol_fused2d_kernel", "rb_fused2d_kernel", "sweep2d_kernel"):
+                    if key in row["Kernel_Name"]:
+                        per.setdefault(key, []).append(float(row["Counter_Value"]))
+                        break
+            for key, vals in per.items():
+                # counter unit KiB; FETCH_SIZE under-reports streaming reads by 2 on gfx950 (the guide's correction)
+                out[key] = out.get(key, 0.0) + statistics.mean(vals) * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0)
+                counts[key] = min(counts.get(key, 1 << 30), len(vals))
+    except (OSError, subprocess.SubprocessError, ValueError, KeyError) as exc:
+        return {}, "live PMC measurement failed: %r" % (exc,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {k: int(round(v)) for k, v in out.items()}, counts
+
+
 def main():
     args = parse()
     import numpy as np
+
+    live, live_note = {}, "not measured in this run"
+    if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and not args.no_live_traffic and not args.in_library_child
+            and not args.slab):
+        live, live_note = live_traffic(args)   # child processes, before anything here initialises the GPU
     import torch  # first: one HIP runtime per process (epic_amd/epic_harmonic.py)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -359,13 +420,22 @@ def main():
         8(d): 8 B per cell per iteration)."""
         achieved = BYTES_PER_CELL_SWEEP * cells_per_launch * per_pass / (launch_us * 1e-6) / 1e9
         fused = per_pass == 2
-        traffic = measured_traffic(n, math, scheme + ("_fused" if fused else "")) if single_device_full_grid else None
         kernel = (("jacobi_fused2d_kernel" if scheme == "jacobi" else "rb_tol_fused2d_kernel" if math == "tol" else "rb_fused2d_kernel")
                   if fused else "sweep2d_kernel")
+        traffic, source = None, None
+        if single_device_full_grid and math == args.math and scheme == args.scheme and kernel in live:
+            traffic = live[kernel]
+            source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + --pmc WRITE_SIZE, separate child passes of "
+                      "this command, mean over %d launches of the kernel" % live_note.get(kernel, 0))
+        elif single_device_full_grid:
+            traffic = measured_traffic(n, math, scheme + ("_fused" if fused else ""))
+            if traffic is not None:
+                source = ("recorded: profiles/hbm_traffic.json (an earlier PMC run of this command; live measurement: %s)"
+                          % (live_note if isinstance(live_note, str) else "not for this kernel"))
         hbm_measured = None if traffic is None else traffic / (launch_us * 1e-6) / 1e9
         return {
             "bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "launch_us": round(launch_us, 3),
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": source, "launch_us": round(launch_us, 3),
             # `frac` prices the ALGORITHMIC bytes (SURVEY.md section 8d: 8 B per cell per iteration).  What the kernel really
             # moves through HBM is `traffic`; that rate against the same peak is this:
             "hbm_frac_measured": None if hbm_measured is None else round(hbm_measured / HBM_PEAK_GBPS, 4),
@@ -378,9 +448,8 @@ def main():
                     + ("; the fused pass performs two iterations per launch while moving the field through HBM once, so its real "
                        "HBM rate (hbm_frac_measured) is about half of frac and the kernel is bound by VALU issue, not by HBM"
                        if fused else "")
-                    + ("; traffic = PMC FETCH_SIZE x2 + WRITE_SIZE per launch of this command (rocprofv3 --pmc, separate passes), "
-                       "recorded in profiles/hbm_traffic.json with the summaries it comes from -- bench.py cannot run under the "
-                       "profiler itself" if traffic is not None else "; traffic: no PMC measurement of this configuration on file"),
+                    + ("; traffic = HBM bytes per launch from the PMC counters, FETCH_SIZE x2 + WRITE_SIZE (see traffic_source)"
+                       if traffic is not None else "; traffic: no PMC measurement of this configuration"),
         }
 
     if args.in_library_child > 0:
@@ -546,7 +615,7 @@ def main():
                               "math": args.math, "us_per_sweep": round(us3, 2),
                               "Mcell_updates_per_s": round(int((l3 == 0).sum()) / us3, 1),
                               "frac": round(BYTES_PER_CELL_SWEEP * 512 ** 3 / (us3 * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
-                              "kernel": "sweep3d_kernel", "developed_sweeps": 1600, "sweeps": 300}
+                              "kernel": "sweep3d_pair_kernel" if args.math == "tol" and os.environ.get("EPIC_HIP_3D_PAIR", "1")[:1] != "0" else "sweep3d_kernel", "developed_sweeps": 1600, "sweeps": 300}
             del u3, l3
         if not args.no_parity:
             out["parity"] = parity_object(args, E, MODES, relaxed, locked)

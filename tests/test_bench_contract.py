@@ -56,8 +56,9 @@ def test_single_gpu_line_roofline_is_the_fused_pass_and_has_a_cpu_baseline():
     assert abs(r["hbm_GBps_measured"] - r["traffic"] / (r["launch_us"] * 1e-6) / 1e9) < 0.01 * r["hbm_GBps_measured"]
     assert abs(r["hbm_frac_measured"] - r["hbm_GBps_measured"] / r["peak"]) < 1e-3 and r["hbm_frac_measured"] < r["frac"]
     assert r["limiter"] == "valu"
-    traffic = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-    assert r["traffic"] == traffic["8192_tol_jacobi_fused"]
+    # traffic is measured in the run itself (two rocprofv3 --pmc child passes) and agrees with the profiling round's summary
+    recorded = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))["8192_tol_jacobi_fused"]
+    assert r["traffic_source"].startswith("measured in this run") and abs(r["traffic"] - recorded) < 0.03 * recorded
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
