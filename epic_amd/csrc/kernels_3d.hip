@@ -42,10 +42,11 @@ struct Sweep3dArgs {
     int m0, m1, pitch;
     int plane_begin, plane_end;
     int nstrips, nchunks, nplane_groups;
-    int nblocks;  // logical blocks: nstrips * nchunks * nplane_groups (a tol launch holds fewer workgroups, which walk them)
+    int nblocks;  // logical blocks: nstrips * 8 cpx * nplane_groups (a tol launch holds fewer workgroups, which walk them)
     int check_lo, check_hi;  // CHECK: only planes [check_lo, check_hi) count for max |du| (a slab's ghost planes do not)
     int parity;  // red-black scheme only: currentIteration & 1
     int rows;    // sweep3d_pair_kernel: x1-rows per task
+    int cpx;     // chunks per XCD = ceil(nchunks / 8): block order of the launches without work lists
     WakeArgs wake;  // TRACK kernels, whole-grid launches only
 };
 
@@ -155,11 +156,14 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB
         chunk = t % a.nchunks;
         x0 = t / a.nchunks;
     } else {
-        int b = vb;
-        strip = b % a.nstrips;
-        b /= a.nstrips;
-        chunk = b % a.nchunks;
-        x0 = a.plane_begin + (b / a.nchunks) * kWavesPerBlock + wave;
+        // XCD-aware order (workgroup vb runs on XCD vb % 8): the strips of a row and the neighbouring plane groups share one L2,
+        // the chunk selects the XCD (see sweep3d_pair_kernel)
+        int j = vb >> 3;
+        chunk = (vb & 7) + 8 * (j % a.cpx);
+        j /= a.cpx;
+        strip = j % a.nstrips;
+        x0 = a.plane_begin + (j / a.nstrips) * kWavesPerBlock + wave;
+        if (chunk >= a.nchunks) x0 = a.plane_end;  // padding of the chunk count to a multiple of 8: a spare block
     }
     if (x0 >= a.plane_end) {  // wave-uniform: the spare waves of the last plane group
         if (listed) break;
@@ -390,11 +394,16 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pa
     const int t_begin = X0M ? a.plane_begin : 0, t_end = X0M ? a.plane_end : a.m1, t_max = (X0M ? a.m0 : a.m1) - 1;
 
     for (int vb = blockIdx.x; vb < a.nblocks; vb += gridDim.x) {
-        int b = vb;
-        const int strip = b % a.nstrips;
-        b /= a.nstrips;
-        const int chunk = b % a.nchunks;
-        const int cA_raw = c_begin + ((b / a.nchunks) * kPairWaves + wave) * 2;
+        // XCD-aware order: workgroup vb runs on XCD vb % 8 (round-robin dispatch; the grid is a multiple of 8), and everything that
+        // shares rows goes to ONE XCD's L2 -- the strips of a row (each fetches its neighbour's edge cell: with the strips on
+        // different XCDs that was a 128-byte line from HBM per 4 bytes used, 12 % of the sweep's reads) and the neighbouring
+        // plane groups.  The chunk selects the XCD.
+        int j = vb >> 3;
+        const int chunk = (vb & 7) + 8 * (j % a.cpx);
+        if (chunk >= a.nchunks) continue;                // wave-uniform (padding of the chunk count to a multiple of 8)
+        j /= a.cpx;
+        const int strip = j % a.nstrips;
+        const int cA_raw = c_begin + ((j / a.nstrips) * kPairWaves + wave) * 2;
 #if EPIC_PAIR_BARRIER_ROWS == 0
         if (cA_raw >= c_end) continue;                   // wave-uniform: the spare waves of the last group
 #endif
@@ -562,7 +571,7 @@ template <bool CHECK, bool RB, bool X0M> void launch_sweep_3d_pair_axis(dim3 blo
     auto kernel = sweep3d_pair_kernel<CHECK, RB, X0M>;
     // resident workgroups walk the logical blocks (each stages the 20 KiB table once)
     const int res = resident_blocks_of((const void *)kernel);
-    const dim3 grid((unsigned)(res > 0 && a.nblocks > res ? res : a.nblocks));
+    const dim3 grid((unsigned)(res >= 8 && a.nblocks > res ? res / 8 * 8 : a.nblocks));   // a multiple of 8: vb % 8 is the XCD
     hipLaunchKernelGGL(kernel, grid, block, 0, stream, a);
 }
 template <bool CHECK, bool RB> void launch_sweep_3d_pair(dim3 block, hipStream_t stream, const Sweep3dArgs &a, bool x0m)
@@ -617,7 +626,8 @@ hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, i
     a.nstrips = (pitch + kStripCols - 1) / kStripCols;
     a.nchunks = (m1 + kRowsPerTask - 1) / kRowsPerTask;
     a.nplane_groups = (plane_end - plane_begin + kWavesPerBlock - 1) / kWavesPerBlock;
-    const long long nblocks = (long long)a.nstrips * a.nchunks * a.nplane_groups;
+    a.cpx = (a.nchunks + 7) / 8;
+    const long long nblocks = 8LL * a.cpx * a.nstrips * a.nplane_groups;   // chunks padded to whole rounds of the 8 XCDs
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
     a.nblocks = (int)nblocks;
     a.check_lo = check_begin < 0 ? plane_begin : check_begin;
@@ -637,7 +647,8 @@ hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, i
         const int march = x0m ? plane_end - plane_begin : m1, pairs = x0m ? m1 : plane_end - plane_begin;
         a.nchunks = (march + a.rows - 1) / a.rows;
         a.nplane_groups = (pairs + 2 * kPairWaves - 1) / (2 * kPairWaves);
-        const long long nb = (long long)a.nstrips * a.nchunks * a.nplane_groups;
+        a.cpx = (a.nchunks + 7) / 8;
+        const long long nb = 8LL * a.cpx * a.nstrips * a.nplane_groups;   // chunks padded to whole rounds of the 8 XCDs
         if (nb > 0x7fffffffLL) return hipErrorInvalidValue;
         a.nblocks = (int)nb;
         const dim3 block(kWave * kPairWaves);
