@@ -874,7 +874,7 @@ bool multi_plan(Ctx *c)
                   hipEventCreateWithFlags(&sl.ev_band, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&sl.ev_comm, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&sl.ev_stage, hipEventDisableTiming) == hipSuccess &&
-                  hipHostMalloc((void **)&sl.h_delta, 64, hipHostMallocDefault) == hipSuccess;
+                  hipHostMalloc((void **)&sl.h_delta, 64, hipHostMallocPortable) == hipSuccess;
         if (!ok) {
             (void)hipGetLastError();
             multi_destroy(c);
@@ -905,8 +905,8 @@ bool multi_plan(Ctx *c)
             sl.peer_up = direct;
             if (!direct) {   // one pinned buffer per direction across this seam
                 const size_t bytes = (size_t)halo * (c->n == 2 ? 1 : c->m[1]) * c->pitch * sizeof(float);
-                if (hipHostMalloc((void **)&sl.bounce[0], bytes, hipHostMallocDefault) != hipSuccess ||
-                    hipHostMalloc((void **)&sl.bounce[1], bytes, hipHostMallocDefault) != hipSuccess) {
+                if (hipHostMalloc((void **)&sl.bounce[0], bytes, hipHostMallocPortable) != hipSuccess ||
+                    hipHostMalloc((void **)&sl.bounce[1], bytes, hipHostMallocPortable) != hipSuccess) {
                     (void)hipGetLastError();
                     multi_destroy(c);
                     return false;
