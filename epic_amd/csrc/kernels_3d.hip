@@ -383,9 +383,8 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pa
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float dmax = 0.0f;
     typedef unsigned vu4 __attribute__((ext_vector_type(4)));
-    typedef const __attribute__((address_space(4))) float cfloat;
     typedef const __attribute__((address_space(4))) uint64_t cu64;
-    struct RowSide { float l, r; lmask m0, m1, m2, m3; };
+    struct RowSide { lmask m0, m1, m2, m3; };
     const size_t pitch = (size_t)a.pitch;
     const size_t plane = (size_t)a.m1 * pitch;
     const unsigned plane_bytes = (unsigned)(plane * sizeof(float)), row_bytes = (unsigned)(pitch * sizeof(float));
@@ -429,13 +428,27 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pa
             const vu4 q = __builtin_amdgcn_raw_buffer_load_b128(rin, lane16, c_off + t_off(t), 0);
             return make_float4(u2f(q.x), u2f(q.y), u2f(q.z), u2f(q.w));
         };
+        // The two strip-edge cells of a row (they belong to the neighbouring strips) come through the VECTOR path like the rows
+        // themselves: one dword load in which lane 0 fetches the cell left of the strip and lane 63 the one right of it -- exactly
+        // the lanes whose wave shifts take them as the edge operand.  (As scalar loads -- two per row and plane, as in
+        // sweep3d_kernel -- they cost 6 % of the sweep, measured: every wait for a table read, lgkmcnt-counted like them, also
+        // waited for the scalar loads just issued for the next step.  profiles/r03_experiments.txt item 8.)
         const int hcol_l = max(col0 - 1, 0), hcol_r = min(col0 + kStripCols, a.pitch - 1);
+        const unsigned lane_e = lane == 0 ? (unsigned)hcol_l * 4u : lane == 63 ? (unsigned)hcol_r * 4u : (unsigned)col0 * 4u + lane16;
+        auto eld = [&](unsigned c_off, int t) -> float {
+            t = min(max(t, 0), t_max);
+            return u2f(__builtin_amdgcn_raw_buffer_load_b32(rin, lane_e, c_off + (unsigned)(t - tlo) * tstride, 0));
+        };
         auto side = [&](int c, int t) -> RowSide {
             t = min(max(t, 0), t_max);
             const int x0 = X0M ? t : c, x1 = X0M ? c : t;
-            cfloat *row = (cfloat *)(a.in + (size_t)x0 * plane + (size_t)x1 * pitch);
             cu64 *mk = (cu64 *)a.maskw + (((size_t)x0 * a.m1 + x1) * a.nstrips + strip) * 4;
-            return RowSide{row[hcol_l], row[hcol_r], mk[0], mk[1], mk[2], mk[3]};
+#ifdef EPIC_EXP3D_NOSIDE  // timing experiment only (wrong results): no scalar loads per row
+            (void)mk;
+            return RowSide{0, 0, 0, 0};
+#else
+            return RowSide{mk[0], mk[1], mk[2], mk[3]};
+#endif
         };
         // planes [check_lo, check_hi) count for max |du|: a property of the pair (x1-march) or of the step (x0-march)
         const bool chkA = CHECK && has_a && (X0M || (cA >= a.check_lo && cA < a.check_hi)),
@@ -450,12 +463,15 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pa
         // rings, rotated through constant indices of fully unrolled steps (no moves): the pair's rows 2 ahead over four sets
         // (steps j - 1, j, j + 1 in use, j + 2 in flight), their splits likewise, the outer rows 2 ahead
         float4 qA[4], qB[4], pa[4], pb[4];
+        float eA[4], eB[4];   // strip-edge cells of the owned rows (lane 0: left, lane 63: right)
         Split4 sA[4], sB[4];
         RowSide hA[2], hB[2];
         // slot of step t0 + j: j & 3 (sides: j & 1); step t0 - 1 sits in slot 3
         qA[3] = ld(ocA, t0 - 1); qB[3] = ld(ocB, t0 - 1);
         qA[0] = ld(ocA, t0); qB[0] = ld(ocB, t0);
+        eA[0] = eld(ocA, t0); eB[0] = eld(ocB, t0);
         qA[1] = ld(ocA, t0 + 1); qB[1] = ld(ocB, t0 + 1);
+        eA[1] = eld(ocA, t0 + 1); eB[1] = eld(ocB, t0 + 1);
         pa[0] = ld(oa, t0); pb[0] = ld(ob, t0);
         if (kPairOuterAhead > 1) { pa[1] = ld(oa, t0 + 1); pb[1] = ld(ob, t0 + 1); }
         hA[0] = side(cA, t0); hB[0] = side(cB, t0);
@@ -466,9 +482,14 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pa
             const int km = (k + 3) & 3, kp = (k + 1) & 3, kn = (k + 2) & 3;
             const int ko = (k + kPairOuterAhead) & 3;
             qA[kn] = ld(ocA, t + 2); qB[kn] = ld(ocB, t + 2); pa[ko] = ld(oa, t + kPairOuterAhead); pb[ko] = ld(ob, t + kPairOuterAhead);
+            eA[kn] = eld(ocA, t + 2); eB[kn] = eld(ocB, t + 2);
             hA[kp & 1] = side(cA, t + 1); hB[kp & 1] = side(cB, t + 1);
             sA[kp] = tol_split4(qA[kp]); sB[kp] = tol_split4(qB[kp]);
+#ifdef EPIC_EXP3D_NOSPLITNB  // timing experiment only (wrong results): the outer rows are not split
+            const Split4 so_a = sA[km], so_b = sB[kp];
+#else
             const Split4 so_a = tol_split4(pa[k]), so_b = tol_split4(pb[k]);
+#endif
             const bool evenA = !RB || ((cA + t + a.parity) & 1) == 0;  // scalar; B has the other colour pattern
             const RowSide &ha = hA[k & 1], &hb = hB[k & 1];
 #ifdef EPIC_EXP3D_TRAFFIC  // timing experiment only (wrong results): the loads and stores of the sweep, no arithmetic
@@ -479,14 +500,14 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pa
             // the reference's order of the six neighbours: x0 - 1, x0 + 1, x1 - 1, x1 + 1, (x2 - 1, x2 + 1 inside tol_row_3d)
             float4 oA, oB;
             if (!X0M) {  // pair axis = x0, ring = x1
-                oA = tol_row_3d<RB>(pa[k], qB[k], qA[km], qA[k], qA[kp], so_a, sB[k], sA[km], sA[k], sA[kp], ha.l, ha.r,
+                oA = tol_row_3d<RB>(pa[k], qB[k], qA[km], qA[k], qA[kp], so_a, sB[k], sA[km], sA[k], sA[kp], eA[k], eA[k],
                                     ha.m0, ha.m1, ha.m2, ha.m3, evenA, tl);
-                oB = tol_row_3d<RB>(qA[k], pb[k], qB[km], qB[k], qB[kp], sA[k], so_b, sB[km], sB[k], sB[kp], hb.l, hb.r,
+                oB = tol_row_3d<RB>(qA[k], pb[k], qB[km], qB[k], qB[kp], sA[k], so_b, sB[km], sB[k], sB[kp], eB[k], eB[k],
                                     hb.m0, hb.m1, hb.m2, hb.m3, !evenA, tl);
             } else {     // ring = x0, pair axis = x1
-                oA = tol_row_3d<RB>(qA[km], qA[kp], pa[k], qA[k], qB[k], sA[km], sA[kp], so_a, sA[k], sB[k], ha.l, ha.r,
+                oA = tol_row_3d<RB>(qA[km], qA[kp], pa[k], qA[k], qB[k], sA[km], sA[kp], so_a, sA[k], sB[k], eA[k], eA[k],
                                     ha.m0, ha.m1, ha.m2, ha.m3, evenA, tl);
-                oB = tol_row_3d<RB>(qB[km], qB[kp], qA[k], qB[k], pb[k], sB[km], sB[kp], sA[k], sB[k], so_b, hb.l, hb.r,
+                oB = tol_row_3d<RB>(qB[km], qB[kp], qA[k], qB[k], pb[k], sB[km], sB[kp], sA[k], sB[k], so_b, eB[k], eB[k],
                                     hb.m0, hb.m1, hb.m2, hb.m3, !evenA, tl);
             }
 #endif
