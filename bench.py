@@ -544,6 +544,7 @@ def main():
                 "grid": grid, "sweeps_per_step": args.stagger, "check_every": args.stagger, "developed_sweeps": develop,
                 "math": args.math, "scheme": args.scheme, "activity_tracking": bool(args.track), "free_cells": free_cells,
                 "parallelism": "1 GPU", "h2d_seconds": round(upload_s, 3),
+                "fused_rows_per_task": int(E.epic_hip_fused_rows_per_task(h)),   # measured by the library on this grid
             },
             "roofline": roofline(cells_per_launch, launch_us, args.math, args.scheme, True, per_pass),
             "step_us_per_iteration": round(step_us_per_sweep, 3),

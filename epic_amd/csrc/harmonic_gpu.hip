@@ -132,6 +132,9 @@ struct Ctx {
     float *h_delta = nullptr;      // pinned
     hipStream_t stream = nullptr;
     int rows_per_task = 0;         // 0 = automatic
+    // Task height of the fused passes, measured on this grid (tune_fused_rows): [0] two Jacobi iterations (tol), [1] two
+    // red-black iterations (tol), [2] two red-black iterations (precise / fast).  0 = not measured yet, -1 = not to be measured.
+    int tuned_rows[3] = {0, 0, 0};
     int math = 0;                  // 0 = precise (default), 1 = fast, 2 = traffic, 4 = tol; EPIC_HIP_MATH / epic_hip_set_math_mode
     // Launch-bound grids replay the plain sweeps between two checks from a captured hipGraph; key = (count, starting
     // buffer, starting parity, math, scheme, rows_per_task, fused-pass configuration) -- everything a captured launch
@@ -459,6 +462,7 @@ void drop_graphs(Ctx *c)
 int fused_rows_per_task(const Ctx *c)
 {
     if (c->rows_per_task > 0) return std::max(c->rows_per_task, 4);
+    if (c->tuned_rows[2] > 0 && !c->multi()) return c->tuned_rows[2];
     const long long nstrips = (c->pitch + 247) / 248;
     long long r = (long long)c->rows * nstrips / 8192 / 8 * 8;
     return (int)std::min<long long>(64, std::max<long long>(16, r));
@@ -485,8 +489,69 @@ int jacobi_fused_rows_per_task(const Ctx *c)
 {
     const char *e = getenv("EPIC_HIP_FUSED_ROWS");  // experiment / test knob
     if (e && atoi(e) > 0) return atoi(e);
+    const int tuned = c->tuned_rows[c->redblack ? 1 : 0];
+    if (tuned > 0 && !c->multi()) return tuned;
     const long long rows = c->multi() ? c->rows / (long long)c->slabs.size() : c->rows;
     return epic_hip::jacobi_fused_auto_rows((int)rows, c->pitch);
+}
+
+// The time of a fused pass depends on its task height in a way no rule of ours predicts: at 8192 x 8192 (tol Jacobi, one
+// box, us per launch) 38 rows 182.2, 39: 179.5, 40: 167.9, 41: 169.6, 42: 172.9, 44: 178.6, 46: 170.1, 64: 184.4, against 178.6 for
+// the 23 of jacobi_fused_auto_rows (profiles/r03_experiments.txt item 9) -- rounds of resident waves, the XCD bands and the
+// memory channels all have a say.  So the height is MEASURED, once per grid and kind of pass, the first time such a pass
+// is about to run on a grid of at least 4 Mcell: every candidate runs three times from the current buffer into the other
+// one (which the next real pass overwrites anyway; nothing else is touched) between two events, ~10 ms in all.  Results do
+// not depend on the height (tests/test_gpu_tol.py, test_gpu_parity.py sweep it).  EPIC_HIP_TUNE=0: the rules only.
+void tune_fused_rows(Ctx *c, int kind, unsigned iteration)
+{
+    if (c->tuned_rows[kind] != 0) return;
+    // not on the field of the first iterations (all cells at the initial value: the passes run up to 15 % faster on it and rank the
+    // heights differently): the rule serves until the front has crossed a good part of the grid
+    if (iteration < (unsigned)std::min(c->rows, c->cols) / 2) return;
+    c->tuned_rows[kind] = -1;
+    const char *t = getenv("EPIC_HIP_TUNE");
+    if ((t && t[0] == '0') || c->multi() || c->n != 2 || c->rows_per_task > 0 || getenv("EPIC_HIP_FUSED_ROWS") != nullptr) return;
+    if ((long long)c->rows * c->pitch < (1ll << 22)) return;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { c->tuned_rows[kind] = 0; return; }
+    const int dflt = kind == 2 ? fused_rows_per_task(c) : jacobi_fused_rows_per_task(c);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess) return;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return; }
+    auto launch = [&](int rows) -> hipError_t {
+        if (kind == 2)
+            return epic_hip::launch_rb_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch, rows, c->math, 0, c->stream,
+                                                c->maskf());
+        return epic_hip::launch_jacobi_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch, rows, c->math, c->stream,
+                                                kind == 1 ? 0 : -1, c->maskf());
+    };
+    auto timed = [&](int rows, float *ms) -> bool {
+        if (launch(rows) != hipSuccess) return false;   // warm
+        if (hipEventRecord(e0, c->stream) != hipSuccess) return false;
+        for (int i = 0; i < 2; ++i)
+            if (launch(rows) != hipSuccess) return false;
+        return hipEventRecord(e1, c->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+               hipEventElapsedTime(ms, e0, e1) == hipSuccess;
+    };
+    static const int kCandidates[] = {20, 23, 26, 29, 32, 35, 38, 40, 41, 43, 46, 49, 52, 58, 64};
+    const bool say = getenv("EPIC_HIP_TUNE_DEBUG") != nullptr;   // the table on stderr
+    float best_ms = 0.0f, dflt_ms = 0.0f;
+    int best = 0;
+    bool ok = timed(dflt, &dflt_ms);
+    if (say && ok) fprintf(stderr, "[epic_hip tune] kind %d, %d x %d: rule %d rows %.1f us", kind, c->rows, c->cols, dflt, dflt_ms * 500.0f);
+    for (int r : kCandidates) {
+        if (!ok) break;
+        if (r == dflt || r > c->rows) continue;
+        float ms = 0.0f;
+        ok = timed(r, &ms);
+        if (say && ok) fprintf(stderr, ", %d: %.1f", r, ms * 500.0f);
+        if (ok && (best == 0 || ms < best_ms)) { best = r; best_ms = ms; }
+    }
+    if (say) fprintf(stderr, "\n");
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (!ok) { (void)hipGetLastError(); return; }
+    c->tuned_rows[kind] = (best > 0 && best_ms < 0.99f * dflt_ms) ? best : dflt;   // a clear win only
 }
 
 hipError_t multi_run(Ctx *c, unsigned count, unsigned first, bool check_first);
@@ -504,6 +569,7 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
     // jacobi_fused2d_kernel: 4 B of HBM traffic per cell-update instead of 8, bit-identical to two sweeps).
     // EPIC_HIP_FUSE_MIN_CELLS: grids below it keep the single sweeps (default 4 Mcell; the tests set 0).
     if (!no_fuse && fuses_jacobi(c)) {
+        if (count >= 2) tune_fused_rows(c, 0, first);
         while (i < count) {
             if (count - i >= 2) {
                 hipError_t e = epic_hip::launch_jacobi_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch,
@@ -520,6 +586,8 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
         }
         return hipSuccess;
     }
+    if (!no_fuse && fuses_rb_tol(c) && count - i >= 2) tune_fused_rows(c, 1, first);
+    if (fuse && count - i >= 2) tune_fused_rows(c, 2, first);
     while (!no_fuse && fuses_rb_tol(c) && count - i >= 2) {
         hipError_t e = epic_hip::launch_jacobi_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch,
                                                         jacobi_fused_rows_per_task(c), c->math, c->stream, (int)((first + i) & 1u),
@@ -1979,6 +2047,13 @@ int epic_hip_iterations_per_pass(Harmonic *harmonic)
     const bool rb_fused = c->redblack && c->n == 2 && !no_fuse && !c->track && c->math != 4 &&
                           (long long)c->rows * c->pitch >= (1ll << 22);
     return rb_fused ? 2 : 1;
+}
+
+int epic_hip_fused_rows_per_task(Harmonic *harmonic)
+{
+    Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
+    if (!c || epic_hip_iterations_per_pass(harmonic) != 2) return 0;
+    return (fuses_jacobi(c) || fuses_rb_tol(c)) ? jacobi_fused_rows_per_task(c) : fused_rows_per_task(c);
 }
 
 int epic_hip_set_rows_per_task(Harmonic *harmonic, unsigned int rows_per_task)

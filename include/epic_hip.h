@@ -49,6 +49,12 @@ int epic_hip_timed_sweeps_gpu(EpicHarmonicT *harmonic, unsigned int sweeps, unsi
  * every check iteration run singly -- 1 otherwise, 0 without device state.  EPIC_HIP_NO_FUSE=1 switches the fusion off. */
 int epic_hip_iterations_per_pass(EpicHarmonicT *harmonic);
 
+/* Rows per task of that fused pass in the current configuration (0: no fused pass).  On grids of at least 4 Mcell on one
+ * device the height is measured on the grid itself the first time a pair of plain iterations is enqueued (a few candidates,
+ * three launches each, ~10 ms, once per grid and kind of pass; results do not depend on it): before that the call returns
+ * the rule's value.  EPIC_HIP_TUNE=0 keeps the rule; EPIC_HIP_FUSED_ROWS / epic_hip_set_rows_per_task fix the height. */
+int epic_hip_fused_rows_per_task(EpicHarmonicT *harmonic);
+
 /* Tuning knob: rows marched by one wave in the 2-D kernel (0 = automatic).  Also EPIC_HIP_ROWS_PER_TASK. */
 int epic_hip_set_rows_per_task(EpicHarmonicT *harmonic, unsigned int rows_per_task);
 

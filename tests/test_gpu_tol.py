@@ -140,6 +140,43 @@ def test_3d_two_planes_per_wave_equals_the_checker_and_the_one_plane_kernel(m, s
                 assert np.array_equal(one, got) and odelta == gdelta
 
 
+@pytest.mark.parametrize("math,scheme", [(eh.MATH_TOL, eh.SCHEME_JACOBI), (eh.MATH_TOL, eh.SCHEME_REDBLACK),
+                                         (eh.MATH_PRECISE, eh.SCHEME_REDBLACK)])
+def test_measured_task_height_of_the_fused_passes_changes_nothing_but_time(math, scheme, monkeypatch):
+    """On grids of at least 4 Mcell the library measures the task height of a fused pass on the grid itself, the first time a
+    pair of plain iterations is enqueued past the first min(rows, cols) / 2 iterations (harmonic_gpu.hip: tune_fused_rows):
+    every candidate runs from the current buffer into the other one.  The field, the delta and the iteration count must be
+    what the rule's height (EPIC_HIP_TUNE=0) gives, and the height in use afterwards is the rule's or one of the candidates."""
+    m = [2048, 2100]
+    u0, locked = with_extra_goals(m, 31, 0.05)
+    k = 1400                                            # the tuner runs at the first batch that starts past iteration 1024
+
+    def run(tune):
+        if tune:
+            monkeypatch.delenv("EPIC_HIP_TUNE", raising=False)
+        else:
+            monkeypatch.setenv("EPIC_HIP_TUNE", "0")
+        h = make(m, u0, locked)
+        gpu_init(h)
+        assert E.epic_hip_set_math_mode(h, math) == 0 and E.epic_hip_set_scheme(h, scheme) == 0
+        assert E.epic_hip_set_activity_tracking(h, 0) == 0 and E.epic_hip_iterations_per_pass(h) == 2
+        rule = E.epic_hip_fused_rows_per_task(h)
+        for _ in range(k // 100):                       # batches, as harmonic_execute_gpu enqueues them
+            assert E.epic_hip_update_n_gpu(h, 100, 0) == 0
+        assert E.epic_hip_update_n_gpu(h, 1, 1) in (0, 1)
+        rows = E.epic_hip_fused_rows_per_task(h)
+        assert E.harmonic_get_potential_values_gpu(h) == 0
+        gpu_fini(h)
+        return h.u_array().ravel().copy(), float(h.delta), rule, rows
+
+    tuned, tdelta, rule, rows = run(True)
+    plain, pdelta, rule0, rows0 = run(False)
+    assert rule == rule0 == rows0 and rule > 0
+    assert rows == rule or rows in (20, 23, 26, 29, 32, 35, 38, 40, 41, 43, 46, 49, 52, 58, 64)
+    assert np.array_equal(tuned, plain) and tdelta == pdelta
+    print("fused pass, math %d scheme %d on %s: rule %d rows, measured %d" % (math, scheme, m, rule, rows))
+
+
 FUSED_GRIDS = [([16, 16], 1, 0.05), ([23, 37], 4, 0.10), ([3, 3], 6, 0.0), ([3, 70], 6, 0.0), ([70, 3], 6, 0.0),
                ([8, 300], 7, 0.05), ([70, 66], 8, 0.30), ([257, 513], 9, 0.05), ([64, 1030], 10, 0.05), ([96, 249], 6, 0.05),
                ([211, 530], 12, 0.06), ([1200, 3000], 5, 0.05)]
