@@ -256,13 +256,18 @@ def live_traffic(args):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return {}, "rocprofv3 not found"
+    # never from a process that is itself being profiled: the profiler's preloaded library has initialised the GPU in it, and
+    # a GPU-initialised process must not start another program
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_PATH",
+                                                                 "HSA_TOOLS_LIB")):
+        return {}, "this process runs under a profiler"
     out, counts = {}, {}
     tmp = tempfile.mkdtemp(prefix="epic_pmc_", dir="/tmp")
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
-                   "--gpus", "1", "--steps", "1", "--warmup", "1", "--develop", "200", "--size", str(args.size),
+                   "--gpus", "1", "--steps", "1", "--warmup", "1", "--develop", "5000",   # (past the point where the library measures its task height) "--size", str(args.size),
                    "--stagger", str(args.stagger), "--math", args.math, "--scheme", args.scheme,
                    "--rows-per-task", str(args.rows_per_task), "--no-cpu", "--no-relax", "--no-extra-legs", "--no-parity",
                    "--no-live-traffic"] + (["--track"] if args.track else [])
@@ -280,6 +285,7 @@ def live_traffic(args):
                         per.setdefault(key, []).append(float(row["Counter_Value"]))
                         break
             for key, vals in per.items():
+                vals = vals[-90:]   # the steady state: the last step's launches (the library settles its task height during the develop phase)
                 # counter unit KiB; FETCH_SIZE under-reports streaming reads by 2 on gfx950 (the guide's correction)
                 out[key] = out.get(key, 0.0) + statistics.mean(vals) * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0)
                 counts[key] = min(counts.get(key, 1 << 30), len(vals))

@@ -16,7 +16,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="$ROOT/bench.py --no-cpu --no-relax --no-extra-legs --no-parity"
+B="$ROOT/bench.py --no-cpu --no-relax --no-extra-legs --no-parity --no-live-traffic"
 C="$ROOT/tools/bench_config.py --grid 512 512 512 --develop 1500"
 SQ="SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE"
 run() { name=$1; shift; case "$name" in *"$ONLY"*) ;; *) return 0;; esac; "$@" > "$OUT/$name.log" 2>&1; echo "[$name] rc=$?"; }
@@ -27,14 +27,14 @@ run stats_3d_precise      rocprofv3 --kernel-trace --stats --output-format csv -
 R="$ROOT/tools/time_relax.py --track 2"
 run stats_relax_tol      rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_relax_tol" -- python3 $R --math tol --scheme jacobi
 run stats_relax_default  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_relax_default" -- python3 $R --math precise --scheme redblack
-run fetch_tol   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_tol_jacobi" -- python3 $B --steps 1 --warmup 1 --develop 200
-run write_tol   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write_tol_jacobi" -- python3 $B --steps 1 --warmup 1 --develop 200
+run fetch_tol   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_tol_jacobi" -- python3 $B --steps 1 --warmup 1 --develop 5000
+run write_tol   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write_tol_jacobi" -- python3 $B --steps 1 --warmup 1 --develop 5000
 run fetch_3d_tol   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_3d_tol" -- python3 $C --math tol --sweeps 100
 run write_3d_tol   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write_3d_tol" -- python3 $C --math tol --sweeps 100
 run fetch_3d_precise   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_3d_precise" -- python3 $C --math precise --sweeps 100
 run write_3d_precise   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write_3d_precise" -- python3 $C --math precise --sweeps 100
-run sq_tol      rocprofv3 --pmc $SQ --output-format csv -d "$OUT/sq_tol_jacobi" -- python3 $B --steps 1 --warmup 1 --develop 2000
-run sq_precise  rocprofv3 --pmc $SQ --output-format csv -d "$OUT/sq_precise_jacobi" -- python3 $B --steps 1 --warmup 1 --develop 2000 --math precise
+run sq_tol      rocprofv3 --pmc $SQ --output-format csv -d "$OUT/sq_tol_jacobi" -- python3 $B --steps 1 --warmup 1 --develop 5000
+run sq_precise  rocprofv3 --pmc $SQ --output-format csv -d "$OUT/sq_precise_jacobi" -- python3 $B --steps 1 --warmup 1 --develop 5000 --math precise
 run sq_3d_tol      rocprofv3 --pmc $SQ --output-format csv -d "$OUT/sq_3d_tol" -- python3 $C --math tol --sweeps 100
 run sq_3d_precise  rocprofv3 --pmc $SQ --output-format csv -d "$OUT/sq_3d_precise" -- python3 $C --math precise --sweeps 100
 cd "$ROOT"
@@ -47,11 +47,11 @@ $S stats "$OUT/stats_3d_tol" > "$OUT/${TAG}_kernel_stats_3d_tol.txt"
 $S stats "$OUT/stats_3d_precise" > "$OUT/${TAG}_kernel_stats_3d_precise.txt"
 $S stats "$OUT/stats_relax_tol" > "$OUT/${TAG}_kernel_stats_relax_tol_tracked.txt"
 $S stats "$OUT/stats_relax_default" > "$OUT/${TAG}_kernel_stats_relax_default.txt"
-PROFILE_KERNEL=jacobi_fused2d $S pmc "$OUT/fetch_tol_jacobi" "$OUT/write_tol_jacobi" > "$OUT/${TAG}_hbm_traffic_tol_jacobi_fused.txt"
+PROFILE_LAST=90 PROFILE_KERNEL=jacobi_fused2d $S pmc "$OUT/fetch_tol_jacobi" "$OUT/write_tol_jacobi" > "$OUT/${TAG}_hbm_traffic_tol_jacobi_fused.txt"
 PROFILE_KERNEL=sweep2d $S pmc "$OUT/fetch_tol_jacobi" "$OUT/write_tol_jacobi" > "$OUT/${TAG}_hbm_traffic_tol_jacobi.txt"
 $S pmc "$OUT/fetch_3d_tol" "$OUT/write_3d_tol" > "$OUT/${TAG}_hbm_traffic_3d_tol.txt"
 $S pmc "$OUT/fetch_3d_precise" "$OUT/write_3d_precise" > "$OUT/${TAG}_hbm_traffic_3d_precise.txt"
-PROFILE_KERNEL=jacobi_fused2d $S sq "$OUT/sq_tol_jacobi" 134217728 > "$OUT/${TAG}_sq_counters_tol_fused.txt" 2>&1
+PROFILE_LAST=90 PROFILE_KERNEL=jacobi_fused2d $S sq "$OUT/sq_tol_jacobi" 134217728 > "$OUT/${TAG}_sq_counters_tol_fused.txt" 2>&1
 PROFILE_KERNEL=sweep2d $S sq "$OUT/sq_tol_jacobi" 67108864 > "$OUT/${TAG}_sq_counters_tol.txt" 2>&1
 $S sq "$OUT/sq_precise_jacobi" 67108864 > "$OUT/${TAG}_sq_counters_precise.txt" 2>&1
 $S sq "$OUT/sq_3d_tol" 134217728 > "$OUT/${TAG}_sq_counters_3d_tol.txt" 2>&1

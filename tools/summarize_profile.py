@@ -18,6 +18,9 @@ import statistics
 import sys
 
 KERNEL = os.environ.get("PROFILE_KERNEL", "sweep")
+# PROFILE_LAST=N: pmc and sq look at the last N matching dispatches only (the library measures the task height of its fused
+# passes a few thousand iterations into a run; the dispatches after that are the steady state)
+LAST = int(os.environ.get("PROFILE_LAST", "0"))
 
 
 def find(d, pat):
@@ -39,6 +42,8 @@ def stats(d):
 def pmc_values(d, counter):
     rows = list(csv.DictReader(open(find(d, "*_counter_collection.csv"))))
     vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == counter and KERNEL in r["Kernel_Name"]]
+    if LAST > 0:
+        vals = vals[-LAST:]
     names = sorted({r["Kernel_Name"] for r in rows if KERNEL in r["Kernel_Name"]})
     return vals, names
 
@@ -64,6 +69,13 @@ def sq(d, cells=8192 * 8192):
     rows = list(csv.DictReader(open(find(d, "*_counter_collection.csv"))))
     rows = [r for r in rows if KERNEL in r["Kernel_Name"]]
     names = sorted({r["Counter_Name"] for r in rows})
+    if LAST > 0 and names:   # the last N dispatches (rows are in dispatch order, one row per counter and dispatch)
+        ids = []
+        for r in rows:
+            if not ids or ids[-1] != r["Dispatch_Id"]:
+                ids.append(r["Dispatch_Id"])
+        keep = set(ids[-LAST:])
+        rows = [r for r in rows if r["Dispatch_Id"] in keep]
     mean = {n: statistics.mean(float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == n) for n in names}
     n_disp = len([r for r in rows if r["Counter_Name"] == names[0]]) if names else 0
     print("# rocprofv3 --pmc SQ_* (%s), mean per sweep dispatch (%d dispatches of %s)" % (
