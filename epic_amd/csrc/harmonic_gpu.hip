@@ -1734,7 +1734,15 @@ static bool bypass_lists_for_batch(Ctx *c)
     // (a forced iteration runs every tile but still lists the tiles it changed)
     if (!c->track || c->track_mode != 2 || c->n != 2) return false;
     const char *e = getenv("EPIC_HIP_TRACK_SWITCH");   // share of due tiles above which lists are bypassed (tests: 0 / 2)
-    const double limit = e ? atof(e) : 0.8;
+    // The break-even share is where a list-driven iteration costs what an iteration of the untracked path costs -- and that path
+    // differs: fused pairs for everything but precise Jacobi, and a red-black pair recomputes each cell once where two list-driven
+    // half-sweeps move the whole field twice.  Measured on whole 8192^2 relaxations, same box (tools/exp_track_switch.sh,
+    // profiles/r03_experiments.txt item 10), seconds at 0.4 / 0.5 / 0.6 / 0.7 / 0.8 / 0.9:
+    //   tol red-black      2.02 / 2.02 / 2.11 / 2.14 / 2.24 / 2.45        precise red-black   2.57 / 2.51 / 2.49 / 2.49 / 2.57 / 2.75
+    //   tol Jacobi           -  / 2.53 / 2.49 / 2.48 / 2.51 / 2.61        precise Jacobi        -  / 4.08 / 3.94 / 3.82 / 3.74 / 3.73
+    const bool tol = c->math == 4;
+    const double rule = c->redblack ? (tol ? 0.45 : 0.6) : (tol ? 0.7 : 0.85);
+    const double limit = e ? atof(e) : rule;
     // the counter sets the next launches would consume were filled by the check iteration that has just been read back
     unsigned long long due = 0, tiles = 0;
     if (!due_tiles(c, &due, &tiles, false) || tiles == 0) return false;
