@@ -54,19 +54,15 @@ struct Sweep3dArgs {
 // x0 - 1 and x0 + 1, s* their splits, hl / hr the two strip-edge cells of the row, m0..m3 its lane masks.  RB: only the cells of
 // one colour are recomputed (even_cols: the lane's .x and .z).  The cells go through the three phases of cell_update.h two at
 // a time: the table reads of one pair are in flight while the other pair is worked on.
+// (hs: the split of the row's two strip-edge cells hl / hr -- .x the left one's, .y the right one's)
 template <bool RB>
 __device__ __forceinline__ float4 tol_row_3d(const float4 &pa, const float4 &pb, const float4 &up, const float4 &c, const float4 &dn,
                                              const Split4 &sa, const Split4 &sb, const Split4 &su, const Split4 &sc, const Split4 &sd,
-                                             float hl, float hr, lmask m0, lmask m1, lmask m2, lmask m3, bool even_cols,
+                                             float hl, float hr, const Split2 &hs, lmask m0, lmask m1, lmask m2, lmask m3, bool even_cols,
                                              const TolLnEntry *tl)
 {
     const float lf = wave_from_left(c.w, hl);
     const float rt = wave_from_right(c.x, hr);
-#ifdef EPIC_EXP3D_NOEDGESPLIT  // timing experiment only (wrong results)
-    const Split2 hs = Split2{v2f{sc.qx, sc.qw}, v2f{u2f(sc.nx), u2f(sc.nw)}};
-#else
-    const Split2 hs = tol_split2(v2f{hl, hr});  // the two strip-edge cells of the row
-#endif
     const float ql = wave_from_left(sc.qw, hs.q.x), qr = wave_from_right(sc.qx, hs.q.y);
     const uint32_t nl = f2u(wave_from_left(u2f(sc.nw), hs.zm.x)), nr = f2u(wave_from_right(u2f(sc.nx), hs.zm.y));
     float4 o = c;
@@ -109,6 +105,20 @@ __device__ __forceinline__ float4 tol_row_3d(const float4 &pa, const float4 &pb,
         o.w = sel(m3, c.w, nw);
     }
     return o;
+}
+
+template <bool RB>
+__device__ __forceinline__ float4 tol_row_3d(const float4 &pa, const float4 &pb, const float4 &up, const float4 &c, const float4 &dn,
+                                             const Split4 &sa, const Split4 &sb, const Split4 &su, const Split4 &sc, const Split4 &sd,
+                                             float hl, float hr, lmask m0, lmask m1, lmask m2, lmask m3, bool even_cols,
+                                             const TolLnEntry *tl)
+{
+#ifdef EPIC_EXP3D_NOEDGESPLIT  // timing experiment only (wrong results)
+    const Split2 hs = Split2{v2f{sc.qx, sc.qw}, v2f{u2f(sc.nx), u2f(sc.nw)}};
+#else
+    const Split2 hs = tol_split2(v2f{hl, hr});  // the two strip-edge cells of the row
+#endif
+    return tol_row_3d<RB>(pa, pb, up, c, dn, sa, sb, su, sc, sd, hl, hr, hs, m0, m1, m2, m3, even_cols, tl);
 }
 
 // RB = true: the reference's 3-D red-black half-sweep in place (in == out): cells with (x0 + x1 + x2 + currentIteration)
@@ -490,24 +500,27 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pa
 #else
             const Split4 so_a = tol_split4(pa[k]), so_b = tol_split4(pb[k]);
 #endif
+            // the strip-edge cells of both owned rows in ONE packed split (.x: plane A's -- lane 0 left, lane 63 right --, .y: plane B's)
+            const Split2 es = tol_split2(v2f{eA[k], eB[k]});
+            const Split2 esA = Split2{v2f{es.q.x, es.q.x}, v2f{es.zm.x, es.zm.x}}, esB = Split2{v2f{es.q.y, es.q.y}, v2f{es.zm.y, es.zm.y}};
             const bool evenA = !RB || ((cA + t + a.parity) & 1) == 0;  // scalar; B has the other colour pattern
             const RowSide &ha = hA[k & 1], &hb = hB[k & 1];
 #ifdef EPIC_EXP3D_TRAFFIC  // timing experiment only (wrong results): the loads and stores of the sweep, no arithmetic
             auto mx4 = [](const float4 &x, const float4 &y) { return make_float4(max2(x.x, y.x), max2(x.y, y.y), max2(x.z, y.z), max2(x.w, y.w)); };
             const float4 oA = mx4(mx4(qA[km], qA[kp]), mx4(pa[k], qB[k])), oB = mx4(mx4(qB[km], qB[kp]), mx4(pb[k], qA[k]));
-            (void)so_a; (void)so_b; (void)evenA; (void)ha; (void)hb;
+            (void)so_a; (void)so_b; (void)evenA; (void)ha; (void)hb; (void)esA; (void)esB;
 #else
             // the reference's order of the six neighbours: x0 - 1, x0 + 1, x1 - 1, x1 + 1, (x2 - 1, x2 + 1 inside tol_row_3d)
             float4 oA, oB;
             if (!X0M) {  // pair axis = x0, ring = x1
-                oA = tol_row_3d<RB>(pa[k], qB[k], qA[km], qA[k], qA[kp], so_a, sB[k], sA[km], sA[k], sA[kp], eA[k], eA[k],
+                oA = tol_row_3d<RB>(pa[k], qB[k], qA[km], qA[k], qA[kp], so_a, sB[k], sA[km], sA[k], sA[kp], eA[k], eA[k], esA,
                                     ha.m0, ha.m1, ha.m2, ha.m3, evenA, tl);
-                oB = tol_row_3d<RB>(qA[k], pb[k], qB[km], qB[k], qB[kp], sA[k], so_b, sB[km], sB[k], sB[kp], eB[k], eB[k],
+                oB = tol_row_3d<RB>(qA[k], pb[k], qB[km], qB[k], qB[kp], sA[k], so_b, sB[km], sB[k], sB[kp], eB[k], eB[k], esB,
                                     hb.m0, hb.m1, hb.m2, hb.m3, !evenA, tl);
             } else {     // ring = x0, pair axis = x1
-                oA = tol_row_3d<RB>(qA[km], qA[kp], pa[k], qA[k], qB[k], sA[km], sA[kp], so_a, sA[k], sB[k], eA[k], eA[k],
+                oA = tol_row_3d<RB>(qA[km], qA[kp], pa[k], qA[k], qB[k], sA[km], sA[kp], so_a, sA[k], sB[k], eA[k], eA[k], esA,
                                     ha.m0, ha.m1, ha.m2, ha.m3, evenA, tl);
-                oB = tol_row_3d<RB>(qB[km], qB[kp], qA[k], qB[k], pb[k], sB[km], sB[kp], sA[k], sB[k], so_b, eB[k], eB[k],
+                oB = tol_row_3d<RB>(qB[km], qB[kp], qA[k], qB[k], pb[k], sB[km], sB[kp], sA[k], sB[k], so_b, eB[k], eB[k], esB,
                                     hb.m0, hb.m1, hb.m2, hb.m3, !evenA, tl);
             }
 #endif
