@@ -263,15 +263,25 @@ def live_traffic(args):
         return {}, "this process runs under a profiler"
     out, counts = {}, {}
     tmp = tempfile.mkdtemp(prefix="epic_pmc_", dir="/tmp")
+    # (--develop 5000: past the point where the library measures the task height of its fused passes)
+    child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "1", "--develop", "5000",
+             "--size", str(args.size), "--stagger", str(args.stagger), "--math", args.math, "--scheme", args.scheme,
+             "--rows-per-task", str(args.rows_per_task), "--no-cpu", "--no-relax", "--no-extra-legs", "--no-parity",
+             "--no-live-traffic"] + (["--track"] if args.track else [])
+    env = dict(os.environ, TMPDIR="/tmp")
     try:
+        # The library measures that height by timing, which a counter pass distorts.  So one plain child first, to learn the
+        # height, and the counter passes with that height fixed.
+        if "EPIC_HIP_FUSED_ROWS" not in env:
+            r = subprocess.run(child, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
+            lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+            rows = json.loads(lines[-1])["config"].get("fused_rows_per_task", 0) if r.returncode == 0 and lines else 0
+            if rows > 0:
+                env["EPIC_HIP_FUSED_ROWS"] = str(rows)
+                counts["fused_rows_per_task"] = rows
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
-                   "--gpus", "1", "--steps", "1", "--warmup", "1", "--develop", "5000",   # (past the point where the library measures its task height) "--size", str(args.size),
-                   "--stagger", str(args.stagger), "--math", args.math, "--scheme", args.scheme,
-                   "--rows-per-task", str(args.rows_per_task), "--no-cpu", "--no-relax", "--no-extra-legs", "--no-parity",
-                   "--no-live-traffic"] + (["--track"] if args.track else [])
-            env = dict(os.environ, TMPDIR="/tmp")
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
             files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
@@ -432,7 +442,9 @@ def main():
         if single_device_full_grid and math == args.math and scheme == args.scheme and kernel in live:
             traffic = live[kernel]
             source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + --pmc WRITE_SIZE, separate child passes of "
-                      "this command, mean over %d launches of the kernel" % live_note.get(kernel, 0))
+                      "this command, mean over %d launches of the kernel" % live_note.get(kernel, 0)
+                      + (" at %d rows per task (the height a plain child pass saw the library measure)" % live_note["fused_rows_per_task"]
+                         if fused and "fused_rows_per_task" in live_note else ""))
         elif single_device_full_grid:
             traffic = measured_traffic(n, math, scheme + ("_fused" if fused else ""))
             if traffic is not None:

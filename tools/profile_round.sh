@@ -20,6 +20,10 @@ B="$ROOT/bench.py --no-cpu --no-relax --no-extra-legs --no-parity --no-live-traf
 C="$ROOT/tools/bench_config.py --grid 512 512 512 --develop 1500"
 SQ="SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE"
 run() { name=$1; shift; case "$name" in *"$ONLY"*) ;; *) return 0;; esac; "$@" > "$OUT/$name.log" 2>&1; echo "[$name] rc=$?"; }
+# the library measures the task height of its fused passes by timing, which counter passes distort: learn it from a plain run
+# and fix it for every 2-D tol pass of this script
+ROWS=$(python3 $B --steps 1 --warmup 1 --develop 5000 2>/dev/null | python3 -c 'import sys,json; print(json.loads(sys.stdin.read().strip().splitlines()[-1])["config"].get("fused_rows_per_task", 0))' 2>/dev/null)
+if [ -n "$ROWS" ] && [ "$ROWS" -gt 0 ] 2>/dev/null; then export EPIC_HIP_FUSED_ROWS=$ROWS; echo "[fused rows per task: $ROWS]"; fi
 run stats_tol_jacobi      rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_tol_jacobi" -- python3 $B --steps 5 --warmup 1
 run stats_precise_jacobi  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_precise_jacobi" -- python3 $B --steps 5 --warmup 1 --math precise
 run stats_3d_tol          rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_3d_tol" -- python3 $C --math tol --sweeps 300
