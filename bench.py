@@ -9,7 +9,7 @@ one check sweep (max |du| reduced on the device, read back) followed by 99 plain
 HBM.  A cell-update is one unlocked cell recomputed once.  With N > 1 (one process per GPU, launched by
 torch.distributed.run) the SAME 8192 x 8192 grid is cut into N row slabs (strong scaling: what the metric names),
 halo rows traded over RCCL (epic_amd/slab.py); the line then also carries a `weak` object (one 8192 x 8192 grid per GPU),
-`ranks` (what every rank saw: device, backend) and `in_library` (the same grid through EPIC_HIP_DEVICES: one process,
+`ranks` (what every rank saw: device, backend) and `in_library` (the same grid through EPIC_HIP_DEVICES: one process -- a child of rank 0, run first --,
 all GPUs, hipMemcpyPeerAsync halos -- include/epic_hip.h).
 The arithmetic is the library's `tol` mode by default (--math): one exp-class split per cell shared by its neighbours,
 the reference's rounding stages kept.  It is a TOLERANCE mode, and the line says how far it is from the reference: the
@@ -218,9 +218,16 @@ def parity_object(args, E, MODES, relaxed, locked_8192):
             for math, scheme in ((args.math, "jacobi"), ("precise", "redblack")):
                 h = Harmonic()
                 h.set_grid(g3, u3, l3)
-                fields[(math, scheme)], _ = complete(h, math, scheme)
+                t3 = time.perf_counter()
+                fields[(math, scheme)], its3 = complete(h, math, scheme)
+                fields[(math, scheme, "s")] = (round(time.perf_counter() - t3, 3), its3)
             e = dist(fields[(args.math, "jacobi")], fields[("precise", "redblack")], l3)
             e.update(against="precise + red-black relaxed in this run (the reference's 3-D iteration bit for bit)")
+            # whole relaxations through harmonic_complete_gpu (upload, iterations to eps = 1e-6 with automatic tracking, download)
+            e.update(relax_seconds={"%s jacobi" % args.math: fields[(args.math, "jacobi", "s")][0],
+                                    "precise redblack (library default)": fields[("precise", "redblack", "s")][0]},
+                     iterations={"%s jacobi" % args.math: fields[(args.math, "jacobi", "s")][1],
+                                 "precise redblack (library default)": fields[("precise", "redblack", "s")][1]})
             out["configs"]["configs[4] 512x512x512"] = e
         missed = [k for k, v in out["configs"].items() if v.get("within_bar") is False]
         out["misses"] = missed
@@ -331,22 +338,39 @@ def main():
     if backend == "nccl" and local >= ndev:
         sys.exit("bench.py: rank %d has no GPU of its own (%d visible)" % (local, ndev))
     local = local % ndev
+    # N > 1: the same grid through the C-ABI in ONE process on all GPUs (EPIC_HIP_DEVICES; halos by the copy engines) -- FIRST,
+    # as a child of rank 0 while rank 0 has not touched a GPU yet (a process that has initialised the GPU must not start
+    # another program) and while the other ranks wait in the rendezvous below with their GPUs idle.  A child, so that a fault
+    # in a path no hardware has run yet cannot take the headline line with it.
+    in_library = None
+    if (world > 1 and rank == 0 and not args.no_extra_legs and not args.in_library_child
+            and ((backend == "nccl" and ndev >= world) or os.environ.get("EPIC_BENCH_DEVLIST"))):
+        import subprocess
+
+        env = {k: v for k, v in os.environ.items()
+               if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                            "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+        try:
+            r2 = subprocess.run([sys.executable, os.path.abspath(__file__), "--in-library-child", str(world), "--steps", str(args.steps),
+                                 "--math", args.math, "--size", str(args.size), "--develop", str(min(args.develop, 6000)),
+                                 "--stagger", str(args.stagger), "--no-live-traffic"],
+                                env=env, capture_output=True, text=True, timeout=240)
+            lines = [l for l in r2.stdout.splitlines() if l.startswith("{")]
+            in_library = json.loads(lines[-1]) if lines else {"error": "rc %d: %s" % (r2.returncode, r2.stderr[-400:])}
+        except BaseException as exc:   # evidence leg only: never lose the headline line
+            in_library = {"error": repr(exc)}
     torch.cuda.set_device(local)
     red_dev = "cuda" if backend == "nccl" else "cpu"          # where the few scalar reductions of this script live
     if world > 1:
+        import datetime
+
         import torch.distributed as dist
 
+        wait = datetime.timedelta(minutes=15)   # the other ranks wait here while rank 0 runs the in-library leg
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=wait)
         else:
-            dist.init_process_group(backend)
-    host_group = None   # a host-side (gloo) group for the waits around the in-library leg: an RCCL barrier would leave a
-    if world > 1 and backend == "nccl":   # spinning kernel on every GPU that rank 0 is about to use from this process
-        try:
-            host_group = dist.new_group(backend="gloo")
-        except Exception:                 # evidence leg only: never lose the headline line
-            host_group = None
-
+            dist.init_process_group(backend, timeout=wait)
     from epic_amd import epic_harmonic as eh
     from epic_amd.synthetic import synthetic_grid
 
@@ -358,16 +382,6 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-
-    def host_barrier():
-        """Ranks meet on the host (no collective kernel left waiting on any GPU)."""
-        torch.cuda.synchronize()
-        if world > 1:
-            if host_group is not None:
-                dist.barrier(group=host_group)
-            else:
-                dist.barrier()
-                torch.cuda.synchronize()
 
     def max_over_ranks(*vals):
         if world == 1:
@@ -656,6 +670,7 @@ def main():
         free = solver.load_synthetic()
         for _ in range(develop):
             solver.sweep(False)
+        pair_rows = solver.tune_pairs() if develop >= min(grid) // 2 else 0   # on a developed field, as the library does
         for _ in range(warmup):
             solver.timed_step()
         barrier()
@@ -672,7 +687,7 @@ def main():
             free = int(f[0])
         rows_local = solver.hi - solver.lo
         res = dict(wall=wall, dev_ms=dev_ms, free=free, halo=solver.halo, rows_local=rows_local,
-                   pairs=bool(getattr(solver.backend, "pairs", False)))
+                   pairs=bool(getattr(solver.backend, "pairs", False)), pair_rows=int(pair_rows))
         del solver
         torch.cuda.empty_cache()
         return res
@@ -694,6 +709,7 @@ def main():
                         + "5% random obstacles + 1 goal (BASELINE configs[2]), log-space Jacobi relax towards eps=1e-6",
             "grid": main_grid, "sweeps_per_step": args.stagger, "check_every": args.stagger, "developed_sweeps": develop,
             "math": args.math, "scheme": "jacobi", "activity_tracking": False, "free_cells": r["free"],
+            "fused_rows_per_task": r["pair_rows"],   # rank 0's slab: measured by SlabSolver.tune_pairs (0: the library's rule)
             "parallelism": "row slabs x%d (one process per GPU), %d halo rows exchanged every %d sweeps: %s"
                            % (world, r["halo"], r["halo"], transport),
         },
@@ -722,26 +738,8 @@ def main():
                 "launch_us": round(wl, 3),
                 "frac_per_gpu": round(BYTES_PER_CELL_SWEEP * w["rows_local"] * n / (wl * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
                 "note": "the other scaling mode, same run, fewer steps"}
-            # the same 8192^2 grid through the C-ABI in ONE process on all GPUs (EPIC_HIP_DEVICES; halos by
-            # hipMemcpyPeerAsync): rank 0 drives, the other ranks wait on the host with their GPUs idle
-            host_barrier()
-            if rank == 0 and backend == "nccl" and ndev >= world:
-                # (a child process: that path has never run on more than one device, and a fault there must not take this line
-                #  with it; the other ranks wait on the host with their GPUs idle)
-                import subprocess
-
-                env = {k: v for k, v in os.environ.items()
-                       if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
-                                    "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
-                try:
-                    r2 = subprocess.run([sys.executable, os.path.abspath(__file__), "--in-library-child", str(world), "--steps", str(args.steps),
-                                         "--math", args.math, "--size", str(n), "--develop", str(args.develop), "--stagger", str(args.stagger)],
-                                        env=env, capture_output=True, text=True, timeout=600)
-                    lines = [l for l in r2.stdout.splitlines() if l.startswith("{")]
-                    out["in_library"] = json.loads(lines[-1]) if lines else {"error": "rc %d: %s" % (r2.returncode, r2.stderr[-400:])}
-                except BaseException as exc:   # evidence leg only: never lose the headline line
-                    out["in_library"] = {"error": repr(exc)}
-            host_barrier()
+    if in_library is not None:
+        out["in_library"] = in_library
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

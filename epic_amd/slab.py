@@ -366,6 +366,41 @@ class SlabSolver:
             self.cur ^= 1
         self.iteration += 1
 
+    PAIR_HEIGHTS = (20, 23, 26, 29, 32, 35, 38, 40, 41, 43, 46, 49, 52, 58, 64)
+
+    def tune_pairs(self):
+        """Measure the task height of the fused double sweep on this slab, as the library does for its own grids
+        (epic_amd/csrc/harmonic_gpu.hip: tune_fused_rows -- the time of a pass depends on the height in a way no rule predicts):
+        every candidate runs three times from the current buffer into the other one, which the next real pass overwrites.
+        Slabs of at least 4 Mcell on a GPU; results do not depend on the height.  Returns the height in use (0: the rule)."""
+        be = self.backend
+        if (not self.cuda or self.redblack or not getattr(be, "pairs", False) or os.environ.get("EPIC_HIP_FUSED_ROWS")
+                or os.environ.get("EPIC_HIP_TUNE", "1")[:1] == "0" or self.rows * self.pitch < (1 << 22)):
+            return be.rows_per_pair
+        src, dst = self.buf[self.cur], self.buf[self.cur ^ 1]
+
+        def timed(height):
+            be.rows_per_pair = height
+            be.sweep2(src, dst, self.maskw, self.rows, self.pitch)          # warm
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            be.sweep2(src, dst, self.maskw, self.rows, self.pitch)
+            be.sweep2(src, dst, self.maskw, self.rows, self.pitch)
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1)
+
+        rule_ms = timed(0)
+        best, best_ms = 0, rule_ms
+        for height in self.PAIR_HEIGHTS:
+            if height >= self.rows:
+                continue
+            ms = timed(height)
+            if ms < best_ms:
+                best, best_ms = height, ms
+        be.rows_per_pair = best if best_ms < 0.99 * rule_ms else 0
+        return be.rows_per_pair
+
     def can_pair(self):
         """Two plain Jacobi iterations as ONE pass (backend.sweep2: the fused double sweep of the tol math, 4 B of HBM
         traffic per cell-update instead of 8): possible when neither of them ends with an exchange -- a pass leaves two
