@@ -42,11 +42,10 @@ struct Sweep3dArgs {
     int m0, m1, pitch;
     int plane_begin, plane_end;
     int nstrips, nchunks, nplane_groups;
-    int nblocks;  // logical blocks: nstrips * 8 cpx * nplane_groups (a tol launch holds fewer workgroups, which walk them)
+    int nblocks;  // logical blocks: nstrips * (chunks * plane groups padded to a multiple of 8) (a tol launch holds fewer workgroups, which walk them)
     int check_lo, check_hi;  // CHECK: only planes [check_lo, check_hi) count for max |du| (a slab's ghost planes do not)
     int parity;  // red-black scheme only: currentIteration & 1
     int rows;    // sweep3d_pair_kernel: x1-rows per task
-    int cpx;     // chunks per XCD = ceil(nchunks / 8): block order of the launches without work lists
     WakeArgs wake;  // TRACK kernels, whole-grid launches only
 };
 
@@ -166,14 +165,14 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB
         chunk = t % a.nchunks;
         x0 = t / a.nchunks;
     } else {
-        // XCD-aware order (workgroup vb runs on XCD vb % 8): the strips of a row and the neighbouring plane groups share one L2,
-        // the chunk selects the XCD (see sweep3d_pair_kernel)
-        int j = vb >> 3;
-        chunk = (vb & 7) + 8 * (j % a.cpx);
-        j /= a.cpx;
+        // XCD-aware order (workgroup vb runs on XCD vb % 8): the strips of a row share one L2, the (plane group, chunk) pairs are
+        // dealt over the XCDs in turn (see sweep3d_pair_kernel)
+        const int j = vb >> 3;
         strip = j % a.nstrips;
-        x0 = a.plane_begin + (j / a.nstrips) * kWavesPerBlock + wave;
-        if (chunk >= a.nchunks) x0 = a.plane_end;  // padding of the chunk count to a multiple of 8: a spare block
+        const int pair = (j / a.nstrips) * 8 + (vb & 7);
+        chunk = pair % a.nchunks;
+        x0 = a.plane_begin + (pair / a.nchunks) * kWavesPerBlock + wave;
+        if (pair >= a.nchunks * a.nplane_groups) x0 = a.plane_end;  // padding of the pair count to a multiple of 8: a spare block
     }
     if (x0 >= a.plane_end) {  // wave-uniform: the spare waves of the last plane group
         if (listed) break;
@@ -403,16 +402,17 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pa
     const int t_begin = X0M ? a.plane_begin : 0, t_end = X0M ? a.plane_end : a.m1, t_max = (X0M ? a.m0 : a.m1) - 1;
 
     for (int vb = blockIdx.x; vb < a.nblocks; vb += gridDim.x) {
-        // XCD-aware order: workgroup vb runs on XCD vb % 8 (round-robin dispatch; the grid is a multiple of 8), and everything that
-        // shares rows goes to ONE XCD's L2 -- the strips of a row (each fetches its neighbour's edge cell: with the strips on
-        // different XCDs that was a 128-byte line from HBM per 4 bytes used, 12 % of the sweep's reads) and the neighbouring
-        // plane groups.  The chunk selects the XCD.
-        int j = vb >> 3;
-        const int chunk = (vb & 7) + 8 * (j % a.cpx);
-        if (chunk >= a.nchunks) continue;                // wave-uniform (padding of the chunk count to a multiple of 8)
-        j /= a.cpx;
+        // XCD-aware order: workgroup vb runs on XCD vb % 8 (round-robin dispatch; the grid is a multiple of 8), and the strips of a
+        // row go to ONE XCD's L2 (each fetches its neighbour's edge cell: with the strips on different XCDs that was a 128-byte
+        // line from HBM per 4 bytes used, 12 % of the sweep's reads).  The (plane group, chunk) pairs are dealt over the XCDs in
+        // turn -- even for any chunk count; with a multiple of 8 chunks the chunk alone selects the XCD and the neighbouring
+        // plane groups share it too.
+        const int j = vb >> 3;
         const int strip = j % a.nstrips;
-        const int cA_raw = c_begin + ((j / a.nstrips) * kPairWaves + wave) * 2;
+        const int pair = (j / a.nstrips) * 8 + (vb & 7);
+        if (pair >= a.nchunks * a.nplane_groups) continue;   // wave-uniform (padding of the pair count to a multiple of 8)
+        const int chunk = pair % a.nchunks;
+        const int cA_raw = c_begin + ((pair / a.nchunks) * kPairWaves + wave) * 2;
 #if EPIC_PAIR_BARRIER_ROWS == 0
         if (cA_raw >= c_end) continue;                   // wave-uniform: the spare waves of the last group
 #endif
@@ -631,7 +631,10 @@ int sweep_3d_pair_rows(int m1)
     const char *e = getenv("EPIC_HIP_3D_PAIR_ROWS");
     const int v = e ? atoi(e) : 0;
     if (v > 0) return v < 4 ? 4 : v > 4096 ? 4096 : v;
-    return m1 < kPairRows ? m1 : kPairRows;
+    // a multiple of 8 chunks of about kPairRows rows where the grid allows it: the chunk alone then selects the XCD (see the kernel)
+    const int rounds = (m1 + 8 * kPairRows / 2) / (8 * kPairRows) > 0 ? (m1 + 8 * kPairRows / 2) / (8 * kPairRows) : 1;
+    const int rows = (m1 + 8 * rounds - 1) / (8 * rounds);
+    return rows < 4 ? 4 : rows;
 }
 }  // namespace
 
@@ -660,8 +663,7 @@ hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, i
     a.nstrips = (pitch + kStripCols - 1) / kStripCols;
     a.nchunks = (m1 + kRowsPerTask - 1) / kRowsPerTask;
     a.nplane_groups = (plane_end - plane_begin + kWavesPerBlock - 1) / kWavesPerBlock;
-    a.cpx = (a.nchunks + 7) / 8;
-    const long long nblocks = 8LL * a.cpx * a.nstrips * a.nplane_groups;   // chunks padded to whole rounds of the 8 XCDs
+    const long long nblocks = ((long long)a.nchunks * a.nplane_groups + 7) / 8 * 8 * a.nstrips;   // (group, chunk) pairs padded to whole rounds of the 8 XCDs
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
     a.nblocks = (int)nblocks;
     a.check_lo = check_begin < 0 ? plane_begin : check_begin;
@@ -681,8 +683,7 @@ hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, i
         const int march = x0m ? plane_end - plane_begin : m1, pairs = x0m ? m1 : plane_end - plane_begin;
         a.nchunks = (march + a.rows - 1) / a.rows;
         a.nplane_groups = (pairs + 2 * kPairWaves - 1) / (2 * kPairWaves);
-        a.cpx = (a.nchunks + 7) / 8;
-        const long long nb = 8LL * a.cpx * a.nstrips * a.nplane_groups;   // chunks padded to whole rounds of the 8 XCDs
+        const long long nb = ((long long)a.nchunks * a.nplane_groups + 7) / 8 * 8 * a.nstrips;   // (group, chunk) pairs padded to whole rounds of the 8 XCDs
         if (nb > 0x7fffffffLL) return hipErrorInvalidValue;
         a.nblocks = (int)nb;
         const dim3 block(kWave * kPairWaves);
