@@ -54,17 +54,20 @@ struct Sweep3dArgs {
 // one colour are recomputed (even_cols: the lane's .x and .z).  The cells go through the three phases of cell_update.h two at
 // a time: the table reads of one pair are in flight while the other pair is worked on.
 // (hs: the split of the row's two strip-edge cells hl / hr -- .x the left one's, .y the right one's)
+// In two halves, so that a wave that updates two rows can have the table reads of both in flight before it waits for any:
+// tol_row_3d_front -- everything up to the ISSUE of the reads (both pairs of cells; red-black: the one pair of this colour);
+// tol_row_3d_back<W0, W1> -- waits until at most W0 (W1) younger LDS reads are outstanding for the first (second) pair, and
+// finishes the cells.
+struct TolRowFront { TolPre2 pxz, pyw; TolLnPair f0, f1; };
 template <bool RB>
-__device__ __forceinline__ float4 tol_row_3d(const float4 &pa, const float4 &pb, const float4 &up, const float4 &c, const float4 &dn,
-                                             const Split4 &sa, const Split4 &sb, const Split4 &su, const Split4 &sc, const Split4 &sd,
-                                             float hl, float hr, const Split2 &hs, lmask m0, lmask m1, lmask m2, lmask m3, bool even_cols,
-                                             const TolLnEntry *tl)
+__device__ __forceinline__ TolRowFront tol_row_3d_front(const float4 &pa, const float4 &pb, const float4 &up, const float4 &c, const float4 &dn,
+                                                        const Split4 &sa, const Split4 &sb, const Split4 &su, const Split4 &sc, const Split4 &sd,
+                                                        float hl, float hr, const Split2 &hs, bool even_cols, const TolLnEntry *tl)
 {
     const float lf = wave_from_left(c.w, hl);
     const float rt = wave_from_right(c.x, hr);
     const float ql = wave_from_left(sc.qw, hs.q.x), qr = wave_from_right(sc.qx, hs.q.y);
     const uint32_t nl = f2u(wave_from_left(u2f(sc.nw), hs.zm.x)), nr = f2u(wave_from_right(u2f(sc.nx), hs.zm.y));
-    float4 o = c;
     auto pre_xz = [&] {
         return tol_pre2_3d(TolNb6{pa.x, pb.x, up.x, dn.x, lf, c.y, sa.qx, sb.qx, su.qx, sd.qx, ql, sc.qy, sa.nx, sb.nx, su.nx, sd.nx, nl, sc.ny},
                            TolNb6{pa.z, pb.z, up.z, dn.z, c.y, c.w, sa.qz, sb.qz, su.qz, sd.qz, sc.qy, sc.qw, sa.nz, sb.nz, su.nz, sd.nz, sc.ny, sc.nw});
@@ -73,37 +76,55 @@ __device__ __forceinline__ float4 tol_row_3d(const float4 &pa, const float4 &pb,
         return tol_pre2_3d(TolNb6{pa.y, pb.y, up.y, dn.y, c.x, c.z, sa.qy, sb.qy, su.qy, sd.qy, sc.qx, sc.qz, sa.ny, sb.ny, su.ny, sd.ny, sc.nx, sc.nz},
                            TolNb6{pa.w, pb.w, up.w, dn.w, c.z, rt, sa.qw, sb.qw, su.qw, sd.qw, sc.qz, qr, sa.nw, sb.nw, su.nw, sd.nw, sc.nz, nr});
     };
+    TolRowFront fr;
+    if (!RB) {
+        fr.pxz = pre_xz();
+        fr.f0 = tol_ln_issue<5>(fr.pxz, tl);
+        fr.pyw = pre_yw();
+        fr.f1 = tol_ln_issue<5>(fr.pyw, tl);
+    } else {   // red-black: the one pair of this colour, kept in pxz / f0 whichever it is
+        fr.pxz = even_cols ? pre_xz() : pre_yw();
+        fr.f0 = tol_ln_issue<5>(fr.pxz, tl);
+    }
+    return fr;
+}
+template <bool RB, int W0, int W1>
+__device__ __forceinline__ float4 tol_row_3d_back(TolRowFront &fr, const float4 &c, lmask m0, lmask m1, lmask m2, lmask m3, bool even_cols)
+{
+    float4 o = c;
     float nx, ny, nz, nw;
     TolLnRaw ea, eb;
     if (!RB) {
-        const TolPre2 pxz = pre_xz();
-        TolLnPair f0 = tol_ln_issue<5>(pxz, tl);
-        const TolPre2 pyw = pre_yw();
-        TolLnPair f1 = tol_ln_issue<5>(pyw, tl);
-        tol_ln_wait<2>(f0, ea, eb);
-        tol_post2(pxz, ea, eb, kLn6, nx, nz);
+        tol_ln_wait<W0>(fr.f0, ea, eb);
+        tol_post2(fr.pxz, ea, eb, kLn6, nx, nz);
         o.x = sel(m0, c.x, nx);
         o.z = sel(m2, c.z, nz);
-        tol_ln_wait<0>(f1, ea, eb);
-        tol_post2(pyw, ea, eb, kLn6, ny, nw);
+        tol_ln_wait<W1>(fr.f1, ea, eb);
+        tol_post2(fr.pyw, ea, eb, kLn6, ny, nw);
         o.y = sel(m1, c.y, ny);
         o.w = sel(m3, c.w, nw);
-    } else if (even_cols) {
-        const TolPre2 pxz = pre_xz();
-        TolLnPair f0 = tol_ln_issue<5>(pxz, tl);
-        tol_ln_wait<0>(f0, ea, eb);
-        tol_post2(pxz, ea, eb, kLn6, nx, nz);
-        o.x = sel(m0, c.x, nx);
-        o.z = sel(m2, c.z, nz);
-    } else {
-        const TolPre2 pyw = pre_yw();
-        TolLnPair f1 = tol_ln_issue<5>(pyw, tl);
-        tol_ln_wait<0>(f1, ea, eb);
-        tol_post2(pyw, ea, eb, kLn6, ny, nw);
-        o.y = sel(m1, c.y, ny);
-        o.w = sel(m3, c.w, nw);
+    } else {   // (one pair of reads per row: W1 counts the younger ones)
+        tol_ln_wait<W1>(fr.f0, ea, eb);
+        tol_post2(fr.pxz, ea, eb, kLn6, nx, nz);
+        if (even_cols) {
+            o.x = sel(m0, c.x, nx);
+            o.z = sel(m2, c.z, nz);
+        } else {
+            o.y = sel(m1, c.y, nx);
+            o.w = sel(m3, c.w, nz);
+        }
     }
+    (void)ny; (void)nw;
     return o;
+}
+template <bool RB>
+__device__ __forceinline__ float4 tol_row_3d(const float4 &pa, const float4 &pb, const float4 &up, const float4 &c, const float4 &dn,
+                                             const Split4 &sa, const Split4 &sb, const Split4 &su, const Split4 &sc, const Split4 &sd,
+                                             float hl, float hr, const Split2 &hs, lmask m0, lmask m1, lmask m2, lmask m3, bool even_cols,
+                                             const TolLnEntry *tl)
+{
+    TolRowFront fr = tol_row_3d_front<RB>(pa, pb, up, c, dn, sa, sb, su, sc, sd, hl, hr, hs, even_cols, tl);
+    return tol_row_3d_back<RB, 2, 0>(fr, c, m0, m1, m2, m3, even_cols);
 }
 
 template <bool RB>
@@ -511,18 +532,18 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pa
             (void)so_a; (void)so_b; (void)evenA; (void)ha; (void)hb; (void)esA; (void)esB;
 #else
             // the reference's order of the six neighbours: x0 - 1, x0 + 1, x1 - 1, x1 + 1, (x2 - 1, x2 + 1 inside tol_row_3d)
-            float4 oA, oB;
+            // both rows' table reads are issued before either is waited for (Jacobi: 8 reads in flight; red-black: 4): the row
+            // B's front end covers row A's round trip to LDS and the other way round
+            TolRowFront fA, fB;
             if (!X0M) {  // pair axis = x0, ring = x1
-                oA = tol_row_3d<RB>(pa[k], qB[k], qA[km], qA[k], qA[kp], so_a, sB[k], sA[km], sA[k], sA[kp], eA[k], eA[k], esA,
-                                    ha.m0, ha.m1, ha.m2, ha.m3, evenA, tl);
-                oB = tol_row_3d<RB>(qA[k], pb[k], qB[km], qB[k], qB[kp], sA[k], so_b, sB[km], sB[k], sB[kp], eB[k], eB[k], esB,
-                                    hb.m0, hb.m1, hb.m2, hb.m3, !evenA, tl);
+                fA = tol_row_3d_front<RB>(pa[k], qB[k], qA[km], qA[k], qA[kp], so_a, sB[k], sA[km], sA[k], sA[kp], eA[k], eA[k], esA, evenA, tl);
+                fB = tol_row_3d_front<RB>(qA[k], pb[k], qB[km], qB[k], qB[kp], sA[k], so_b, sB[km], sB[k], sB[kp], eB[k], eB[k], esB, !evenA, tl);
             } else {     // ring = x0, pair axis = x1
-                oA = tol_row_3d<RB>(qA[km], qA[kp], pa[k], qA[k], qB[k], sA[km], sA[kp], so_a, sA[k], sB[k], eA[k], eA[k], esA,
-                                    ha.m0, ha.m1, ha.m2, ha.m3, evenA, tl);
-                oB = tol_row_3d<RB>(qB[km], qB[kp], qA[k], qB[k], pb[k], sB[km], sB[kp], sA[k], sB[k], so_b, eB[k], eB[k], esB,
-                                    hb.m0, hb.m1, hb.m2, hb.m3, !evenA, tl);
+                fA = tol_row_3d_front<RB>(qA[km], qA[kp], pa[k], qA[k], qB[k], sA[km], sA[kp], so_a, sA[k], sB[k], eA[k], eA[k], esA, evenA, tl);
+                fB = tol_row_3d_front<RB>(qB[km], qB[kp], qA[k], qB[k], pb[k], sB[km], sB[kp], sA[k], sB[k], so_b, eB[k], eB[k], esB, !evenA, tl);
             }
+            const float4 oA = tol_row_3d_back<RB, 6, (RB ? 2 : 4)>(fA, qA[k], ha.m0, ha.m1, ha.m2, ha.m3, evenA);
+            const float4 oB = tol_row_3d_back<RB, 2, 0>(fB, qB[k], hb.m0, hb.m1, hb.m2, hb.m3, !evenA);
 #endif
             const bool chk_t = !X0M || (t >= a.check_lo && t < a.check_hi);  // scalar
             if (chkA && chk_t) fold(qA[k], oA);
