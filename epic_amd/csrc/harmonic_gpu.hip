@@ -1804,6 +1804,23 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
         float last_check = -1.0f;  // no check yet
         ~Handover() { if (done) { c->redblack = false; force_all(c); } }
     } handover{c};   // (the context outlives this function: it still holds the field and the mask)
+    // Finish (tol math only; EPIC_HIP_TOL_FINISH=0 switches it off).  Where a converged f32 field ends inside the iteration's
+    // dead band is decided by the last few per cent of the iterations, and the parity bar is on the reference's end point:
+    // so at the first check with delta < 10 epsilon this loop leaves the tol arithmetic and continues with THE REFERENCE'S OWN
+    // ITERATION -- red-black half-sweeps with the bit-exact expf / logf, what the library runs by default from the start --
+    // and only a check of that phase may end it.  Measured with the checker (oracle_tol_complete states the same rule) on the
+    // reference's maps: umass.png 1.6e-5 -> 1.4e-6 from harmonic_complete_cpu's field, after 86 101 + 8 101 iterations against the
+    // reference's 94 401; maze 1.4e-6 -> 5.6e-7 (52 001 + 3 501); basic 3.3e-6 -> 2.3e-7 (19 601 + 4 301).  More than nine
+    // iterations in ten still run at the tol kernels' speed, and the finishing ones find most tiles at rest.
+    struct Finish {
+        Ctx *c;
+        int math0;
+        bool redblack0, on = false;
+        ~Finish() { if (on) { c->math = math0; c->redblack = redblack0; force_all(c); } }
+    } finish{c, c->math, c->redblack};
+    const char *fin_env = getenv("EPIC_HIP_TOL_FINISH");
+    const bool finish_wanted = c->math == 4 && !(fin_env && fin_env[0] == '0');
+    const float finish_below = 10.0f * harmonic->epsilon;
     const unsigned stagger = harmonic->numIterationsToStaggerCheck;
     result = EPIC_SUCCESS;
     while (result != EPIC_SUCCESS_AND_CONVERGED || harmonic->currentIteration < mMax) {
@@ -1813,7 +1830,13 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
                 report(fn, "Failed to perform the Jacobi update and check step.");
                 return result;
             }
-            if (!c->redblack && result == EPIC_SUCCESS && harmonic->delta < 1.0f && handover.last_check >= 0.0f &&
+            if (finish_wanted && !finish.on && harmonic->delta < finish_below) {
+                finish.on = true;
+                c->math = 0;          // precise
+                c->redblack = true;   // the reference's half-sweeps, colour by currentIteration
+                force_all(c);
+                result = EPIC_SUCCESS;   // only a check of the finishing phase may end the loop
+            } else if (!c->redblack && result == EPIC_SUCCESS && harmonic->delta < 1.0f && handover.last_check >= 0.0f &&
                 harmonic->delta >= handover.last_check) {
                 c->redblack = true;
                 force_all(c);

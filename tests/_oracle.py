@@ -99,6 +99,8 @@ def oracle():
         lib.oracle_reset_counters.restype = None
         lib.oracle_tol_run.argtypes = (P, ct.c_uint, ct.c_int)      # oracle/tol_checker.c
         lib.oracle_tol_complete.argtypes = (P, ct.c_int)
+        lib.oracle_tol_set_finish.argtypes = (ct.c_int,)
+        lib.oracle_tol_set_finish.restype = None
         lib.oracle_tol_split.argtypes = (ct.POINTER(ct.c_float), ct.c_size_t, ct.POINTER(ct.c_float), ct.POINTER(ct.c_int))
         lib.oracle_tol_split.restype = None
         lib.oracle_libm_mismatches.restype = ct.c_size_t

@@ -32,7 +32,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
 E = eh._epic
 NT = 1024
 CONVERGED_TOL = 1e-5
-UMASS_REGRESSION_GUARD = 2e-5   # the tol mode's known miss on umass.png is 1.6e-5: see test_tol_umass_is_within_the_stated_bar
+UMASS_REGRESSION_GUARD = 2e-5   # the tol ITERATION ALONE ends 1.6e-5 from the reference on umass.png: test_tol_iteration_alone_misses_the_bar_on_umass
 
 
 def make(m, u, locked, eps=1e-6, stagger=100):
@@ -333,13 +333,13 @@ def test_tol_complete_gpu_vs_reference_golden(goldens, name, tol_env):
     assert_close(h.u_array(), g[name + "/converged"], g[name + "/locked"], CONVERGED_TOL, name)
 
 
-def _tol_map_run(goldens, name, record_property):
+def _tol_map_run(goldens, name, record_property, iteration_slack=0.02):
     want = goldens["maps"][name + "/converged_1e-06"]
     run = goldens["manifest"]["maps"][name]["runs"]["1e-06"]
     h = HarmonicMap().load(os.path.join(O.ROOT, "tests", "golden", "maps", name + ".png"))
     h.solve(process="gpu", epsilon=1e-6)
     assert h.delta < 1e-6
-    assert abs(h.currentIteration - run["iterations"]) <= 0.02 * run["iterations"]
+    assert abs(h.currentIteration - run["iterations"]) <= iteration_slack * run["iterations"]
     free = h.locked_array().ravel() == 0
     got = h.u_array().ravel()
     assert np.array_equal(got[~free], want[~free])
@@ -347,37 +347,41 @@ def _tol_map_run(goldens, name, record_property):
     worst, absmax = float((d / np.maximum(1.0, np.abs(want[free]))).max()), float(d.max())
     record_property("max_rel_err", worst)
     record_property("max_abs_err", absmax)
-    print(f"tol {name}: {h.currentIteration} sweeps (reference {run['iterations']} half-sweeps), delta {h.delta:.3e}, "
+    print(f"tol {name}: {h.currentIteration} iterations (reference {run['iterations']} half-sweeps), delta {h.delta:.3e}, "
           f"max rel {worst:.3e}, max abs {absmax:.3e}")
     return worst
 
 
-@pytest.mark.parametrize("name", ["basic", "maze"])
-def test_tol_maps_converge_under_jacobi_by_the_reference_test(goldens, name, tol_env, record_property):
-    """BASELINE configs 1-2 with the tol arithmetic, Jacobi: the reference's absolute test max |du| < 1e-6 fires (the
-    packed double-float mode of round 1 never terminated on umass under Jacobi), after about as many iterations as the
-    reference needed, and the field is within the stated bar of the reference's."""
-    assert _tol_map_run(goldens, name, record_property) <= CONVERGED_TOL
+FINISHED_TOL = 2e-6   # tol relaxations that finish with the reference's iteration: measured 1.4e-6 (umass), 5.6e-7 (maze), 2.3e-7 (basic)
 
 
-@pytest.mark.xfail(strict=True, reason="KNOWN MISS of the tol mode: umass.png converges 1.6e-5 max(1, |u|) from the reference's field, "
-                                       "above the stated 1e-5 (DESIGN.md section 2; the bit-exact default mode meets it)")
-def test_tol_umass_is_within_the_stated_bar(goldens, tol_env, record_property):
-    """BASELINE config 2 (maps/umass.yaml) with the tol arithmetic: stops by the reference's test after about the
-    reference's number of iterations, but ends 1.6e-5 (relative; 2.4e-4 absolute at |u| ~ 12) from the reference's
-    field.  Kept as an EXPECTED FAILURE against the stated bar -- a miss that is reported, not a tolerance that was widened;
-    strict, so that an arithmetic that closes the gap shows up as XPASS.  What the study found: on this map the stagnation
-    point of the f32 iteration moves by ~2e-4 under any change of the noise below the roundings; an arithmetic whose exp
-    and log are CORRECTLY ROUNDED (99.95 % of terms equal to glibc's) lands 1.0e-6 away, so the bar is a statement about the
-    reference's bits (tools/cr_study.c)."""
+@pytest.mark.parametrize("name", ["basic", "maze", "umass"])
+def test_tol_maps_converge_within_the_bar_with_the_finishing_iterations(goldens, name, tol_env, record_property):
+    """BASELINE configs 1-2 with the tol arithmetic as the library runs it by default (Jacobi here): the loop leaves the tol
+    arithmetic at the first check with delta < 10 eps and finishes with the reference's own iteration (harmonic_execute_gpu,
+    "Finish"; oracle_tol_complete states the same rule).  ALL THREE maps end within the 1e-5 bar -- umass.png, which the tol
+    iteration alone misses (1.6e-5, next test), at 1.4e-6 -- after about the reference's number of iterations (maze: 52 001 +
+    3 501 against 52 101, the tol phase freezes between two checks there)."""
+    assert _tol_map_run(goldens, name, record_property, iteration_slack=0.08) <= FINISHED_TOL
+
+
+def test_tol_iteration_alone_misses_the_bar_on_umass(goldens, tol_env, record_property, monkeypatch):
+    """EPIC_HIP_TOL_FINISH=0: the tol iteration to the end.  It stops by the reference's test after about the reference's number
+    of iterations, but on maps/umass.png it ends 1.6e-5 (relative; 2.4e-4 absolute at |u| ~ 12) from the reference's field --
+    outside the stated 1e-5.  Recorded here as what it is (and held to its size, so that a regression of the arithmetic shows):
+    where a converged f32 field ends inside the iteration's dead band is decided by the last iterations, which is why the
+    default finishes with the reference's own (tools/cr_study.c)."""
+    monkeypatch.setenv("EPIC_HIP_TOL_FINISH", "0")
     worst = _tol_map_run(goldens, "umass", record_property)
-    assert worst <= UMASS_REGRESSION_GUARD, "further from the reference than the known miss"   # (XFAIL either way; read the log)
-    assert worst <= CONVERGED_TOL
+    assert CONVERGED_TOL < worst <= UMASS_REGRESSION_GUARD
 
 
-def test_tol_umass_known_miss_has_not_grown(goldens, tol_env, record_property):
-    """The same run held to the size of the known miss, so that a regression of the arithmetic cannot hide behind the xfail."""
-    assert _tol_map_run(goldens, "umass", record_property) <= UMASS_REGRESSION_GUARD
+@pytest.mark.parametrize("name", ["basic", "maze"])
+def test_tol_iteration_alone_on_the_other_maps(goldens, name, tol_env, record_property, monkeypatch):
+    """The same without the finishing iterations: within the bar on these two (3.3e-6, 1.4e-6), stopping by the reference's
+    absolute test under Jacobi (the packed double-float mode of round 1 never did on umass)."""
+    monkeypatch.setenv("EPIC_HIP_TOL_FINISH", "0")
+    assert _tol_map_run(goldens, name, record_property) <= CONVERGED_TOL
 
 
 def test_tol_jacobi_and_redblack_end_in_the_same_field(goldens, tol_env):
