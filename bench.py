@@ -188,6 +188,9 @@ def parity_object(args, E, MODES, relaxed, locked_8192):
         return h.u_array().ravel().copy(), int(h.currentIteration)
 
     out = {"mode": {"math": args.math, "scheme": args.scheme}, "bar": "|du| <= 1e-5 max(1, |u|) over reached free cells",
+           "finish": ("tol relaxations leave the tol arithmetic at the first check with delta < 10 eps and finish with the reference's own "
+                      "iteration (precise red-black): the library's default for harmonic_execute_gpu / harmonic_complete_gpu; "
+                      "`tol_iteration_alone` repeats a config with EPIC_HIP_TOL_FINISH=0") if args.math == "tol" else None,
            "configs": {}}
     try:
         maps = np.load(os.path.join(gdir, "maps_converged.npz"))
@@ -196,6 +199,16 @@ def parity_object(args, E, MODES, relaxed, locked_8192):
             got, its = complete(h, args.math, args.scheme)
             e = dist(got, maps[name + "/converged_1e-06"], h.locked_array())
             e.update(iterations=its, against="harmonic_complete_cpu's converged field (tests/golden/maps_converged.npz)")
+            if args.math == "tol" and os.environ.get("EPIC_HIP_TOL_FINISH") is None:
+                os.environ["EPIC_HIP_TOL_FINISH"] = "0"     # the tol iteration to the end, for the record
+                try:
+                    h = HarmonicMap().load(os.path.join(gdir, "maps", name + ".png"))
+                    got0, its0 = complete(h, args.math, args.scheme)
+                    e0 = dist(got0, maps[name + "/converged_1e-06"], h.locked_array())
+                    e["tol_iteration_alone"] = {"max_rel": e0["max_rel"], "max_abs": e0["max_abs"], "within_bar": e0["within_bar"],
+                                                "iterations": its0}
+                finally:
+                    del os.environ["EPIC_HIP_TOL_FINISH"]
             out["configs"][cfg] = e
         synth = np.load(os.path.join(gdir, "synthetic_converged.npz"))
         for n in (512, 1024):
@@ -595,8 +608,12 @@ def main():
             other = "redblack" if args.scheme == "jacobi" else "jacobi"
             legs = [("relax", args.math, args.scheme, 2), ("relax_" + other, args.math, other, 2),
                     ("relax_untracked", args.math, args.scheme, 0), ("relax_default", "precise", "redblack", 2)]
+            if args.math == "tol" and os.environ.get("EPIC_HIP_TOL_FINISH") is None:
+                legs.append(("relax_tol_alone", args.math, args.scheme, 2))   # without the finishing iterations, for the record
             work = ct.c_double(0.0)
             for key, math, scheme, track in legs:
+                if key == "relax_tol_alone":
+                    os.environ["EPIC_HIP_TOL_FINISH"] = "0"
                 h.u_array().ravel()[:] = u0
                 assert E.harmonic_update_model_gpu(h) == 0
                 assert E.epic_hip_set_math_mode(h, MODES[math]) == 0
@@ -606,11 +623,16 @@ def main():
                 t0 = time.perf_counter()
                 rc = E.harmonic_execute_gpu(h, 1024)
                 dt = time.perf_counter() - t0
+                os.environ.pop("EPIC_HIP_TOL_FINISH", None) if key == "relax_tol_alone" else None
                 assert rc == 0, rc
                 its = int(h.currentIteration)
                 assert E.epic_hip_work_done(h, ct.byref(work), 0) == 0    # whole-grid iterations' worth of tiles actually run
-                every = updates_in(scheme, its)                             # every unlocked cell (of the colour) once per iteration
+                # tol: the loop finishes with the reference's own iteration (red-black half-sweeps) from iteration `fin` on
+                fin = int(E.epic_hip_finish_iteration(h))
+                every = (updates_in(scheme, its) if fin == 0 else                 # every unlocked cell (of the colour) once per iteration
+                         updates_in(scheme, fin) + updates_in("redblack", its - fin, fin))
                 out[key] = {
+                    "finishing_iterations": (its - fin) if fin else 0,
                     "math": math, "scheme": scheme, "activity_tracking": bool(track), "epsilon": 1e-6, "iterations": its,
                     "seconds": round(dt, 3), "delta": float(h.delta), "grid_iterations_run": round(work.value, 1),
                     "recomputed_Mcell_updates_per_s": round(every * (work.value / its) / dt / 1e6, 1),
@@ -619,7 +641,10 @@ def main():
                             "kernels recomputed (iterations x unlocked cells of the colour x the share of tiles that ran, "
                             "epic_hip_work_done); effective = the same with every tile counted, i.e. the rate an untracked "
                             "solver would need for this time-to-solution -- tiles skipped by activity tracking hold exactly the "
-                            "values the update would have produced"}
+                            "values the update would have produced.  finishing_iterations: tol math -- the last iterations of the call "
+                            "are the reference's own (precise red-black half-sweeps, from the first check with delta < 10 eps on), "
+                            "which is what puts the converged field within the parity bar on every config; relax_tol_alone is the same "
+                            "leg with EPIC_HIP_TOL_FINISH=0"}
                 if key in ("relax", "relax_default"):
                     relaxed[key] = h.u_array().ravel().copy()
             assert E.epic_hip_set_math_mode(h, MODES[args.math]) == 0

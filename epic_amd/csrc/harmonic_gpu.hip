@@ -135,6 +135,7 @@ struct Ctx {
     // Task height of the fused passes, measured on this grid (tune_fused_rows): [0] two Jacobi iterations (tol), [1] two
     // red-black iterations (tol), [2] two red-black iterations (precise / fast).  0 = not measured yet, -1 = not to be measured.
     int tuned_rows[3] = {0, 0, 0};
+    unsigned finish_from = 0;      // harmonic_execute_gpu, tol math: first iteration of the finishing phase of the latest call (0: none)
     int math = 0;                  // 0 = precise (default), 1 = fast, 2 = traffic, 4 = tol; EPIC_HIP_MATH / epic_hip_set_math_mode
     // Launch-bound grids replay the plain sweeps between two checks from a captured hipGraph; key = (count, starting
     // buffer, starting parity, math, scheme, rows_per_task, fused-pass configuration) -- everything a captured launch
@@ -1775,6 +1776,7 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
     harmonic->currentIteration = 0;
     fold_listed_work(c);
     c->work_full = 0.0;  // epic_hip_work_done counts from here
+    c->finish_from = 0;
     int result = harmonic_initialize_gpu(harmonic, numThreads);
     if (result != EPIC_SUCCESS) {
         report(fn, "Failed to initialize GPU variables.");
@@ -1832,6 +1834,7 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
             }
             if (finish_wanted && !finish.on && harmonic->delta < finish_below) {
                 finish.on = true;
+                c->finish_from = harmonic->currentIteration;
                 c->math = 0;          // precise
                 c->redblack = true;   // the reference's half-sweeps, colour by currentIteration
                 force_all(c);
@@ -2078,6 +2081,12 @@ int epic_hip_iterations_per_pass(Harmonic *harmonic)
     const bool rb_fused = c->redblack && c->n == 2 && !no_fuse && !c->track && c->math != 4 &&
                           (long long)c->rows * c->pitch >= (1ll << 22);
     return rb_fused ? 2 : 1;
+}
+
+unsigned int epic_hip_finish_iteration(Harmonic *harmonic)
+{
+    Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
+    return c ? c->finish_from : 0u;
 }
 
 int epic_hip_fused_rows_per_task(Harmonic *harmonic)

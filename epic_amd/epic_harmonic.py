@@ -125,6 +125,7 @@ _SIGNATURES = {
     "epic_hip_set_rows_per_task": (_H, ct.c_uint),
     "epic_hip_iterations_per_pass": (_H,),
     "epic_hip_fused_rows_per_task": (_H,),
+    "epic_hip_finish_iteration": (_H,),
     "epic_hip_set_math_mode": (_H, ct.c_int),
     "epic_hip_set_scheme": (_H, ct.c_int),
     "epic_hip_set_activity_tracking": (_H, ct.c_int),

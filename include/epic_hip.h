@@ -55,6 +55,14 @@ int epic_hip_iterations_per_pass(EpicHarmonicT *harmonic);
  * the rule's value.  EPIC_HIP_TUNE=0 keeps the rule; EPIC_HIP_FUSED_ROWS / epic_hip_set_rows_per_task fix the height. */
 int epic_hip_fused_rows_per_task(EpicHarmonicT *harmonic);
 
+/* tol math, harmonic_execute_gpu / harmonic_complete_gpu: the loop leaves the tol arithmetic at the first check with
+ * delta < 10 epsilon and FINISHES with the reference's own iteration (red-black half-sweeps, bit-exact expf / logf), and only
+ * a check of that phase may end it -- the converged field is then the end point of the reference's iteration from a state
+ * within a few 1e-5 of it: maps/umass.png 1.4e-6 from harmonic_complete_cpu's field instead of 1.6e-5.
+ * EPIC_HIP_TOL_FINISH=0 in the environment keeps the tol iteration to the end.  Returns the iteration number at which the
+ * finishing phase of the latest call began (0: it had none). */
+unsigned int epic_hip_finish_iteration(EpicHarmonicT *harmonic);
+
 /* Tuning knob: rows marched by one wave in the 2-D kernel (0 = automatic).  Also EPIC_HIP_ROWS_PER_TASK. */
 int epic_hip_set_rows_per_task(EpicHarmonicT *harmonic, unsigned int rows_per_task);
 
