@@ -71,9 +71,11 @@ int epic_hip_set_rows_per_task(EpicHarmonicT *harmonic, unsigned int rows_per_ta
  *   4 tol                one exp-class split e^u = q 2^n per CELL (packed f32 polynomial), shared by the cells it is a
  *                        neighbour of, one table-driven log per cell (256 intervals per binade, exact f32 reduction,
  *                        2^-33 accurate); every rounding stage of the reference kept.  2-D and 3-D,
- *                        Jacobi and red-black.  Jacobi stops by the reference's own test; converged fields within
- *                        1e-5 max(1, |u|) of the reference's on its seeded grids, basic.png and maze.png, 1.6e-5 on the
- *                        ill-conditioned umass.png.  ~1.35x faster per sweep than precise, ~1.5x where pairs of
+ *                        Jacobi and red-black.  Jacobi stops by the reference's own test.  harmonic_execute_gpu /
+ *                        harmonic_complete_gpu finish a tol relaxation with the reference's own iteration
+ *                        (epic_hip_finish_iteration, above): converged fields within 1e-5 max(1, |u|) of the reference's
+ *                        on every map and grid under test, 1.4e-6 on the ill-conditioned umass.png (the tol iteration
+ *                        alone: 1.6e-5 there).  ~1.3x faster per sweep than precise, ~1.75x where pairs of
  *                        iterations run as one fused pass (epic_hip_iterations_per_pass); the benchmarked mode;
  *   1 fast               v_exp_f32 / v_log_f32: biased, ~1e-4 relative drift on ill-conditioned maps; no parity claim;
  *   2 traffic            diagnostic: same loads/stores, trivial arithmetic (2-D only).
