@@ -177,6 +177,37 @@ def test_measured_task_height_of_the_fused_passes_changes_nothing_but_time(math,
     print("fused pass, math %d scheme %d on %s: rule %d rows, measured %d" % (math, scheme, m, rule, rows))
 
 
+@pytest.mark.parametrize("name", ["g2d_64", "g2d_70x66_dense", "g2d_8x300", "g2d_32"])
+@pytest.mark.parametrize("finish", [1, 0])
+def test_slab_driver_solves_tol_like_the_library_and_the_checker(goldens, name, finish, monkeypatch):
+    """SlabSolver.solve() (epic_amd/slab.py, one slab) with the tol math states the rules of harmonic_execute_gpu -- Jacobi
+    handover, and the finishing iterations (the reference's own, from the first check with delta < 10 eps on) -- so its field,
+    iteration count and delta are oracle_tol_complete's and harmonic_complete_gpu's, bit for bit, with the rule on and off."""
+    import torch
+
+    from epic_amd.slab import SlabSolver
+
+    monkeypatch.setenv("EPIC_HIP_TOL_FINISH", str(finish))
+    lib = O.oracle()
+    lib.oracle_tol_set_finish(finish)
+    try:
+        g, info = goldens["small"], goldens["manifest"]["small"][name]
+        m = [int(x) for x in g[name + "/m"]]
+        p = O.Problem(m, g[name + "/u0"], g[name + "/locked"], info["epsilon"], info["stagger"])
+        assert lib.oracle_tol_complete(ct.byref(p.h), 0) == 0
+        s = SlabSolver(m, 0, 1, device=torch.device("cuda:0"), stagger=info["stagger"], epsilon=info["epsilon"], math="tol")
+        s.load_rows(np.asarray(g[name + "/u0"]).reshape(m), np.asarray(g[name + "/locked"]).reshape(m))
+        its = s.solve()
+        assert its == p.h.currentIteration and np.float32(s.delta) == np.float32(p.h.delta)
+        assert np.array_equal(np.asarray(s.owned()).ravel(), p.u)
+        monkeypatch.setenv("EPIC_HIP_MATH", "tol")
+        h = make(m, g[name + "/u0"], g[name + "/locked"], info["epsilon"], info["stagger"])
+        assert E.harmonic_complete_gpu(h, NT) == 0
+        assert h.currentIteration == its and np.array_equal(h.u_array().ravel(), p.u)
+    finally:
+        lib.oracle_tol_set_finish(1)
+
+
 FUSED_GRIDS = [([16, 16], 1, 0.05), ([23, 37], 4, 0.10), ([3, 3], 6, 0.0), ([3, 70], 6, 0.0), ([70, 3], 6, 0.0),
                ([8, 300], 7, 0.05), ([70, 66], 8, 0.30), ([257, 513], 9, 0.05), ([64, 1030], 10, 0.05), ([96, 249], 6, 0.05),
                ([211, 530], 12, 0.06), ([1200, 3000], 5, 0.05)]
