@@ -15,7 +15,9 @@ The arithmetic is the library's `tol` mode by default (--math): one exp-class sp
 the reference's rounding stages kept.  It is a TOLERANCE mode, and the line says how far it is from the reference: the
 `parity` object holds, per BASELINE config, the measured distance of the converged field from the reference's (fields the
 reference itself converged, tests/golden/; at 8192^2 and 512^3 the library's reference-identical default mode, relaxed in this
-same run) next to the 1e-5 bar -- including the one config that MISSES it (umass.png, 1.6e-5).  The bit-exact `precise` mode
+same run) next to the 1e-5 bar.  A tol relaxation finishes with the reference's own iteration (from the first check with
+delta < 10 eps on; harmonic_execute_gpu, "Finish"): with that every config is within the bar; what the tol iteration ALONE
+does is recorded beside it (`tol_iteration_alone`: umass.png 1.6e-5, outside the bar) and timed (`relax_tol_alone`).  The bit-exact `precise` mode
 is timed beside it (`kernels.precise`), and `relax_default` is the whole relaxation as the unchanged ROS plugin gets it
 (no environment: precise + red-black, bit-identical to harmonic_complete_cpu).
 
