@@ -463,7 +463,7 @@ void drop_graphs(Ctx *c)
 int fused_rows_per_task(const Ctx *c)
 {
     if (c->rows_per_task > 0) return std::max(c->rows_per_task, 4);
-    if (c->tuned_rows[2] > 0 && !c->multi()) return c->tuned_rows[2];
+    if (c->tuned_rows[2] > 0) return c->tuned_rows[2];   // (several devices: measured on the first slab)
     const long long nstrips = (c->pitch + 247) / 248;
     long long r = (long long)c->rows * nstrips / 8192 / 8 * 8;
     return (int)std::min<long long>(64, std::max<long long>(16, r));
@@ -491,7 +491,7 @@ int jacobi_fused_rows_per_task(const Ctx *c)
     const char *e = getenv("EPIC_HIP_FUSED_ROWS");  // experiment / test knob
     if (e && atoi(e) > 0) return atoi(e);
     const int tuned = c->tuned_rows[c->redblack ? 1 : 0];
-    if (tuned > 0 && !c->multi()) return tuned;
+    if (tuned > 0) return tuned;   // (several devices: measured on the first slab)
     const long long rows = c->multi() ? c->rows / (long long)c->slabs.size() : c->rows;
     return epic_hip::jacobi_fused_auto_rows((int)rows, c->pitch);
 }
@@ -511,27 +511,33 @@ void tune_fused_rows(Ctx *c, int kind, unsigned iteration)
     if (iteration < (unsigned)std::min(c->rows, c->cols) / 2) return;
     c->tuned_rows[kind] = -1;
     const char *t = getenv("EPIC_HIP_TUNE");
-    if ((t && t[0] == '0') || c->multi() || c->n != 2 || c->rows_per_task > 0 || getenv("EPIC_HIP_FUSED_ROWS") != nullptr) return;
-    if ((long long)c->rows * c->pitch < (1ll << 22)) return;
+    if ((t && t[0] == '0') || c->n != 2 || c->rows_per_task > 0 || getenv("EPIC_HIP_FUSED_ROWS") != nullptr) return;
+    // several devices: the first slab stands for all (they are of one size within a row), on its own device and stream
+    const bool multi = c->multi();
+    DeviceGuard restore_device;
+    if (multi && hipSetDevice(c->slabs[0].dev) != hipSuccess) { (void)hipGetLastError(); return; }
+    const int rows = multi ? c->slabs[0].rows : c->rows;
+    const hipStream_t stream = multi ? c->slabs[0].stream : c->stream;
+    const float *in = multi ? c->slabs[0].buf[c->cur] : c->buf[c->cur];
+    float *out = multi ? c->slabs[0].buf[c->cur ^ 1] : c->buf[c->cur ^ 1];
+    const uint32_t *maskw = multi ? c->slabs[0].maskw : c->maskw, *maskf = multi ? c->maskf(c->slabs[0]) : c->maskf();
+    if ((long long)rows * c->pitch < (1ll << 22)) return;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(c->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { c->tuned_rows[kind] = 0; return; }
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { c->tuned_rows[kind] = 0; return; }
     const int dflt = kind == 2 ? fused_rows_per_task(c) : jacobi_fused_rows_per_task(c);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess) return;
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return; }
-    auto launch = [&](int rows) -> hipError_t {
-        if (kind == 2)
-            return epic_hip::launch_rb_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch, rows, c->math, 0, c->stream,
-                                                c->maskf());
-        return epic_hip::launch_jacobi_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch, rows, c->math, c->stream,
-                                                kind == 1 ? 0 : -1, c->maskf());
+    auto launch = [&](int height) -> hipError_t {
+        if (kind == 2) return epic_hip::launch_rb_fused_2d(in, out, maskw, rows, c->pitch, height, c->math, 0, stream, maskf);
+        return epic_hip::launch_jacobi_fused_2d(in, out, maskw, rows, c->pitch, height, c->math, stream, kind == 1 ? 0 : -1, maskf);
     };
-    auto timed = [&](int rows, float *ms) -> bool {
-        if (launch(rows) != hipSuccess) return false;   // warm
-        if (hipEventRecord(e0, c->stream) != hipSuccess) return false;
+    auto timed = [&](int height, float *ms) -> bool {
+        if (launch(height) != hipSuccess) return false;   // warm
+        if (hipEventRecord(e0, stream) != hipSuccess) return false;
         for (int i = 0; i < 2; ++i)
-            if (launch(rows) != hipSuccess) return false;
-        return hipEventRecord(e1, c->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+            if (launch(height) != hipSuccess) return false;
+        return hipEventRecord(e1, stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
                hipEventElapsedTime(ms, e0, e1) == hipSuccess;
     };
     static const int kCandidates[] = {20, 23, 26, 29, 32, 35, 38, 40, 41, 43, 46, 49, 52, 58, 64};
@@ -539,10 +545,10 @@ void tune_fused_rows(Ctx *c, int kind, unsigned iteration)
     float best_ms = 0.0f, dflt_ms = 0.0f;
     int best = 0;
     bool ok = timed(dflt, &dflt_ms);
-    if (say && ok) fprintf(stderr, "[epic_hip tune] kind %d, %d x %d: rule %d rows %.1f us", kind, c->rows, c->cols, dflt, dflt_ms * 500.0f);
+    if (say && ok) fprintf(stderr, "[epic_hip tune] kind %d, %d x %d%s: rule %d rows %.1f us", kind, rows, c->cols, multi ? " (first slab)" : "", dflt, dflt_ms * 500.0f);
     for (int r : kCandidates) {
         if (!ok) break;
-        if (r == dflt || r > c->rows) continue;
+        if (r == dflt || r > rows) continue;
         float ms = 0.0f;
         ok = timed(r, &ms);
         if (say && ok) fprintf(stderr, ", %d: %.1f", r, ms * 500.0f);
@@ -1143,6 +1149,7 @@ hipError_t multi_run(Ctx *c, unsigned count, unsigned first, bool check_first)
             const unsigned it0 = first + done;
             const bool chk = check_first && done == 0;
             const int cur0 = c->cur;
+            if (fuse && n_calm >= 2) tune_fused_rows(c, fuse_rb ? 2 : c->redblack ? 1 : 0, it0);
             const int fused_rpt = !fuse ? 0 : fuse_rb ? fused_rows_per_task(c) : jacobi_fused_rows_per_task(c);
             hipError_t e = for_each_slab(c, [&, it0, chk, cur0, fused_rpt, n_calm](int k) -> hipError_t {
                 Ctx::Slab &sl = c->slabs[k];
