@@ -540,7 +540,7 @@ void tune_fused_rows(Ctx *c, int kind, unsigned iteration)
         return hipEventRecord(e1, stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
                hipEventElapsedTime(ms, e0, e1) == hipSuccess;
     };
-    static const int kCandidates[] = {20, 23, 26, 29, 32, 35, 38, 40, 41, 43, 46, 49, 52, 58, 64};
+    static const int kCandidates[] = {20, 23, 26, 29, 32, 35, 38, 40, 41, 43, 46, 49, 52, 58, 64, 80, 96, 128};   // (the tall ones: grids of many rounds, 32768^2)
     const bool say = getenv("EPIC_HIP_TUNE_DEBUG") != nullptr;   // the table on stderr
     float best_ms = 0.0f, dflt_ms = 0.0f;
     int best = 0;

@@ -366,7 +366,7 @@ class SlabSolver:
             self.cur ^= 1
         self.iteration += 1
 
-    PAIR_HEIGHTS = (20, 23, 26, 29, 32, 35, 38, 40, 41, 43, 46, 49, 52, 58, 64)
+    PAIR_HEIGHTS = (20, 23, 26, 29, 32, 35, 38, 40, 41, 43, 46, 49, 52, 58, 64, 80, 96, 128)
 
     def tune_pairs(self):
         """Measure the task height of the fused double sweep on this slab, as the library does for its own grids
