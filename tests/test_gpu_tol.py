@@ -364,6 +364,34 @@ def test_tol_complete_gpu_vs_reference_golden(goldens, name, tol_env):
     assert_close(h.u_array(), g[name + "/converged"], g[name + "/locked"], CONVERGED_TOL, name)
 
 
+@pytest.mark.parametrize("name", SMALL)
+@pytest.mark.parametrize("scheme", ["jacobi", "redblack"])
+@pytest.mark.parametrize("finish,devices", [(1, None), (0, None), (1, "0,0")])
+def test_tol_complete_gpu_equals_the_checkers_loop_bit_for_bit(goldens, name, scheme, finish, devices, tol_env, monkeypatch):
+    """harmonic_complete_gpu with the tol math against oracle_tol_complete, which states the same driver loop (the reference's
+    exit rule, the Jacobi handover, the finishing iterations): field, iteration count and delta at tolerance 0 -- 2-D and 3-D,
+    both schemes, with the finishing rule on and off, on one device and on two slabs."""
+    from conftest import scheme_env
+
+    g, info = goldens["small"], goldens["manifest"]["small"][name]
+    m = [int(x) for x in g[name + "/m"]]
+    monkeypatch.setenv("EPIC_HIP_TOL_FINISH", str(finish))
+    if devices:
+        monkeypatch.setenv("EPIC_HIP_DEVICES", devices)
+    lib = O.oracle()
+    lib.oracle_tol_set_finish(finish)
+    try:
+        p = O.Problem(m, g[name + "/u0"], g[name + "/locked"], info["epsilon"], info["stagger"])
+        assert lib.oracle_tol_complete(ct.byref(p.h), 0 if scheme == "jacobi" else 1) == 0
+        with scheme_env(scheme):
+            h = make(m, g[name + "/u0"], g[name + "/locked"], info["epsilon"], info["stagger"])
+            assert E.harmonic_complete_gpu(h, NT) == 0
+        assert h.currentIteration == p.h.currentIteration and np.float32(h.delta) == np.float32(p.h.delta)
+        assert np.array_equal(h.u_array().ravel(), p.u)
+    finally:
+        lib.oracle_tol_set_finish(1)
+
+
 def _tol_map_run(goldens, name, record_property, iteration_slack=0.02):
     want = goldens["maps"][name + "/converged_1e-06"]
     run = goldens["manifest"]["maps"][name]["runs"]["1e-06"]
