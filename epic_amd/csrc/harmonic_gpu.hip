@@ -1966,7 +1966,14 @@ int harmonic_utilities_set_cells_2d_gpu(Harmonic *harmonic, unsigned int numThre
 // ---------------------------------------------------------------------------------------------------------
 extern "C" {
 
+// A library built with one of the kernels' timing-experiment switches (-DEPIC_EXP*: profiles/r0*_experiments.txt) computes WRONG
+// results by design; it says so in its version string, and the test-suite refuses to run against it.
+#if defined(EPIC_EXP_NOLDS) || defined(EPIC_EXP_LDS_UNIFORM) || defined(EPIC_EXP_NOMASK) || defined(EPIC_EXP3D_NOEDGESPLIT) || \
+    defined(EPIC_EXP3D_NONB) || defined(EPIC_EXP3D_NOSIDE) || defined(EPIC_EXP3D_NOSPLITNB) || defined(EPIC_EXP3D_TRAFFIC)
+const char *epic_hip_version(void) { return "epic-hip 0.1.0 gfx950 [TIMING-EXPERIMENT BUILD: results are wrong]"; }
+#else
 const char *epic_hip_version(void) { return "epic-hip 0.1.0 gfx950"; }
+#endif
 
 int epic_hip_device_count(void)
 {

@@ -50,6 +50,15 @@ def test_reference_abi_symbols_present():
         assert hasattr(lib, n), n
 
 
+def test_the_shipped_library_is_not_a_timing_experiment_build():
+    """The kernels carry timing-only switches (-DEPIC_EXP*: they remove work to price it and compute wrong results by
+    design; profiles/r0*_experiments.txt).  A library built with one says so in its version string."""
+    lib = ct.CDLL(eh.LIB_PATH)
+    lib.epic_hip_version.restype = ct.c_char_p
+    version = lib.epic_hip_version().decode()
+    assert version.startswith("epic-hip") and "EXPERIMENT" not in version, version
+
+
 def test_struct_layout():
     offs = {f[0]: getattr(eh.EpicHarmonic, f[0]).offset for f in eh.EpicHarmonic._fields_}
     assert ct.sizeof(eh.EpicHarmonic) == 80
