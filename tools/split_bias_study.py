@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Where the tol iteration's offset on plateaus comes from (profiles/r03_experiments.txt item 12).
+"""The local bias of the tol split -- a hypothesis about the tol iteration's offset on plateaus that was tested and refuted
+(profiles/r03_experiments.txt item 12; DESIGN.md section 7: removing the bias left umass.png where it was).
 
 The split e^u = q 2^n of the tol mode (cell_update.h: tol_split2; oracle/tol_checker.c) is unbiased over wide ranges of u
 (mean relative error ~1e-11) but NOT locally: this script bins the error by the fraction f = u log2(e) - n and attributes it
