@@ -130,6 +130,9 @@ struct Ctx {
     unsigned *d_m = nullptr;
     unsigned *d_delta = nullptr;   // float bits of max |du|
     float *h_delta = nullptr;      // pinned
+    // small grids (kernels_tile2d.hip): max |du| per tile of a check iteration, written by the kernel straight into pinned host
+    // memory -- no zeroing, no atomics on one word, no copy: the check costs the wait for the stream and nothing else
+    float *h_tile_delta = nullptr;
     hipStream_t stream = nullptr;
     int rows_per_task = 0;         // 0 = automatic
     // Task height of the fused passes, measured on this grid (tune_fused_rows): [0] two Jacobi iterations (tol), [1] two
@@ -193,6 +196,8 @@ struct Ctx {
     uint32_t *maskf() const { return n == 2 && maskw ? maskw + epic_hip::mask_words_2d(rows, pitch) : nullptr; }
     uint32_t *maskf(const Slab &sl) const { return sl.maskw ? sl.maskw + epic_hip::mask_words_2d(sl.rows, pitch) : nullptr; }
 };
+
+constexpr size_t kTileDeltaCap = 4096;   // tiles of a launch whose check may go through Ctx::h_tile_delta
 
 std::mutex g_mu;
 std::unordered_map<Harmonic *, Ctx *> g_ctx;
@@ -284,6 +289,10 @@ Ctx *get_ctx(Harmonic *h, bool create)
         delete c;
         return nullptr;
     }
+    if (hipHostMalloc((void **)&c->h_tile_delta, kTileDeltaCap * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();   // (the tile path then checks with the plain sweep)
+        c->h_tile_delta = nullptr;
+    }
     const char *e = getenv("EPIC_HIP_ROWS_PER_TASK");
     if (e) c->rows_per_task = atoi(e);
     e = getenv("EPIC_HIP_MATH");
@@ -329,6 +338,7 @@ void drop_ctx_if_empty(Harmonic *h)
     c->trk.release();
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->h_delta) (void)hipHostFree(c->h_delta);
+    if (c->h_tile_delta) (void)hipHostFree(c->h_tile_delta);
     delete c;
     g_ctx.erase(it);
 }
@@ -563,9 +573,55 @@ void tune_fused_rows(Ctx *c, int kind, unsigned iteration)
 
 hipError_t multi_run(Ctx *c, unsigned count, unsigned first, bool check_first);
 
-hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
+// Small 2-D grids (one device, no work lists): the plain iterations between two checks run several per launch on tiles that
+// stay in LDS (kernels_tile2d.hip) -- the ROS maps are launch-bound, 2.5-3 us per half-sweep whatever it computes.  halo == 0:
+// not for this context.  Knobs (read per batch; the tests switch them): EPIC_HIP_TILE=0 off; EPIC_HIP_TILE_HALO = ghost rings =
+// iterations per launch (default 8); EPIC_HIP_TILE_ROWS = owned rows per tile; EPIC_HIP_TILE_MAX_CELLS (default 0.5 Mcell).
+// Where it pays (tools/tile_probe.py, us per iteration, tiles / per-iteration kernels, bit-exact mode): 256^2 1.3 / 2.8, 482^2 1.4 / 3.5,
+// 310 x 940 1.5 / 3.2 -- one tile per CU; 1024^2 3.8 / 4.3 and 962^2 3.8 / 4.2 (four rounds of tiles: break-even); 954 x 1280 5.5 / 4.7,
+// 1442^2 7.1 / 6.7 (lost: every tile recomputes 2.3 cells per cell it owns).  Hence the limit.
+epic_hip::TilePlan tile_plan(const Ctx *c)
 {
-    if (c->multi()) return multi_run(c, count, first, false);
+    epic_hip::TilePlan none = {0, 0, 0, 0, 0};
+    if (c->n != 2 || c->multi() || c->track || c->math == 2) return none;
+    if (fuses_tol(c)) return none;   // (a fused pass asked for on a small grid: EPIC_HIP_FUSE_MIN_CELLS, the tests)
+    const char *e = getenv("EPIC_HIP_TILE");
+    if (e && e[0] == '0') return none;
+    e = getenv("EPIC_HIP_TILE_MAX_CELLS");
+    const long long max_cells = e ? atoll(e) : (1ll << 19);
+    if ((long long)c->rows * c->cols > max_cells) return none;
+    e = getenv("EPIC_HIP_TILE_HALO");
+    const int halo = e && atoi(e) > 0 ? atoi(e) : 8;
+    e = getenv("EPIC_HIP_TILE_ROWS");
+    return epic_hip::tile_2d_plan(c->rows, c->cols, halo, e ? atoi(e) : 0);
+}
+
+// Whether a check iteration may run as the LAST step of a tile launch (its max |du| per tile into Ctx::h_tile_delta).
+bool tile_checks(const Ctx *c, const epic_hip::TilePlan &tp)
+{
+    return tp.halo > 0 && c->h_tile_delta != nullptr && (size_t)tp.tiles_r * tp.tiles_c <= kTileDeltaCap;
+}
+
+// check_last (tile path only, tile_checks()): one more iteration after the `count` plain ones, a check, in the same launches.
+hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first, bool check_last = false)
+{
+    if (c->multi()) return check_last ? hipErrorInvalidValue : multi_run(c, count, first, false);
+    const epic_hip::TilePlan tp = tile_plan(c);
+    if (check_last && !tile_checks(c, tp)) return hipErrorInvalidValue;
+    if (tp.halo > 0 && (count >= 2 || check_last)) {   // (a single plain iteration is cheaper as the plain sweep: no ghost rings to load)
+        const unsigned total = count + (check_last ? 1u : 0u);
+        for (unsigned i = 0; i < total;) {
+            const unsigned k = std::min<unsigned>(total - i, (unsigned)tp.halo);
+            hipError_t e = epic_hip::launch_tile_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch, tp, (int)k, c->math,
+                                                    c->redblack ? (int)((first + i) & 1u) : -1, nullptr, c->stream,
+                                                    check_last && i + k == total ? c->h_tile_delta : nullptr);
+            if (e != hipSuccess) return e;
+            c->cur ^= 1;
+            c->work_full += (double)k;
+            i += k;
+        }
+        return hipSuccess;
+    }
     const bool no_fuse = getenv("EPIC_HIP_NO_FUSE") != nullptr;   // (read per call: the tests switch it)
     // (the fused passes have their own 248-column tiling and no work lists: they are used when tracking is off -- or
     //  bypassed for the batch, harmonic_execute_gpu; rb_fused2d_kernel for the precise / fast arithmetic, the RB instance of
@@ -619,19 +675,20 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first)
     return hipSuccess;
 }
 
-hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
+hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first, bool check_last = false)
 {
     const bool small = (long long)c->rows * c->pitch <= (1ll << 22);
     const bool no_graph = getenv("EPIC_HIP_NO_GRAPH") != nullptr;  // (read per batch: the tests switch it)
     // a captured sequence bakes in the work-list buffers and list mode: run eagerly until the forced iterations are over
     if (!small || count < 8 || no_graph || c->multi() || (c->track && (c->trk.force > 0 || c->trk.tiles == 0)))
-        return enqueue_plain_run(c, count, first);
+        return enqueue_plain_run(c, count, first, check_last);
     // (the fused-pass switches are read per batch -- EPIC_HIP_NO_FUSE, EPIC_HIP_FUSE_MIN_CELLS, EPIC_HIP_FUSED_ROWS --, so they
     // belong to the key: 0 = single sweeps, otherwise the task height of the pass)
-    const int fuse_cfg = fuses_tol(c) ? jacobi_fused_rows_per_task(c) : 0;
-    const auto key = std::make_tuple(count, c->cur + 2 * (c->track ? 1 + c->trk.phase : 0), (int)(first & 1u), c->math,
+    const epic_hip::TilePlan tp = tile_plan(c);
+    const int fuse_cfg = tp.halo > 0 ? -(tp.halo * 1024 + tp.tile_rows) : fuses_tol(c) ? jacobi_fused_rows_per_task(c) : 0;
+    const auto key = std::make_tuple(2u * count + (check_last ? 1u : 0u), c->cur + 2 * (c->track ? 1 + c->trk.phase : 0), (int)(first & 1u), c->math,
                                      (int)c->redblack, auto_rows_per_task(c), fuse_cfg);
-    if (c->graphs_broken) return enqueue_plain_run(c, count, first);
+    if (c->graphs_broken) return enqueue_plain_run(c, count, first, check_last);
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         // Capture is an optimisation: whatever goes wrong in it (begin, a launch during capture, end, instantiate), the
@@ -642,7 +699,7 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
         hipGraphExec_t exec = nullptr;
         hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
-            e = enqueue_plain_run(c, count, first);  // (fused passes included)
+            e = enqueue_plain_run(c, count, first, check_last);  // (fused passes included)
             hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
             if (e == hipSuccess) e = e2;
         }
@@ -657,7 +714,7 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
         if (e != hipSuccess) {
             (void)hipGetLastError();
             c->graphs_broken = true;
-            return enqueue_plain_run(c, count, first);
+            return enqueue_plain_run(c, count, first, check_last);
         }
         if (c->graphs.size() >= 16) drop_graphs(c);
         it = c->graphs.emplace(key, Ctx::Replay{exec, cur_flip, work}).first;
@@ -666,12 +723,27 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first)
     if (e != hipSuccess) {  // nothing was enqueued: run the batch eagerly instead, and stop replaying
         (void)hipGetLastError();
         c->graphs_broken = true;
-        return enqueue_plain_run(c, count, first);
+        return enqueue_plain_run(c, count, first, check_last);
     }
     c->cur ^= it->second.cur_flip;
     c->work_full += it->second.work;
     if (c->track) c->trk.phase = (int)((c->trk.phase + count) % 6);
     return hipSuccess;
+}
+
+// max |du| of a check iteration that ran as the last step of a tile launch (enqueue_plain_run, check_last): wait for the
+// stream, take the maximum over the tiles' words in pinned memory
+int read_tile_delta(Harmonic *h, Ctx *c, const char *fn)
+{
+    if (hipStreamSynchronize(c->stream) != hipSuccess) {
+        report(fn, "Failed to synchronize the device after the 'update and check' kernel.");
+        return EPIC_ERROR_DEVICE_SYNCHRONIZE;
+    }
+    const epic_hip::TilePlan tp = tile_plan(c);
+    float d = 0.0f;
+    for (int t = 0, n = tp.tiles_r * tp.tiles_c; t < n; ++t) d = std::max(d, c->h_tile_delta[t]);
+    h->delta = d;
+    return EPIC_SUCCESS;
 }
 
 int multi_read_delta(Harmonic *h, Ctx *c, const char *fn);
@@ -1832,6 +1904,23 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
     const float finish_below = 10.0f * harmonic->epsilon;
     const unsigned stagger = harmonic->numIterationsToStaggerCheck;
     result = EPIC_SUCCESS;
+    // what follows every check iteration (result and harmonic->delta are the check's)
+    auto after_check = [&] {
+        if (finish_wanted && !finish.on && harmonic->delta < finish_below) {
+            finish.on = true;
+            c->finish_from = harmonic->currentIteration;
+            c->math = 0;          // precise
+            c->redblack = true;   // the reference's half-sweeps, colour by currentIteration
+            force_all(c);
+            result = EPIC_SUCCESS;   // only a check of the finishing phase may end the loop
+        } else if (!c->redblack && result == EPIC_SUCCESS && harmonic->delta < 1.0f && handover.last_check >= 0.0f &&
+                   harmonic->delta >= handover.last_check) {
+            c->redblack = true;
+            force_all(c);
+            handover.done = true;
+        }
+        handover.last_check = harmonic->delta;
+    };
     while (result != EPIC_SUCCESS_AND_CONVERGED || harmonic->currentIteration < mMax) {
         if (harmonic->currentIteration % stagger == 0) {
             result = harmonic_update_and_check_gpu(harmonic, numThreads);
@@ -1839,20 +1928,23 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
                 report(fn, "Failed to perform the Jacobi update and check step.");
                 return result;
             }
-            if (finish_wanted && !finish.on && harmonic->delta < finish_below) {
-                finish.on = true;
-                c->finish_from = harmonic->currentIteration;
-                c->math = 0;          // precise
-                c->redblack = true;   // the reference's half-sweeps, colour by currentIteration
-                force_all(c);
-                result = EPIC_SUCCESS;   // only a check of the finishing phase may end the loop
-            } else if (!c->redblack && result == EPIC_SUCCESS && harmonic->delta < 1.0f && handover.last_check >= 0.0f &&
-                harmonic->delta >= handover.last_check) {
-                c->redblack = true;
-                force_all(c);
-                handover.done = true;
+            after_check();
+        } else if (tile_checks(c, tile_plan(c))) {
+            // Small grids (kernels_tile2d.hip): the plain iterations up to the next check AND that check are one sequence of tile
+            // launches (one captured graph); the check is the last step of the last launch and leaves its max |du| per tile in
+            // pinned memory.  Same iterations in the same order as the branches above and below run them.
+            const unsigned batch = stagger - harmonic->currentIteration % stagger;
+            if (enqueue_plain_batch(c, batch, harmonic->currentIteration, true) != hipSuccess) {
+                report(fn, "Failed to perform the Jacobi update step.");
+                return EPIC_ERROR_KERNEL_EXECUTION;
             }
-            handover.last_check = harmonic->delta;
+            harmonic->d_u = current_u(c);
+            harmonic->currentIteration += batch;
+            result = read_tile_delta(harmonic, c, fn);
+            if (result != EPIC_SUCCESS) return result;
+            harmonic->currentIteration++;
+            result = harmonic->delta < harmonic->epsilon ? EPIC_SUCCESS_AND_CONVERGED : EPIC_SUCCESS;
+            after_check();
         } else {
             // every plain iteration returns SUCCESS (which clears a previous CONVERGED), so the ones up to the next
             // check need no host decision in between: enqueue them as one batch
@@ -1994,15 +2086,16 @@ int epic_hip_update_n_gpu(Harmonic *harmonic, unsigned int sweeps, int check_las
         return EPIC_ERROR_INVALID_DATA;
     }
     const unsigned plain = sweeps - ((check_last && sweeps > 0) ? 1u : 0u);
-    if (enqueue_plain_batch(c, plain, harmonic->currentIteration) != hipSuccess ||
-        (plain < sweeps && enqueue_sweep(c, true, harmonic->currentIteration + plain) != hipSuccess)) {
+    const bool tiled_check = plain < sweeps && plain > 0 && tile_checks(c, tile_plan(c));   // the check rides the last tile launch
+    if (enqueue_plain_batch(c, plain, harmonic->currentIteration, tiled_check) != hipSuccess ||
+        (plain < sweeps && !tiled_check && enqueue_sweep(c, true, harmonic->currentIteration + plain) != hipSuccess)) {
         report(fn, "Failed to execute the 'Jacobi update' kernel.");
         return EPIC_ERROR_KERNEL_EXECUTION;
     }
     harmonic->currentIteration += plain;
     harmonic->d_u = current_u(c);
     if (check_last && sweeps > 0) {
-        int rc = read_delta(harmonic, c, fn);
+        int rc = tiled_check ? read_tile_delta(harmonic, c, fn) : read_delta(harmonic, c, fn);
         if (rc != EPIC_SUCCESS) return rc;
         harmonic->currentIteration++;
         return harmonic->delta < harmonic->epsilon ? EPIC_SUCCESS_AND_CONVERGED : EPIC_SUCCESS;
@@ -2095,6 +2188,12 @@ int epic_hip_iterations_per_pass(Harmonic *harmonic)
     const bool rb_fused = c->redblack && c->n == 2 && !no_fuse && !c->track && c->math != 4 &&
                           (long long)c->rows * c->pitch >= (1ll << 22);
     return rb_fused ? 2 : 1;
+}
+
+int epic_hip_tile_iterations(Harmonic *harmonic)
+{
+    Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
+    return c ? tile_plan(c).halo : 0;
 }
 
 unsigned int epic_hip_finish_iteration(Harmonic *harmonic)

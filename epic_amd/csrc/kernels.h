@@ -78,6 +78,18 @@ hipError_t launch_set_cells_2d(float *u, uint32_t *maskw, int rows, int cols, in
                                const unsigned *v, const unsigned *types, hipStream_t stream, int row0 = 0, int grid_rows = 0,
                                int pin_top = 0, int pin_bottom = 0);
 
+// ---- small grids: several iterations per launch on LDS tiles (kernels_tile2d.hip) ----------------
+// A tile owns tile_rows x tile_cols cells and carries `halo` ghost rings; a launch performs up to `halo` iterations.
+struct TilePlan { int halo, tile_rows, tile_cols, tiles_r, tiles_c; };   // halo == 0: no plan (grid or halo out of range)
+// tile_rows <= 0: as tall as gives every CU one tile (at most 64 - 2 halo)
+TilePlan tile_2d_plan(int rows, int cols, int halo, int tile_rows = 0);
+// `steps` (<= plan.halo) iterations in -> out (in != out, also for red-black: a neighbouring tile must find the old ghost
+// values).  parity < 0: Jacobi; else red-black, parity = number of the first iteration & 1.  delta_bits (may be null): max |du|
+// of the LAST of the iterations (zero it first); tile_delta (may be null): the same maximum per tile, tiles_r x tiles_c floats
+// written with plain stores -- nothing to zero, and the array may be pinned host memory.  math: precise, fast or tol.
+hipError_t launch_tile_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, const TilePlan &plan, int steps,
+                          int math, int parity, unsigned *delta_bits, hipStream_t stream, float *tile_delta = nullptr);
+
 // ---- streamlines on the resident field (path_2d.hip): one lane per start point ----------------
 // d_pts: n_paths x 2 * max_points floats; d_k: points per path (0 on failure); d_rc: EPIC_* code per path.
 hipError_t launch_follow_paths_2d(const float *u, const uint32_t *maskw, int rows, int cols, int pitch, unsigned n_paths,

@@ -1,0 +1,268 @@
+// kernels_tile2d.hip -- small 2-D grids: SEVERAL iterations per launch on tiles that live in LDS (gfx950).
+//
+// The maps the reference's callers actually relax (src/epic_nav_core_plugin.cpp:256 -> harmonic_gpu.cu:266-290: one
+// launch and one device synchronisation per half-sweep) are 0.1-1 Mcell: a half-sweep is ~0.2 us of arithmetic for the
+// whole chip and 2.5-3 us of launch latency, captured graph or not.  So the plain iterations between two convergence
+// checks run here K at a time: a workgroup loads its tile plus a ring of H >= K ghost cells into LDS, performs K
+// iterations on it without leaving the CU (one workgroup barrier per iteration), and writes the cells it owns into the
+// other buffer.  Ghost cells are swept like owned ones; the outermost ring has no neighbours to be computed from, so one
+// more ring goes stale per iteration from the outside in -- the scheme the slabs of the multi-device mode use between
+// GPUs (harmonic_gpu.hip), at CU scale: after K <= H iterations every owned cell holds exactly what K whole-grid
+// iterations would have given it.  The arithmetic of a cell is cell_update.h's, the same functions on the same values
+// as in kernels_2d.hip: bit-identical to the per-iteration kernels and, with the precise math and the red-black scheme,
+// to harmonic_complete_cpu (tests/test_gpu_tile.py: goldens, iteration counts, delta, whole fields).
+//
+// Geometry.  A tile is 64 columns wide in LDS (one lane per column: every LDS access of a wave hits 64 different banks)
+// and S_r = T_r + 2 H <= 64 rows tall; it owns the inner T_r x (64 - 2 H) cells.  Red-black: the cells of one colour in
+// a PAIR of rows are exactly one per column, so a wave takes a row pair per pass, each lane the row of the pair that has
+// its column's active cell.  Jacobi: a wave takes a row per pass, the tile ping-pongs between two LDS arrays.  Rows that
+// have gone stale are skipped (wave-uniform), stale columns idle.  Ping-pong in global memory (in != out): a neighbour
+// must still find the old values of the cells it loads as ghosts.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "cell_update.h"
+#include "kernels.h"
+
+namespace epic_hip {
+
+namespace {
+
+#ifndef EPIC_TILE_WAVES  // build knob (A/B): waves per workgroup
+#define EPIC_TILE_WAVES 16
+#endif
+constexpr int kTileCols = 64;          // LDS tile width = lanes of a wave
+constexpr int kTileMaxRows = 64;       // S_r <= 64
+constexpr int kTileWaves = EPIC_TILE_WAVES;
+constexpr int kTileThreads = 64 * kTileWaves;
+// A step is as long as its slowest wave, and a cell's update is one chain of ~80 dependent instructions with three LDS round
+// trips in it (~0.8 us for a wave alone on its SIMD, measured): the tile's row pairs are therefore spread over SIXTEEN
+// waves -- one or two passes each -- and the four waves of a SIMD cover each other's latencies (4 waves per workgroup: 18.3 us
+// per launch of 8 iterations on maps/maze.png, 16 waves: 10.8; tools/tile_probe.py, profiles/r04_experiments.txt).
+constexpr int kRbPasses = (kTileMaxRows / 2 + kTileWaves - 1) / kTileWaves;   // row pairs per wave
+constexpr int kJcPasses = (kTileMaxRows + kTileWaves - 1) / kTileWaves;       // rows per wave
+constexpr lmask kOddLanes = 0xaaaaaaaaaaaaaaaaull;
+
+struct Tile2dArgs {
+    const float *in;
+    float *out;
+    const uint32_t *maskw;   // lane masks (kernels.h), 1 = locked; border and padding are locked
+    unsigned *delta_bits;    // null, or: max |du| of the LAST iteration of the launch over the owned cells (atomicMax on float bits)
+    float *tile_delta;       // null, or: the same maximum per tile, one plain store each (no zeroing, no atomics; may be host memory)
+    int rows, pitch;
+    int halo, tile_rows;     // H, T_r; owned columns per tile = 64 - 2 H
+    int tiles_c;
+    int steps;               // iterations of this launch, <= halo
+    int parity;              // red-black: number of the first iteration & 1
+};
+
+template <int MATH, bool RB>
+__global__ __launch_bounds__(kTileThreads) void tile2d_kernel(Tile2dArgs a)
+{
+    constexpr bool TOL = MATH == kMathTol;
+    constexpr int kBufs = RB ? 1 : 2;
+    constexpr int kPasses = RB ? kRbPasses : kJcPasses;
+    constexpr int kSlots = RB ? 2 * kRbPasses : kJcPasses;   // rows a lane may update
+    constexpr int kPlane = (kTileMaxRows + 2) * kTileCols;   // one pad row above and below: the neighbours of a stale edge cell stay inside
+    __shared__ float u_lds[kBufs * kPlane];
+    __shared__ float q_lds[TOL ? kBufs * kPlane : 1];
+    __shared__ uint32_t n_lds[TOL ? kBufs * kPlane : 1];
+    __shared__ unsigned wg_delta;
+    __shared__ __attribute__((aligned(16))) char math_lds_bytes[TOL ? TolLn<4>::kLdsBytes : kMathLdsDoubles * (int)sizeof(double)];
+    const TolLnEntry *const tl = reinterpret_cast<const TolLnEntry *>(math_lds_bytes);
+    const MathTab tab = math_tables_at(reinterpret_cast<double *>(math_lds_bytes));
+    MathTabRegs tab_regs = {};
+    if (MATH == kMathPrecise) tab_regs = math_tables_fetch();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tr = blockIdx.x / a.tiles_c, tc = blockIdx.x % a.tiles_c;
+    const int H = a.halo, Sr = a.tile_rows + 2 * H, Tc = kTileCols - 2 * H;
+    const int R0 = tr * a.tile_rows - H, C0 = tc * Tc - H;   // global position of local cell (0, 0)
+    const int gc = C0 + lane;
+    const bool col_in = gc >= 0 && gc < a.pitch;
+    auto at = [](int lr, int lc) { return (lr + 1) * kTileCols + lc; };
+    // local row of slot k of this wave -- red-black: the two rows of row pair wave + W i are slots 2 i, 2 i + 1; Jacobi: row wave + W k
+    auto slot_row = [&](int k) { return RB ? 2 * (wave + kTileWaves * (k >> 1)) + (k & 1) : wave + kTileWaves * k; };
+
+    // ---- load: the tile with its ghost ring; cells outside the grid never change and are never read by a cell that does
+    // (the grid's border is locked).  The locks of the rows a wave will update stay with it as LANE MASKS in scalar registers.
+    lmask lockm[kSlots];
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k) {
+        const int lr = slot_row(k);
+        lockm[k] = ~0ull;
+        if (lr >= Sr) continue;   // wave-uniform
+        const int gr = R0 + lr;
+        const bool inside = col_in && gr >= 0 && gr < a.rows;
+        float v = -1e6f;
+        uint32_t lk = 1;
+        if (inside) {
+            v = a.in[(size_t)gr * a.pitch + gc];
+            lk = (a.maskw[mask_word_2d((unsigned)gr, (unsigned)gc, (unsigned)a.pitch)] >> mask_bit_2d((unsigned)gc)) & 1u;
+        }
+        lockm[k] = __builtin_amdgcn_ballot_w64(lk != 0);
+        u_lds[at(lr, lane)] = v;
+        if (TOL) {
+            const Split1 sp = tol_split1(v);
+            q_lds[at(lr, lane)] = sp.q;
+            n_lds[at(lr, lane)] = f2u(sp.zm);
+        }
+    }
+    if (threadIdx.x < 2 * kTileCols) {   // the pad rows: read by the (discarded) updates of the outermost ring only
+        const int lr = threadIdx.x < kTileCols ? -1 : Sr;
+#pragma unroll
+        for (int b = 0; b < kBufs; ++b) {
+            u_lds[b * kPlane + at(lr, lane)] = -1e6f;
+            if (TOL) { q_lds[b * kPlane + at(lr, lane)] = 1.0f; n_lds[b * kPlane + at(lr, lane)] = kTolMagicBits; }
+        }
+    }
+    if (threadIdx.x == 0) wg_delta = 0;
+    if (MATH == kMathPrecise) math_tables_commit(tab_regs, reinterpret_cast<double *>(math_lds_bytes));
+    if (TOL) TolLn<4>::stage(reinterpret_cast<TolLnEntry *>(math_lds_bytes));   // ends with a workgroup barrier
+    else __syncthreads();
+
+    // ---- K iterations on the tile
+    const int own_r0 = H, own_r1 = H + a.tile_rows;   // owned local rows [own_r0, own_r1), columns [H, 64 - H)
+    const lmask own_cols = (~0ull << H) & (~0ull >> H);
+    const int odd_lane = lane & 1;
+    const bool want_delta = a.delta_bits != nullptr || a.tile_delta != nullptr;
+    float dmax = 0.0f;
+    for (int j = 0; j < a.steps; ++j) {
+        // cells that still have four valid neighbours: local rows [lo, hi_r], columns [lo, 63 - lo]
+        const int lo = j + 1, hi_r = Sr - 2 - j;
+        const lmask cols_ok = (~0ull << lo) & (~0ull >> lo);
+        const bool check = want_delta && j == a.steps - 1;
+        const int src = RB ? 0 : (j & 1) * kPlane, dst = RB ? 0 : ((j & 1) ^ 1) * kPlane;
+        // red-black: the active cell of column gc in global row gr has (gr + gc + iteration) odd (harmonic_cpu.cpp:46-51); in a row
+        // pair that starts at an even local row the lanes with (lane + b) odd take the first row, the others the second
+        const int b = (R0 + C0 + a.parity + j) & 1;
+        const lmask first_row = b ? ~kOddLanes : kOddLanes;
+#pragma unroll
+        for (int i = 0; i < kPasses; ++i) {
+            lmask upd, own;
+            int p;
+            if (RB) {
+                const int r2 = 2 * (wave + kTileWaves * i);
+                const bool v0 = r2 >= lo && r2 <= hi_r, v1 = r2 + 1 >= lo && r2 + 1 <= hi_r;
+                if (!(v0 || v1)) continue;   // wave-uniform: the pair has gone stale (or lies beyond the tile)
+                const lmask lock = (lockm[2 * i] & first_row) | (lockm[2 * i + 1] & ~first_row);
+                upd = ((v0 ? first_row : 0ull) | (v1 ? ~first_row : 0ull)) & cols_ok & ~lock;
+                own = ((r2 >= own_r0 && r2 < own_r1 ? first_row : 0ull) | (r2 + 1 >= own_r0 && r2 + 1 < own_r1 ? ~first_row : 0ull)) & own_cols;
+                p = at(r2, lane) + ((odd_lane ^ b) ? 0 : kTileCols);
+            } else {
+                const int lr = wave + kTileWaves * i;
+                if (lr < lo || lr > hi_r) continue;   // wave-uniform
+                upd = cols_ok & ~lockm[i];
+                own = lr >= own_r0 && lr < own_r1 ? own_cols : 0ull;
+                p = at(lr, lane);
+            }
+            const float c = u_lds[src + p];
+            const float uu = u_lds[src + p - kTileCols], ud = u_lds[src + p + kTileCols], ul = u_lds[src + p - 1], ur = u_lds[src + p + 1];
+            float nv;
+            if (TOL) {
+                nv = tol_update_2d(uu, ud, ul, ur, q_lds[src + p - kTileCols], n_lds[src + p - kTileCols], q_lds[src + p + kTileCols],
+                                   n_lds[src + p + kTileCols], q_lds[src + p - 1], n_lds[src + p - 1], q_lds[src + p + 1],
+                                   n_lds[src + p + 1], tl);
+            } else {
+                nv = cell_update_2d<MATH>(uu, ud, ul, ur, tab);
+            }
+            const float o = sel(upd, nv, c);
+            u_lds[dst + p] = o;
+            if (TOL) {
+                const Split1 sp = tol_split1(o);
+                q_lds[dst + p] = sp.q;
+                n_lds[dst + p] = f2u(sp.zm);
+            }
+            if (check) dmax = max2(dmax, sel(own, fabsf(c - o), 0.0f));   // (wave-uniform branch)
+        }
+        __syncthreads();
+    }
+
+    // ---- store the owned cells (locked ones included: `out` is the other buffer)
+    const int fin = RB ? 0 : (a.steps & 1) * kPlane;
+    const bool own_col = lane >= H && lane < kTileCols - H;
+    for (int lr = own_r0 + wave; lr < own_r1; lr += kTileWaves) {
+        const int gr = R0 + lr;
+        if (gr >= a.rows) break;   // wave-uniform
+        if (own_col && gc < a.pitch) a.out[(size_t)gr * a.pitch + gc] = u_lds[fin + at(lr, lane)];
+    }
+    if (want_delta) {
+        dmax = wave_max(dmax);
+        if (a.delta_bits != nullptr && lane == 0 && dmax > 0.0f) atomicMax(a.delta_bits, __float_as_uint(dmax));
+        if (a.tile_delta != nullptr) {
+            if (lane == 0 && dmax > 0.0f) atomicMax(&wg_delta, __float_as_uint(dmax));
+            __syncthreads();
+            if (threadIdx.x == 0) a.tile_delta[blockIdx.x] = __uint_as_float(wg_delta);
+        }
+    }
+}
+
+}  // namespace
+
+// How a grid is cut into tiles for `halo` ghost rings: owned columns 64 - 2 halo; owned rows as tall as the LDS tile
+// allows, but not taller than what gives every CU of the chip a tile (the tiles of a launch run side by side: its time
+// is the time of ONE tile, so smaller tiles are faster until the chip is full).
+TilePlan tile_2d_plan(int rows, int cols, int halo, int tile_rows)
+{
+    TilePlan p = {0, 0, 0, 0, 0};
+    if (halo < 1 || 2 * halo >= kTileCols - 8 || rows < 3 || cols < 3) return p;
+    const int tc = kTileCols - 2 * halo;
+    const int tiles_c = (cols + tc - 1) / tc;
+    const int max_tr = kTileMaxRows - 2 * halo;
+    int tr = tile_rows;
+    if (tr <= 0) {
+        int cus = 256, dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+            (void)hipGetLastError();
+            cus = 256;
+        }
+        const int tiles_r_max = std::max(1, cus / tiles_c);   // rows of tiles the chip takes in one round
+        tr = (rows + tiles_r_max - 1) / tiles_r_max;
+        tr = std::max((tr + 1) / 2 * 2, 8);                   // (even: the LDS tile is walked in row pairs)
+    }
+    tr = std::min(tr, max_tr) / 2 * 2;
+    if (tr < 2) return p;
+    p.halo = halo;
+    p.tile_rows = tr;
+    p.tile_cols = tc;
+    p.tiles_r = (rows + tr - 1) / tr;
+    p.tiles_c = tiles_c;
+    return p;
+}
+
+hipError_t launch_tile_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, const TilePlan &plan, int steps,
+                          int math, int parity, unsigned *delta_bits, hipStream_t stream, float *tile_delta)
+{
+    if (steps <= 0) return hipSuccess;
+    if (!in || !out || in == out || !maskw || pitch <= 0 || (pitch % 256) != 0 || rows <= 0) return hipErrorInvalidValue;
+    if (plan.halo < 1 || steps > plan.halo || plan.tile_rows < 2 || plan.tile_rows + 2 * plan.halo > kTileMaxRows ||
+        plan.tile_cols != kTileCols - 2 * plan.halo || plan.tiles_r < 1 || plan.tiles_c < 1 ||
+        (long long)plan.tiles_r * plan.tile_rows < rows)
+        return hipErrorInvalidValue;
+    if (math != kMathPrecise && math != kMathFast && math != kMathTol) return hipErrorInvalidValue;
+    Tile2dArgs a;
+    a.in = in;
+    a.out = out;
+    a.maskw = maskw;
+    a.delta_bits = delta_bits;
+    a.tile_delta = tile_delta;
+    a.rows = rows;
+    a.pitch = pitch;
+    a.halo = plan.halo;
+    a.tile_rows = plan.tile_rows;
+    a.tiles_c = plan.tiles_c;
+    a.steps = steps;
+    a.parity = parity < 0 ? 0 : (parity & 1);
+    const bool rb = parity >= 0;
+    void (*kernel)(Tile2dArgs) = math == kMathTol    ? (rb ? tile2d_kernel<kMathTol, true> : tile2d_kernel<kMathTol, false>)
+                                 : math == kMathFast ? (rb ? tile2d_kernel<kMathFast, true> : tile2d_kernel<kMathFast, false>)
+                                                     : (rb ? tile2d_kernel<kMathPrecise, true> : tile2d_kernel<kMathPrecise, false>);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(plan.tiles_r * plan.tiles_c)), dim3(kTileThreads), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace epic_hip

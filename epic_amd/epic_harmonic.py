@@ -124,6 +124,7 @@ _SIGNATURES = {
     "epic_hip_timed_sweeps_gpu": (_H, ct.c_uint, ct.c_uint, ct.POINTER(ct.c_float)),
     "epic_hip_set_rows_per_task": (_H, ct.c_uint),
     "epic_hip_iterations_per_pass": (_H,),
+    "epic_hip_tile_iterations": (_H,),
     "epic_hip_fused_rows_per_task": (_H,),
     "epic_hip_finish_iteration": (_H,),
     "epic_hip_set_math_mode": (_H, ct.c_int),

@@ -1,0 +1,163 @@
+"""Small 2-D grids: several iterations per launch on LDS tiles (epic_amd/csrc/kernels_tile2d.hip).
+
+The path replaces, for grids of at most 1 Mcell, the launch-per-iteration loop of the reference
+(/root/reference/libepic/src/harmonic/harmonic_gpu.cu:266-290) between two convergence checks.  Its arithmetic is the
+per-iteration kernels', so everything here is held at tolerance 0: against the per-iteration kernels (EPIC_HIP_TILE=0),
+against the checker (oracle/), and against the vectors the reference itself produced (tests/golden/).
+"""
+import ctypes as ct
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from conftest import scheme_env
+from epic_amd import epic_harmonic as eh
+from epic_amd.harmonic import Harmonic
+from epic_amd.synthetic import synthetic_grid
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+
+E = eh._epic
+NT = 1024
+
+
+class env:
+    def __init__(self, **kv):
+        self.kv = {k: v for k, v in kv.items()}
+
+    def __enter__(self):
+        self.prev = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        return False
+
+
+def run_gpu(m, u0, locked, k, math, scheme, check_last=True, expect_tile=None):
+    """k iterations as ONE batch (epic_hip_update_n_gpu: k - 1 plain ones and a check), field and delta."""
+    h = Harmonic()
+    h.set_grid(m, u0, locked)
+    h.epsilon = 1e-6
+    for fn in (E.harmonic_initialize_dimension_size_gpu, E.harmonic_initialize_potential_values_gpu,
+               E.harmonic_initialize_locked_gpu):
+        assert fn(h) == 0
+    assert E.harmonic_initialize_gpu(h, NT) == 0
+    assert E.epic_hip_set_math_mode(h, math) == 0 and E.epic_hip_set_scheme(h, scheme) == 0
+    if expect_tile is not None:
+        assert (E.epic_hip_tile_iterations(h) > 0) == expect_tile, E.epic_hip_tile_iterations(h)
+    assert E.epic_hip_update_n_gpu(h, k, 1 if check_last else 0) in (0, 1)
+    assert h.currentIteration == k
+    assert E.harmonic_get_potential_values_gpu(h) == 0
+    delta = float(h.delta)
+    for fn in (E.harmonic_uninitialize_gpu, E.harmonic_uninitialize_dimension_size_gpu,
+               E.harmonic_uninitialize_potential_values_gpu, E.harmonic_uninitialize_locked_gpu):
+        assert fn(h) == 0
+    return h.u_array().ravel().copy(), delta
+
+
+def seeded(m, seed, dens):
+    u0, locked = synthetic_grid(m, seed, dens)
+    free = np.flatnonzero(locked == 0)
+    if free.size > 4:   # goals off-centre too, so that every tile and seam sees a moving front early
+        for idx in (free[0], free[free.size // 3], free[-1]):
+            u0[idx] = 0.0
+            locked[idx] = 1
+    if free.size > 16:  # and a non-uniform start: a store that lands in the wrong cell must not write -1e6 over -1e6
+        O.scramble_free(m, u0, locked, seed=seed + 100, lo=-40.0, hi=0.0)
+    return u0, locked
+
+
+GRIDS = [([16, 16], 1, 0.05), ([3, 3], 6, 0.0), ([3, 70], 6, 0.0), ([70, 3], 6, 0.0), ([23, 37], 4, 0.10), ([70, 66], 8, 0.30),
+         ([48, 48], 2, 0.05), ([49, 97], 3, 0.05), ([130, 256], 11, 0.05), ([257, 513], 9, 0.05), ([310, 940], 5, 0.20),
+         ([482, 482], 7, 0.10), ([64, 1030], 10, 0.05)]
+MODES = [(eh.MATH_PRECISE, eh.SCHEME_REDBLACK), (eh.MATH_PRECISE, eh.SCHEME_JACOBI), (eh.MATH_TOL, eh.SCHEME_REDBLACK),
+         (eh.MATH_TOL, eh.SCHEME_JACOBI)]
+
+
+@pytest.mark.parametrize("math,scheme", MODES)
+@pytest.mark.parametrize("m,seed,dens", GRIDS)
+def test_tiles_equal_the_per_iteration_kernels_bit_for_bit(m, seed, dens, math, scheme):
+    u0, locked = seeded(m, seed, dens)
+    for k in (3, 9, 10, 26):
+        with env(EPIC_HIP_TILE="0"):
+            want, wdelta = run_gpu(m, u0, locked, k, math, scheme, expect_tile=False)
+        got, gdelta = run_gpu(m, u0, locked, k, math, scheme, expect_tile=True)
+        assert np.array_equal(got, want), (m, k, int(np.flatnonzero(got != want)[0]), int((got != want).sum()))
+        assert gdelta == wdelta
+
+
+@pytest.mark.parametrize("halo,tile_rows", [(1, 0), (2, 6), (3, 0), (5, 20), (8, 8), (8, 48), (12, 0), (16, 32), (27, 10)])
+@pytest.mark.parametrize("math,scheme", MODES)
+def test_any_halo_and_tile_height_gives_the_same_bits(halo, tile_rows, math, scheme):
+    m = [150, 203]
+    u0, locked = seeded(m, 21, 0.08)
+    with env(EPIC_HIP_TILE="0"):
+        want, wdelta = run_gpu(m, u0, locked, 31, math, scheme)
+    for graph in (None, "1"):
+        with env(EPIC_HIP_TILE_HALO=halo, EPIC_HIP_TILE_ROWS=tile_rows or None, EPIC_HIP_NO_GRAPH=graph):
+            got, gdelta = run_gpu(m, u0, locked, 31, math, scheme, expect_tile=True)
+        assert np.array_equal(got, want), (halo, tile_rows, int((got != want).sum()))
+        assert gdelta == wdelta
+
+
+@pytest.mark.parametrize("m,seed,dens", [([23, 37], 4, 0.10), ([130, 256], 11, 0.05), ([257, 513], 9, 0.05)])
+def test_tiles_against_the_checker(m, seed, dens):
+    """The default mode against the checker's statement of the reference's half-sweeps (oracle_update*), Jacobi against
+    oracle_jacobi_run, the tol arithmetic against oracle/tol_checker.c: tolerance 0."""
+    u0, locked = seeded(m, seed, dens)
+    k = 19
+    p = O.Problem(m, u0, locked)
+    for i in range(k):
+        (O.oracle().oracle_update_and_check if i == k - 1 else O.oracle().oracle_update)(ct.byref(p.h))
+    got, gdelta = run_gpu(m, u0, locked, k, eh.MATH_PRECISE, eh.SCHEME_REDBLACK, expect_tile=True)
+    assert np.array_equal(got, p.u) and gdelta == float(p.h.delta)
+    p = O.Problem(m, u0, locked)
+    assert O.oracle().oracle_jacobi_run(ct.byref(p.h), k) == 0
+    got, gdelta = run_gpu(m, u0, locked, k, eh.MATH_PRECISE, eh.SCHEME_JACOBI, expect_tile=True)
+    assert np.array_equal(got, p.u) and gdelta == float(p.h.delta)
+    for rb in (0, 1):
+        p = O.Problem(m, u0, locked)
+        assert O.oracle().oracle_tol_run(ct.byref(p.h), k, rb) == 0
+        got, gdelta = run_gpu(m, u0, locked, k, eh.MATH_TOL, eh.SCHEME_REDBLACK if rb else eh.SCHEME_JACOBI, expect_tile=True)
+        assert np.array_equal(got, p.u) and gdelta == float(p.h.delta)
+
+
+def test_reference_half_sweeps_through_tiles(goldens):
+    """rb10 of every 2-D golden grid: ten of the reference's own half-sweeps (harmonic_update_cpu x 9 + _and_check_cpu)."""
+    small = goldens["small"]
+    names = sorted({k.split("/")[0] for k in small.files if k.startswith("g2d_")})
+    assert names
+    for name in names:
+        m = [int(x) for x in small[name + "/m"]]
+        u0, locked = small[name + "/u0"], small[name + "/locked"].astype(np.uint32)
+        got, gdelta = run_gpu(m, u0, locked, 10, eh.MATH_PRECISE, eh.SCHEME_REDBLACK, expect_tile=True)
+        assert np.array_equal(got, small[name + "/rb10"].ravel()), name
+        assert gdelta == float(small[name + "/rb10_delta"]), name
+
+
+@pytest.mark.parametrize("name", ["basic", "maze", "umass"])
+def test_maps_relax_through_tiles_to_the_reference_field(name, goldens):
+    """harmonic_complete_gpu with an empty environment (what the unchanged plugin gets, src/epic_nav_core_plugin.cpp:256):
+    the plain iterations run eight per launch on tiles, and field, iteration count and delta are harmonic_complete_cpu's."""
+    from epic_amd.harmonic_map import HarmonicMap
+
+    hm = HarmonicMap()
+    hm.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "maps", name + ".png"))
+    hm.epsilon = 1e-6
+    hm.numIterationsToStaggerCheck = 100
+    with scheme_env(None), env(EPIC_HIP_MATH=None, EPIC_HIP_TRACK=None, EPIC_HIP_TILE=None):
+        assert E.harmonic_complete_gpu(hm, NT) == 0
+    run = goldens["manifest"]["maps"][name]["runs"]["1e-06"]
+    assert hm.currentIteration == run["iterations"] and float(hm.delta) == run["delta"]
+    assert np.array_equal(hm.u_array().ravel(), goldens["maps"][name + "/converged_1e-06"].ravel())
