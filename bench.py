@@ -180,11 +180,16 @@ def parity_object(args, E, MODES, relaxed, locked_8192):
     def complete(h, math, scheme):
         h.epsilon = 1e-6
         h.numIterationsToStaggerCheck = 100
+        prev = {k: os.environ.get(k) for k in ("EPIC_HIP_MATH", "EPIC_HIP_SCHEME")}   # (a user may have exported them for the run)
         os.environ["EPIC_HIP_MATH"], os.environ["EPIC_HIP_SCHEME"] = math, scheme
         try:
             rc = E.harmonic_complete_gpu(h, 1024)
         finally:
-            del os.environ["EPIC_HIP_MATH"], os.environ["EPIC_HIP_SCHEME"]
+            for k, v in prev.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         if rc != 0:
             raise RuntimeError("harmonic_complete_gpu returned %d" % rc)
         return h.u_array().ravel().copy(), int(h.currentIteration)
@@ -336,30 +341,19 @@ def main():
     if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and not args.no_live_traffic and not args.in_library_child
             and not args.slab):
         live, live_note = live_traffic(args)   # child processes, before anything here initialises the GPU
-    import torch  # first: one HIP runtime per process (epic_amd/epic_harmonic.py)
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
-        args.gpus = world
-    ndev = torch.cuda.device_count()
     backend = os.environ.get("EPIC_BENCH_BACKEND", "nccl")   # "gloo": ranks may share a GPU (1-GPU smoke of the N > 1 path)
-    if ndev < 1:
-        sys.exit("bench.py: no GPU visible")
-    if backend == "nccl" and local >= ndev:
-        sys.exit("bench.py: rank %d has no GPU of its own (%d visible)" % (local, ndev))
-    local = local % ndev
     # N > 1: the same grid through the C-ABI in ONE process on all GPUs (EPIC_HIP_DEVICES; halos by the copy engines) -- FIRST,
-    # as a child of rank 0 while rank 0 has not touched a GPU yet (a process that has initialised the GPU must not start
-    # another program) and while the other ranks wait in the rendezvous below with their GPUs idle.  A child, so that a fault
-    # in a path no hardware has run yet cannot take the headline line with it.
+    # as a child of rank 0 BEFORE this process makes any torch.cuda call (device_count() included: without amdsmi it is
+    # hipGetDeviceCount, which initialises the runtime, and a process that has initialised the GPU must not start another
+    # program) and while the other ranks wait in the rendezvous below with their GPUs idle.  Eligibility comes from the
+    # environment alone; a child that finds too few devices says so in its line.  A child, so that a fault in a path no
+    # hardware has run yet cannot take the headline line with it.
     in_library = None
     if (world > 1 and rank == 0 and not args.no_extra_legs and not args.in_library_child
-            and ((backend == "nccl" and ndev >= world) or os.environ.get("EPIC_BENCH_DEVLIST"))):
+            and (backend == "nccl" or os.environ.get("EPIC_BENCH_DEVLIST"))):
         import subprocess
 
         env = {k: v for k, v in os.environ.items()
@@ -372,8 +366,23 @@ def main():
                                 env=env, capture_output=True, text=True, timeout=240)
             lines = [l for l in r2.stdout.splitlines() if l.startswith("{")]
             in_library = json.loads(lines[-1]) if lines else {"error": "rc %d: %s" % (r2.returncode, r2.stderr[-400:])}
+            if in_library is not None and r2.stderr:
+                in_library["stderr_tail"] = r2.stderr[-600:]   # the library reports refused peer access here
         except BaseException as exc:   # evidence leg only: never lose the headline line
             in_library = {"error": repr(exc)}
+    import torch  # first: one HIP runtime per process (epic_amd/epic_harmonic.py)
+
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        sys.exit("bench.py: no GPU visible")
+    if backend == "nccl" and local >= ndev:
+        sys.exit("bench.py: rank %d has no GPU of its own (%d visible)" % (local, ndev))
+    local = local % ndev
     torch.cuda.set_device(local)
     red_dev = "cuda" if backend == "nccl" else "cpu"          # where the few scalar reductions of this script live
     if world > 1:

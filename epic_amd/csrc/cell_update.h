@@ -453,9 +453,6 @@ __device__ __forceinline__ uint32_t tol_ln_addr(float s, const TolLnEntry *lds)
 {
     const uint32_t b = f2u(s);
     const uint32_t off = BINADES == 4 ? ((b >> 11) & 0x3ff0u) : (((b - 0x3f000000u) >> 11) & 0x7ff0u);
-#ifdef EPIC_EXP_LDS_UNIFORM  // timing experiment only (wrong results): every lane reads the same entry -- no bank conflicts
-    return (uint32_t)(uintptr_t)lds + (off & 0x10u);
-#endif
     return (uint32_t)(uintptr_t)lds + off;
 }
 // The reads of a pair are ISSUED here and WAITED FOR later (tol_ln_wait).  Written out in assembly: the compiler waits after
@@ -470,11 +467,7 @@ __device__ __forceinline__ TolLnPair tol_ln_issue(const TolPre2 &p, const TolLnE
 {
     TolLnPair r;
     const uint32_t a0 = tol_ln_addr<BINADES>(p.s.x, lds), a1 = tol_ln_addr<BINADES>(p.s.y, lds);
-#ifdef EPIC_EXP_NOLDS  // timing experiment only (wrong results): no table lookups
-    r.a = r.b = vu3_t{a0 + a1, 0x3ff00000u, 0x3f800000u};
-#else
     asm volatile("ds_read_b96 %0, %2\n\tds_read_b96 %1, %3" : "=&v"(r.a), "=&v"(r.b) : "v"(a0), "v"(a1));
-#endif
     __builtin_amdgcn_sched_barrier(0);
     return r;
 }
@@ -483,9 +476,7 @@ template <int N>
 __device__ __forceinline__ void tol_ln_wait(TolLnPair &r, TolLnRaw &e0, TolLnRaw &e1)
 {
     __builtin_amdgcn_sched_barrier(0);
-#ifndef EPIC_EXP_NOLDS
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(r.a), "+v"(r.b) : "n"(N));
-#endif
     e0 = TolLnRaw{r.a.x, r.a.y, r.a.z};
     e1 = TolLnRaw{r.b.x, r.b.y, r.b.z};
 }

@@ -642,9 +642,6 @@ __device__ __forceinline__ void tol_fused_pass(const Sweep2dArgs &a, TolLnEntry 
     // (FMASK: the library keeps a second copy of the masks already cut for this mapping -- kernels.h, fused layout --, one
     // s_load_dwordx8 per row and no shifts; the funnel remains for callers that hold the standard layout only)
     auto mask_fetch = [&](int r) -> RowMaskRaw {
-#ifdef EPIC_EXP_NOMASK  // timing experiment only (wrong results): no mask loads at all
-        return RowMaskRaw{0, 0, 0, 0, 0, 0, 0, 0};
-#endif
         r = min(max(r, 0), rlast);
         if (FMASK) {
             cu64 *mk = (cu64 *)a.maskf + ((size_t)r * a.nstrips + strip) * 4;

@@ -133,11 +133,7 @@ __device__ __forceinline__ float4 tol_row_3d(const float4 &pa, const float4 &pb,
                                              float hl, float hr, lmask m0, lmask m1, lmask m2, lmask m3, bool even_cols,
                                              const TolLnEntry *tl)
 {
-#ifdef EPIC_EXP3D_NOEDGESPLIT  // timing experiment only (wrong results)
-    const Split2 hs = Split2{v2f{sc.qx, sc.qw}, v2f{u2f(sc.nx), u2f(sc.nw)}};
-#else
     const Split2 hs = tol_split2(v2f{hl, hr});  // the two strip-edge cells of the row
-#endif
     return tol_row_3d<RB>(pa, pb, up, c, dn, sa, sb, su, sc, sd, hl, hr, hs, m0, m1, m2, m3, even_cols, tl);
 }
 
@@ -228,9 +224,6 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB
     typedef unsigned vu4 __attribute__((ext_vector_type(4)));
     auto row_off = [&](int r) -> unsigned { return (unsigned)((r - rlo) * a.pitch + col0) * 4u; };  // r already clamped
     auto ld = [&](unsigned plane_off, int r) -> float4 {
-#ifdef EPIC_EXP3D_NONB  // timing experiment only (wrong results): the neighbouring planes' rows are the plane's own (a third of the loads)
-        plane_off = rc;
-#endif
         r = min(max(r, 0), rlast);
         const vu4 q = __builtin_amdgcn_raw_buffer_load_b128(rin, lane16, plane_off + row_off(r), 0);
         return make_float4(u2f(q.x), u2f(q.y), u2f(q.z), u2f(q.w));
@@ -243,12 +236,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB
         r = min(max(r, 0), rlast);
         cfloat *row = (cfloat *)(pc + (size_t)r * pitch);
         cu64 *mk = (cu64 *)a.maskw + (((size_t)x0 * a.m1 + r) * a.nstrips + strip) * 4;
-#ifdef EPIC_EXP3D_NOSIDE  // timing experiment only (wrong results): no scalar loads per row
-        (void)row; (void)mk;
-        return RowSide{-3.0f, -4.0f, 0, 0, 0, 0};
-#else
         return RowSide{row[hcol_l], row[hcol_r], mk[0], mk[1], mk[2], mk[3]};
-#endif
     };
 
     lmask chg_any = 0, chg_x = 0, chg_w = 0, chg_top = 0, chg_bot = 0;  // lane masks, as in the 2-D kernel
@@ -262,11 +250,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB
         const float lf = TOL ? 0.0f : wave_from_left(c.w, h.l);
         const float rt = TOL ? 0.0f : wave_from_right(c.x, h.r);
         if (TOL) {
-#ifdef EPIC_EXP3D_NOSPLITNB  // timing experiment only (wrong results): the neighbouring planes' rows are not split
-            const Split4 sa = su, sb = sd;
-#else
             const Split4 sa = tol_split4(pa), sb = tol_split4(pb);
-#endif
             const bool even_cols = !RB || ((x0 + r + a.parity) & 1) == 0;  // scalar
             o = tol_row_3d<RB>(pa, pb, up, c, dn, sa, sb, su, sc, sd, h.l, h.r, h.m0, h.m1, h.m2, h.m3, even_cols, tl);
         } else if (RB) {
@@ -380,7 +364,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB
 // window two are already in registers with their splits.  Per updated row: 2 rows loaded and split instead of 3 (51.6 VALU
 // instructions per cell against 56.8).  177-189 registers, two waves per SIMD (three -- 168 registers and a few spills -- time
 // the same); the four waves of a workgroup hold eight consecutive planes.  512^3, same box: 295 -> 270-273 us per sweep.
-// The loads and stores of this march alone (-DEPIC_EXP3D_TRAFFIC) take 217-225 us whatever the occupancy and the
+// The loads and stores of this march alone (a traffic-only build of round 3) take 217-225 us whatever the occupancy and the
 // prefetch depth: the floor of the pattern.  Build knobs below: measured alternatives (profiles/r03_experiments.txt item 8).
 // Same arithmetic on the same inputs as sweep3d_kernel: bit-identical results (tests/test_gpu_full_configs.py and the
 // whole 3-D parity suite run through it; EPIC_HIP_3D_PAIR=0 selects the one-plane kernel).
@@ -474,12 +458,7 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pa
             t = min(max(t, 0), t_max);
             const int x0 = X0M ? t : c, x1 = X0M ? c : t;
             cu64 *mk = (cu64 *)a.maskw + (((size_t)x0 * a.m1 + x1) * a.nstrips + strip) * 4;
-#ifdef EPIC_EXP3D_NOSIDE  // timing experiment only (wrong results): no scalar loads per row
-            (void)mk;
-            return RowSide{0, 0, 0, 0};
-#else
             return RowSide{mk[0], mk[1], mk[2], mk[3]};
-#endif
         };
         // planes [check_lo, check_hi) count for max |du|: a property of the pair (x1-march) or of the step (x0-march)
         const bool chkA = CHECK && has_a && (X0M || (cA >= a.check_lo && cA < a.check_hi)),
@@ -516,21 +495,12 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pa
             eA[kn] = eld(ocA, t + 2); eB[kn] = eld(ocB, t + 2);
             hA[kp & 1] = side(cA, t + 1); hB[kp & 1] = side(cB, t + 1);
             sA[kp] = tol_split4(qA[kp]); sB[kp] = tol_split4(qB[kp]);
-#ifdef EPIC_EXP3D_NOSPLITNB  // timing experiment only (wrong results): the outer rows are not split
-            const Split4 so_a = sA[km], so_b = sB[kp];
-#else
             const Split4 so_a = tol_split4(pa[k]), so_b = tol_split4(pb[k]);
-#endif
             // the strip-edge cells of both owned rows in ONE packed split (.x: plane A's -- lane 0 left, lane 63 right --, .y: plane B's)
             const Split2 es = tol_split2(v2f{eA[k], eB[k]});
             const Split2 esA = Split2{v2f{es.q.x, es.q.x}, v2f{es.zm.x, es.zm.x}}, esB = Split2{v2f{es.q.y, es.q.y}, v2f{es.zm.y, es.zm.y}};
             const bool evenA = !RB || ((cA + t + a.parity) & 1) == 0;  // scalar; B has the other colour pattern
             const RowSide &ha = hA[k & 1], &hb = hB[k & 1];
-#ifdef EPIC_EXP3D_TRAFFIC  // timing experiment only (wrong results): the loads and stores of the sweep, no arithmetic
-            auto mx4 = [](const float4 &x, const float4 &y) { return make_float4(max2(x.x, y.x), max2(x.y, y.y), max2(x.z, y.z), max2(x.w, y.w)); };
-            const float4 oA = mx4(mx4(qA[km], qA[kp]), mx4(pa[k], qB[k])), oB = mx4(mx4(qB[km], qB[kp]), mx4(pb[k], qA[k]));
-            (void)so_a; (void)so_b; (void)evenA; (void)ha; (void)hb; (void)esA; (void)esB;
-#else
             // the reference's order of the six neighbours: x0 - 1, x0 + 1, x1 - 1, x1 + 1, (x2 - 1, x2 + 1 inside tol_row_3d)
             // both rows' table reads are issued before either is waited for (Jacobi: 8 reads in flight; red-black: 4): the row
             // B's front end covers row A's round trip to LDS and the other way round
@@ -544,7 +514,6 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pa
             }
             const float4 oA = tol_row_3d_back<RB, 6, (RB ? 2 : 4)>(fA, qA[k], ha.m0, ha.m1, ha.m2, ha.m3, evenA);
             const float4 oB = tol_row_3d_back<RB, 2, 0>(fB, qB[k], hb.m0, hb.m1, hb.m2, hb.m3, !evenA);
-#endif
             const bool chk_t = !X0M || (t >= a.check_lo && t < a.check_hi);  // scalar
             if (chkA && chk_t) fold(qA[k], oA);
             if (chkB && chk_t) fold(qB[k], oB);

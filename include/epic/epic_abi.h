@@ -84,7 +84,10 @@ int harmonic_update_and_check_cpu(Harmonic *harmonic); /* harmonic_cpu.h:56 */
 /* ---- GPU solver, libepic/include/epic/harmonic/harmonic_gpu.h:39-86.
  * numThreads is kept for ABI compatibility: it must be a multiple of 32
  * (else EPIC_ERROR_INVALID_CUDA_PARAM, as harmonic_gpu.cu:240-244) and is otherwise a hint.
- * One "iteration" here is one full Jacobi sweep of every unlocked cell. ---- */
+ * One "iteration" is what it is in the reference: one red-black half-sweep, the colour chosen by currentIteration
+ * (harmonic_cpu.cpp:46-51); with the library's defaults every iteration, the iteration count and the converged field are
+ * harmonic_complete_cpu's bit for bit.  EPIC_HIP_SCHEME=jacobi / epic_hip_set_scheme make an iteration a full Jacobi sweep
+ * of every unlocked cell instead (include/epic_hip.h). ---- */
 int harmonic_complete_gpu(Harmonic *harmonic, unsigned int numThreads);         /* harmonic_gpu.h:39 */
 int harmonic_initialize_gpu(Harmonic *harmonic, unsigned int numThreads);       /* harmonic_gpu.h:47 */
 int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads);          /* harmonic_gpu.h:55 */

@@ -175,14 +175,15 @@ int epic_hip_sweep_2d(const float *d_in, float *d_out, const uint32_t *d_maskw, 
  * rows_per_task = 0: the library's choice for this size. */
 int epic_hip_sweep2_2d(const float *d_in, float *d_out, const uint32_t *d_maskw, unsigned int rows, unsigned int pitch,
                        unsigned int rows_per_task, int math_mode, void *stream);
-/* The masks a second time, cut for the fused passes' lane -> column mapping (strips of 248 columns): epic_hip_sweep2_2d and
- * epic_hip_sweeps_2d take them as d_maskf and then skip a funnel shift of two mask words per row and wave (NULL: they shift).
+/* The masks a second time, cut for the fused passes' lane -> column mapping (strips of 248 columns): epic_hip_sweeps_2d takes
+ * them as d_maskf and then skips a funnel shift of two mask words per row and wave (NULL: it shifts, as epic_hip_sweep2_2d,
+ * which has no such parameter, always does -- a different instantiation of the pass: time and tune through the call you run).
  * epic_hip_mask_words_fused_2d(rows, pitch) uint32 words; derive after every epic_hip_pack_mask_2d. */
 size_t epic_hip_mask_words_fused_2d(unsigned int rows, unsigned int pitch);
 int epic_hip_fuse_masks_2d(const uint32_t *d_maskw, unsigned int rows, unsigned int pitch, uint32_t *d_maskf, void *stream);
 /* `n` plain Jacobi sweeps of the whole local grid in ONE call (a driver in an interpreted language pays its per-call cost
  * once per stretch between two halo exchanges instead of once per launch): the field starts in d_a, the sweeps ping-pong
- * between d_a and d_b, *flips receives the number of buffer changes (odd: the result is in d_b).  tol math (math_mode 4):
+ * between d_a and d_b, *flips receives the PARITY of the number of buffer changes (1: the result is in d_b, 0: in d_a).  tol math (math_mode 4):
  * pairs of sweeps run as fused passes (rows_per_pair = 0: the library's choice), a last odd sweep singly; other modes: n single
  * sweeps.  Bit-identical to n calls of epic_hip_sweep_2d. */
 int epic_hip_sweeps_2d(float *d_a, float *d_b, const uint32_t *d_maskw, const uint32_t *d_maskf, unsigned int rows,

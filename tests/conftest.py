@@ -11,7 +11,9 @@ os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
 # The library's default iteration is the reference's red-black half-sweep (bit-identical to harmonic_complete_cpu with the
 # default precise math).  Most of this suite was written against the Jacobi scheme -- the one BASELINE.json's metric names and
 # bench.py times -- and compares with the checker's Jacobi, so the session selects it the way a user would; the tests of the
-# DEFAULT (tests/test_gpu_default_scheme.py, the plugin replay without any variable) remove the variable again.
+# DEFAULT remove the variable again (scheme_env(None) below): tests/test_gpu_bench_parity.py::test_empty_environment_...,
+# tests/test_gpu_tile.py::test_maps_relax_through_tiles_..., tests/test_gpu_callers_eps.py (every reference map at the
+# callers' epsilons) and the C++ plugin replay (tests/test_gpu_plugin_replay.py), which runs without any variable.
 os.environ.setdefault("EPIC_HIP_SCHEME", "jacobi")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -33,6 +33,7 @@ using namespace epic;
 
 struct Input {
     unsigned rows = 0, cols = 0;
+    float epsilon = 1e-3f;                        // the callers' own: src/epic_nav_core_plugin.cpp:61,85, src/epic_navigation_node_harmonic.cpp:64
     std::vector<unsigned char> occupied;          // rows x cols, 1 = obstacle
     std::vector<unsigned> goals;                  // (x, y) pairs
     std::vector<float> starts;                    // x, y, step, precision
@@ -42,10 +43,11 @@ static bool read_input(const char *path, Input &in)
 {
     FILE *f = fopen(path, "rb");
     if (!f) return false;
-    unsigned hdr[4];
-    bool ok = fread(hdr, 4, 4, f) == 4;
+    unsigned hdr[5];   // rows, cols, goals, starts, epsilon (float bits)
+    bool ok = fread(hdr, 4, 5, f) == 5;
     if (ok) {
         in.rows = hdr[0]; in.cols = hdr[1];
+        memcpy(&in.epsilon, &hdr[4], 4);
         in.occupied.resize((size_t)in.rows * in.cols);
         in.goals.resize(2 * (size_t)hdr[2]);
         in.starts.resize(4 * (size_t)hdr[3]);
@@ -85,7 +87,7 @@ struct Node {
             harmonic.locked[(harmonic.m[0] - 1) * harmonic.m[1] + x] = 1;
         }
     }
-    bool initAlg(unsigned w, unsigned h)
+    bool initAlg(unsigned w, unsigned h, float epsilon)
     {
         harmonic.n = 2;
         harmonic.m = new unsigned int[2];
@@ -95,7 +97,7 @@ struct Node {
         harmonic.locked = new unsigned int[w * h];
         for (unsigned i = 0; i < w * h; i++) { harmonic.u[i] = 0.0f; harmonic.locked[i] = 0; }
         setBoundariesAsObstacles();
-        harmonic.epsilon = 1e-6f;
+        harmonic.epsilon = epsilon;
         harmonic.numIterationsToStaggerCheck = 100;
         int result = harmonic_initialize_dimension_size_gpu(&harmonic);
         result += harmonic_initialize_potential_values_gpu(&harmonic);
@@ -142,7 +144,7 @@ struct Node {
 static int run_node(const Input &in, FILE *out)
 {
     Node node;
-    if (!node.initAlg(in.cols, in.rows)) { fprintf(stderr, "replay: initAlg failed (no GPU?)\n"); return 3; }
+    if (!node.initAlg(in.cols, in.rows, in.epsilon)) { fprintf(stderr, "replay: initAlg failed (no GPU?)\n"); return 3; }
     // the /map callback (epic_navigation_node_harmonic.cpp:383-422): every interior cell becomes an obstacle or a free cell
     std::vector<unsigned int> v, types;
     for (unsigned y = 1; y + 1 < in.rows; y++)
@@ -207,7 +209,7 @@ static void plugin_grid(const Input &in, Harmonic &harmonic)   // epic_nav_core_
             harmonic.u[y * in.cols + x] = obst ? EPIC_LOG_SPACE_OBSTACLE : EPIC_LOG_SPACE_FREE;
             harmonic.locked[y * in.cols + x] = obst ? 1 : 0;
         }
-    harmonic.epsilon = 1e-6f;
+    harmonic.epsilon = in.epsilon;
     harmonic.delta = 0.0f;
     harmonic.numIterationsToStaggerCheck = 100;
 }

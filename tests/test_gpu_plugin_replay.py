@@ -42,10 +42,10 @@ def replay_exe(tmp_path_factory):
     return exe
 
 
-def write_input(path, occupied, goals, starts):
+def write_input(path, occupied, goals, starts, epsilon):
     rows, cols = occupied.shape
     with open(path, "wb") as f:
-        f.write(struct.pack("<4I", rows, cols, len(goals), len(starts)))
+        f.write(struct.pack("<4If", rows, cols, len(goals), len(starts), epsilon))
         f.write(np.ascontiguousarray(occupied, dtype=np.uint8).tobytes())
         f.write(np.asarray(goals, dtype=np.uint32).tobytes())
         f.write(np.asarray(starts, dtype=np.float32).tobytes())
@@ -81,7 +81,14 @@ def test_navigation_node_sequence_on_maze_gives_the_reference_paths(replay_exe, 
     paths = np.load(os.path.join(ROOT, "tests", "golden", "paths.npz"))
     starts = [paths[f"maze/path{j}_start"] for j in range(6)]
     inp, outp = str(tmp_path / "maze.in"), str(tmp_path / "maze.out")
-    write_input(inp, occupied, goals, starts)
+    # the node's own epsilon (src/epic_navigation_node_harmonic.cpp:64): the reference stops after 49 301 iterations there
+    # (tests/golden/manifest.json, harmonic_complete_cpu at 1e-3; the node's update(100) loop checks at the same iterations)
+    write_input(inp, occupied, goals, starts, 1e-3)
+    buf, err = run(replay_exe, "node", inp, outp, None)
+    (iterations,) = struct.unpack_from("<I", buf, 0)
+    assert iterations == goldens["manifest"]["maps"]["maze"]["runs"]["0.001"]["iterations"], err
+    # and relaxed to stagnation, where the golden streamlines were taken
+    write_input(inp, occupied, goals, starts, 1e-6)
     for scheme in (None, "redblack"):   # None: an EMPTY environment -- the library default must be the reference's iteration
         buf, err = run(replay_exe, "node", inp, outp, scheme)
         (iterations,) = struct.unpack_from("<I", buf, 0)
@@ -105,7 +112,7 @@ def test_nav_core_plugin_sequence_equals_its_cpu_fallback(replay_exe, tmp_path):
     starts = [(float(free[len(free) // 2][1]), float(free[len(free) // 2][0]), 0.05, 0.5),
               (float(free[len(free) // 3][1]) + 0.25, float(free[len(free) // 3][0]) - 0.25, 0.05, 0.5)]
     inp, outp = str(tmp_path / "plugin.in"), str(tmp_path / "plugin.out")
-    write_input(inp, locked != 0, goals, starts)
+    write_input(inp, locked != 0, goals, starts, 1e-3)      # the plugin's epsilon (src/epic_nav_core_plugin.cpp:61,85)
     buf, err = run(replay_exe, "plugin", inp, outp, None)   # empty environment: the library default
     off = 0
     for g in range(2):
