@@ -179,6 +179,7 @@ struct Ctx {
         int top() const { return lo - g_top; }           // global row of local row 0
     };
     std::vector<Slab> slabs;
+    bool plan_failed = false;      // multi_plan: the slabs of a usable device list could not be given their streams / events / pinned buffers
     int slab_n = 0;                // dimensionality the slabs were laid out for
     Crew *crew = nullptr;          // one issuing thread per slab (null: the caller's thread issues everything)
     std::vector<int> devices;      // EPIC_HIP_DEVICES as given (validated); fewer than 2 entries: single-device mode
@@ -993,6 +994,7 @@ bool multi_plan(Ctx *c)
     const int want = (int)c->devices.size();
     const int units = c->n == 2 ? c->rows : c->m[0];
     const bool multi = want >= 2 && (c->n == 2 || c->n == 3) && units >= 4 * want;
+    c->plan_failed = false;
     if (!multi) {
         if (!c->slabs.empty() && !multi_holds_anything(c)) multi_destroy(c);
         return false;
@@ -1030,6 +1032,7 @@ bool multi_plan(Ctx *c)
         if (!ok) {
             (void)hipGetLastError();
             multi_destroy(c);
+            c->plan_failed = true;
             return false;
         }
         // the seam between slab k - 1 and this one: direct copies where the fabric allows them, checked in both directions
@@ -1061,6 +1064,7 @@ bool multi_plan(Ctx *c)
                     hipHostMalloc((void **)&sl.bounce[1], bytes, hipHostMallocPortable) != hipSuccess) {
                     (void)hipGetLastError();
                     multi_destroy(c);
+                    c->plan_failed = true;
                     return false;
                 }
             }
@@ -1548,6 +1552,12 @@ int harmonic_initialize_potential_values_gpu(Harmonic *harmonic)  // harmonic_mo
     for (float *&b : c->buf) { if (b) (void)hipFree(b); b = nullptr; }
     if (c->multi()) { DeviceGuard g; multi_free_u(c); }
     dims_into_ctx(harmonic, c);
+    if (c->plan_failed) {   // (EPIC_HIP_DEVICES: not silently on one device instead -- the caller asked for the node)
+        report(fn, "Failed to create the streams, events and staging buffers of the device slabs.");
+        harmonic->d_u = nullptr;
+        drop_ctx_if_empty(harmonic);
+        return EPIC_ERROR_DEVICE_MALLOC;
+    }
     if (c->multi()) {  // one pair of buffers per slab, each on its device
         DeviceGuard g;
         for (auto &sl : c->slabs)
@@ -1623,6 +1633,12 @@ int harmonic_initialize_locked_gpu(Harmonic *harmonic)  // harmonic_model_gpu.cu
     if (c->maskw) { (void)hipFree(c->maskw); c->maskw = nullptr; }
     if (c->multi()) { DeviceGuard g; multi_free_mask(c); }
     dims_into_ctx(harmonic, c);
+    if (c->plan_failed) {
+        report(fn, "Failed to create the streams, events and staging buffers of the device slabs.");
+        harmonic->d_locked = nullptr;
+        drop_ctx_if_empty(harmonic);
+        return EPIC_ERROR_DEVICE_MALLOC;
+    }
     if (c->multi()) {
         {
             DeviceGuard g;

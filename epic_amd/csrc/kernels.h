@@ -81,8 +81,38 @@ hipError_t launch_set_cells_2d(float *u, uint32_t *maskw, int rows, int cols, in
 // ---- small grids: several iterations per launch on LDS tiles (kernels_tile2d.hip) ----------------
 // A tile owns tile_rows x tile_cols cells and carries `halo` ghost rings; a launch performs up to `halo` iterations.
 struct TilePlan { int halo, tile_rows, tile_cols, tiles_r, tiles_c; };   // halo == 0: no plan (grid or halo out of range)
-// tile_rows <= 0: as tall as gives every CU one tile (at most 64 - 2 halo)
-TilePlan tile_2d_plan(int rows, int cols, int halo, int tile_rows = 0);
+constexpr int kTile2dCols = 64, kTile2dMaxRows = 64;   // the LDS tile: one lane per column, at most 64 rows with the ghost rings
+// How a grid is cut into tiles for `halo` ghost rings: owned columns 64 - 2 halo; owned rows as tall as the LDS tile allows, but
+// not taller than what gives every CU of the chip a tile (the tiles of a launch run side by side: its time is the time of ONE
+// tile, so smaller tiles are faster until the chip is full).  tile_rows > 0: that height (clamped).
+inline TilePlan tile_2d_plan(int rows, int cols, int halo, int tile_rows = 0)
+{
+    TilePlan p = {0, 0, 0, 0, 0};
+    if (halo < 1 || 2 * halo >= kTile2dCols - 8 || rows < 3 || cols < 3) return p;
+    const int tc = kTile2dCols - 2 * halo;
+    const int tiles_c = (cols + tc - 1) / tc;
+    const int max_tr = kTile2dMaxRows - 2 * halo;
+    int tr = tile_rows;
+    if (tr <= 0) {
+        int cus = 256, dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+            (void)hipGetLastError();
+            cus = 256;
+        }
+        const int tiles_r_max = cus / tiles_c > 1 ? cus / tiles_c : 1;   // rows of tiles the chip takes in one round
+        tr = (rows + tiles_r_max - 1) / tiles_r_max;
+        tr = (tr + 1) / 2 * 2;                                           // (even: the LDS tile is walked in row pairs)
+        if (tr < 8) tr = 8;
+    }
+    tr = (tr < max_tr ? tr : max_tr) / 2 * 2;
+    if (tr < 2) return p;
+    p.halo = halo;
+    p.tile_rows = tr;
+    p.tile_cols = tc;
+    p.tiles_r = (rows + tr - 1) / tr;
+    p.tiles_c = tiles_c;
+    return p;
+}
 // `steps` (<= plan.halo) iterations in -> out (in != out, also for red-black: a neighbouring tile must find the old ghost
 // values).  parity < 0: Jacobi; else red-black, parity = number of the first iteration & 1.  delta_bits (may be null): max |du|
 // of the LAST of the iterations (zero it first); tile_delta (may be null): the same maximum per tile, tiles_r x tiles_c floats

@@ -34,8 +34,8 @@ namespace {
 #ifndef EPIC_TILE_WAVES  // build knob (A/B): waves per workgroup
 #define EPIC_TILE_WAVES 16
 #endif
-constexpr int kTileCols = 64;          // LDS tile width = lanes of a wave
-constexpr int kTileMaxRows = 64;       // S_r <= 64
+constexpr int kTileCols = kTile2dCols;        // LDS tile width = lanes of a wave
+constexpr int kTileMaxRows = kTile2dMaxRows;  // S_r <= 64
 constexpr int kTileWaves = EPIC_TILE_WAVES;
 constexpr int kTileThreads = 64 * kTileWaves;
 // A step is as long as its slowest wave, and a cell's update is one chain of ~80 dependent instructions with three LDS round
@@ -202,37 +202,6 @@ __global__ __launch_bounds__(kTileThreads) void tile2d_kernel(Tile2dArgs a)
 }
 
 }  // namespace
-
-// How a grid is cut into tiles for `halo` ghost rings: owned columns 64 - 2 halo; owned rows as tall as the LDS tile
-// allows, but not taller than what gives every CU of the chip a tile (the tiles of a launch run side by side: its time
-// is the time of ONE tile, so smaller tiles are faster until the chip is full).
-TilePlan tile_2d_plan(int rows, int cols, int halo, int tile_rows)
-{
-    TilePlan p = {0, 0, 0, 0, 0};
-    if (halo < 1 || 2 * halo >= kTileCols - 8 || rows < 3 || cols < 3) return p;
-    const int tc = kTileCols - 2 * halo;
-    const int tiles_c = (cols + tc - 1) / tc;
-    const int max_tr = kTileMaxRows - 2 * halo;
-    int tr = tile_rows;
-    if (tr <= 0) {
-        int cus = 256, dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
-            (void)hipGetLastError();
-            cus = 256;
-        }
-        const int tiles_r_max = std::max(1, cus / tiles_c);   // rows of tiles the chip takes in one round
-        tr = (rows + tiles_r_max - 1) / tiles_r_max;
-        tr = std::max((tr + 1) / 2 * 2, 8);                   // (even: the LDS tile is walked in row pairs)
-    }
-    tr = std::min(tr, max_tr) / 2 * 2;
-    if (tr < 2) return p;
-    p.halo = halo;
-    p.tile_rows = tr;
-    p.tile_cols = tc;
-    p.tiles_r = (rows + tr - 1) / tr;
-    p.tiles_c = tiles_c;
-    return p;
-}
 
 hipError_t launch_tile_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, const TilePlan &plan, int steps,
                           int math, int parity, unsigned *delta_bits, hipStream_t stream, float *tile_delta)

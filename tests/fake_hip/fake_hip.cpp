@@ -1,0 +1,288 @@
+// fake_hip.cpp -- a malloc-backed stand-in for the HIP runtime and for the kernel launchers, TEST INFRASTRUCTURE ONLY.
+//
+// tests/test_host_driver_faults.py compiles epic_amd/csrc/harmonic_gpu.hip (the library's HOST driver, unchanged) against
+// tests/fake_hip/hip/hip_runtime.h and links it with this file under -fsanitize=address,undefined (and, for the issuing
+// threads of the multi-device mode, -fsanitize=thread).  What the fake provides:
+//   * memory: hipMalloc / hipHostMalloc are malloc + a registry; copies are memcpy with the device side checked against the
+//     registry (and by ASan against the allocation); streams execute at once; events and graphs are registered objects;
+//   * fault injection: fake_hip_fail_at(n) makes the n-th fallible call fail -- allocations, copies, memsets, stream / event
+//     creation, synchronisations, kernel launches --, once;
+//   * kernels: the launchers of epic_amd/csrc/kernels.h as no-ops that honour the injection (a check iteration then reports
+//     max |du| = 0, so the "until converged" loops end after max(m) iterations);
+//   * accounting: live objects per kind and a misuse counter (free / destroy of something not live, copies outside an
+//     allocation), which the driver program asserts on after every unwind.
+// Stream capture is refused (hipErrorNotSupported), which sends the library down its eager fallback.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <set>
+
+#include "../../epic_amd/csrc/kernels.h"
+
+namespace {
+struct State {
+    std::mutex mu;
+    std::map<char *, size_t> dev, host;
+    std::set<void *> streams, events, graphs;
+    long calls = 0, fail_at = 0, misuse = 0;
+    bool failed = false;
+    const char *failed_name = "";
+    int devices = 1;
+};
+State g;
+thread_local int t_dev = 0;
+thread_local hipError_t t_last = hipSuccess;
+
+hipError_t fail(hipError_t e)
+{
+    t_last = e;
+    return e;
+}
+// one fallible call: true = this is the one that fails
+bool trip(const char *name)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    g.calls++;
+    if (g.fail_at > 0 && !g.failed && g.calls == g.fail_at) {
+        g.failed = true;
+        g.failed_name = name;
+        return true;
+    }
+    return false;
+}
+// [p, p + bytes) inside a live allocation of `m`
+bool inside(std::map<char *, size_t> &m, const void *p, size_t bytes)
+{
+    auto it = m.upper_bound((char *)const_cast<void *>(p));
+    if (it == m.begin()) return false;
+    --it;
+    return (char *)p >= it->first && (char *)p + bytes <= it->first + it->second;
+}
+void check_device(const void *p, size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!inside(g.dev, p, bytes)) g.misuse++;
+}
+void check_side(const void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    if (bytes == 0) return;
+    if (kind == hipMemcpyHostToDevice || kind == hipMemcpyDeviceToDevice) check_device(dst, bytes);
+    if (kind == hipMemcpyDeviceToHost || kind == hipMemcpyDeviceToDevice) check_device(src, bytes);
+}
+template <class T> hipError_t make(T **out, std::set<void *> &reg, const char *name)
+{
+    if (trip(name)) return fail(hipErrorOutOfMemory);
+    *out = (T *)malloc(16);
+    std::lock_guard<std::mutex> lk(g.mu);
+    reg.insert(*out);
+    return hipSuccess;
+}
+hipError_t unmake(void *p, std::set<void *> &reg)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!reg.erase(p)) { g.misuse++; return fail(hipErrorInvalidValue); }
+    free(p);
+    return hipSuccess;
+}
+}  // namespace
+
+extern "C" {
+void fake_hip_fail_at(long n)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    g.calls = 0;
+    g.fail_at = n;
+    g.failed = false;
+    g.failed_name = "";
+}
+long fake_hip_calls(void) { std::lock_guard<std::mutex> lk(g.mu); return g.calls; }
+int fake_hip_failed(void) { std::lock_guard<std::mutex> lk(g.mu); return g.failed; }
+const char *fake_hip_failed_call(void) { std::lock_guard<std::mutex> lk(g.mu); return g.failed_name; }
+long fake_hip_live(int kind)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    return kind == 0 ? (long)g.dev.size() : kind == 1 ? (long)g.host.size() : kind == 2 ? (long)g.streams.size()
+           : kind == 3 ? (long)g.events.size() : (long)g.graphs.size();
+}
+long fake_hip_misuse(void) { std::lock_guard<std::mutex> lk(g.mu); return g.misuse; }
+void fake_hip_set_devices(int n) { std::lock_guard<std::mutex> lk(g.mu); g.devices = n; }
+
+hipError_t hipGetLastError(void) { const hipError_t e = t_last; t_last = hipSuccess; return e; }
+hipError_t hipGetDeviceCount(int *n) { std::lock_guard<std::mutex> lk(g.mu); *n = g.devices; return hipSuccess; }
+hipError_t hipGetDevice(int *dev) { *dev = t_dev; return hipSuccess; }
+hipError_t hipSetDevice(int dev)
+{
+    { std::lock_guard<std::mutex> lk(g.mu); if (dev < 0 || dev >= g.devices) return fail(hipErrorInvalidDevice); }
+    t_dev = dev;
+    return hipSuccess;
+}
+hipError_t hipDeviceGetAttribute(int *value, hipDeviceAttribute_t, int) { *value = 256; return hipSuccess; }
+hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = 1; return hipSuccess; }
+hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
+
+hipError_t hipMalloc(void **p, size_t bytes)
+{
+    *p = nullptr;
+    if (trip("hipMalloc")) return fail(hipErrorOutOfMemory);
+    char *q = (char *)malloc(bytes ? bytes : 1);
+    if (!q) return fail(hipErrorOutOfMemory);
+    memset(q, 0xA5, bytes);   // device memory is not zeroed
+    std::lock_guard<std::mutex> lk(g.mu);
+    g.dev[q] = bytes;
+    *p = q;
+    return hipSuccess;
+}
+hipError_t hipFree(void *p)
+{
+    if (!p) return hipSuccess;
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g.dev.erase((char *)p)) { g.misuse++; return fail(hipErrorInvalidValue); }
+    free(p);
+    return hipSuccess;
+}
+hipError_t hipHostMalloc(void **p, size_t bytes, unsigned)
+{
+    *p = nullptr;
+    if (trip("hipHostMalloc")) return fail(hipErrorOutOfMemory);
+    char *q = (char *)malloc(bytes ? bytes : 1);
+    if (!q) return fail(hipErrorOutOfMemory);
+    memset(q, 0x5A, bytes);
+    std::lock_guard<std::mutex> lk(g.mu);
+    g.host[q] = bytes;
+    *p = q;
+    return hipSuccess;
+}
+hipError_t hipHostFree(void *p)
+{
+    if (!p) return hipSuccess;
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g.host.erase((char *)p)) { g.misuse++; return fail(hipErrorInvalidValue); }
+    free(p);
+    return hipSuccess;
+}
+hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    if (trip("hipMemcpy")) return fail(hipErrorUnknown);
+    check_side(dst, src, bytes, kind);
+    memmove(dst, src, bytes);
+    return hipSuccess;
+}
+hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t)
+{
+    if (trip("hipMemcpyAsync")) return fail(hipErrorUnknown);
+    check_side(dst, src, bytes, kind);
+    memmove(dst, src, bytes);
+    return hipSuccess;
+}
+hipError_t hipMemcpy2D(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind)
+{
+    if (trip("hipMemcpy2D")) return fail(hipErrorUnknown);
+    if (width > dpitch || width > spitch) { std::lock_guard<std::mutex> lk(g.mu); g.misuse++; return fail(hipErrorInvalidValue); }
+    for (size_t r = 0; r < height; r++) {
+        check_side((char *)dst + r * dpitch, (const char *)src + r * spitch, width, kind);
+        memmove((char *)dst + r * dpitch, (const char *)src + r * spitch, width);
+    }
+    return hipSuccess;
+}
+hipError_t hipMemcpyPeerAsync(void *dst, int, const void *src, int, size_t bytes, hipStream_t)
+{
+    if (trip("hipMemcpyPeerAsync")) return fail(hipErrorUnknown);
+    check_side(dst, src, bytes, hipMemcpyDeviceToDevice);
+    memmove(dst, src, bytes);
+    return hipSuccess;
+}
+hipError_t hipMemset(void *p, int v, size_t bytes)
+{
+    if (trip("hipMemset")) return fail(hipErrorUnknown);
+    check_device(p, bytes);
+    memset(p, v, bytes);
+    return hipSuccess;
+}
+hipError_t hipMemsetAsync(void *p, int v, size_t bytes, hipStream_t)
+{
+    if (trip("hipMemsetAsync")) return fail(hipErrorUnknown);
+    check_device(p, bytes);
+    memset(p, v, bytes);
+    return hipSuccess;
+}
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { return make(s, g.streams, "hipStreamCreateWithFlags"); }
+hipError_t hipStreamDestroy(hipStream_t s) { return unmake(s, g.streams); }
+hipError_t hipStreamSynchronize(hipStream_t) { return trip("hipStreamSynchronize") ? fail(hipErrorUnknown) : hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return trip("hipStreamWaitEvent") ? fail(hipErrorUnknown) : hipSuccess; }
+hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus *status) { *status = hipStreamCaptureStatusNone; return hipSuccess; }
+hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return fail(hipErrorNotSupported); }
+hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *gr) { *gr = nullptr; return fail(hipErrorNotSupported); }
+hipError_t hipGraphInstantiate(hipGraphExec_t *e, hipGraph_t, hipGraphNode_t *, char *, size_t) { *e = nullptr; return fail(hipErrorNotSupported); }
+hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return fail(hipErrorNotSupported); }
+hipError_t hipEventCreate(hipEvent_t *e) { return make(e, g.events, "hipEventCreate"); }
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return make(e, g.events, "hipEventCreateWithFlags"); }
+hipError_t hipEventDestroy(hipEvent_t e) { return unmake(e, g.events); }
+hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return trip("hipEventRecord") ? fail(hipErrorUnknown) : hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return trip("hipEventSynchronize") ? fail(hipErrorUnknown) : hipSuccess; }
+hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 1.0f; return hipSuccess; }
+}  // extern "C"
+
+// ---- the kernel launchers of epic_amd/csrc/kernels.h: no-ops that can be made to fail --------------------------------
+namespace epic_hip {
+#define FAKE_LAUNCH(name) do { if (trip(name)) return fail(hipErrorUnknown); } while (0)
+int resident_blocks_of(const void *) { return 2048; }
+hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *, int rows, int pitch, int, int, int, int, int, unsigned *, hipStream_t,
+                           const Activity *, int, int)
+{
+    FAKE_LAUNCH("launch_sweep_2d");
+    check_device(in, (size_t)rows * pitch * 4);
+    check_device(out, (size_t)rows * pitch * 4);
+    return hipSuccess;
+}
+hipError_t launch_wake_tile_range(const Activity *, size_t, int, int, hipStream_t) { FAKE_LAUNCH("launch_wake_tile_range"); return hipSuccess; }
+hipError_t launch_rb_fused_2d(const float *, float *, const uint32_t *, int, int, int, int, int, hipStream_t, const uint32_t *) { FAKE_LAUNCH("launch_rb_fused_2d"); return hipSuccess; }
+hipError_t launch_jacobi_fused_2d(const float *, float *, const uint32_t *, int, int, int, int, hipStream_t, int, const uint32_t *) { FAKE_LAUNCH("launch_jacobi_fused_2d"); return hipSuccess; }
+hipError_t launch_fuse_masks_2d(const uint32_t *, int, int, uint32_t *, hipStream_t) { FAKE_LAUNCH("launch_fuse_masks_2d"); return hipSuccess; }
+hipError_t launch_eval_math(const float *, float *, size_t, int, hipStream_t) { FAKE_LAUNCH("launch_eval_math"); return hipSuccess; }
+hipError_t launch_pack_mask_2d(const uint32_t *locked, int rows, int cols, int, int, int, uint32_t *, hipStream_t)
+{
+    FAKE_LAUNCH("launch_pack_mask_2d");
+    check_device(locked, (size_t)rows * cols * 4);
+    return hipSuccess;
+}
+hipError_t launch_fill(float *p, size_t n, float v, hipStream_t)
+{
+    FAKE_LAUNCH("launch_fill");
+    check_device(p, n * 4);
+    for (size_t i = 0; i < n; i++) p[i] = v;
+    return hipSuccess;
+}
+hipError_t launch_set_cells_2d(float *, uint32_t *, int, int, int, unsigned, const unsigned *, const unsigned *, hipStream_t, int, int, int, int) { FAKE_LAUNCH("launch_set_cells_2d"); return hipSuccess; }
+hipError_t launch_tile_2d(const float *in, float *out, const uint32_t *, int rows, int pitch, const TilePlan &plan, int, int, int, unsigned *, hipStream_t,
+                          float *tile_delta)
+{
+    FAKE_LAUNCH("launch_tile_2d");
+    check_device(in, (size_t)rows * pitch * 4);
+    check_device(out, (size_t)rows * pitch * 4);
+    if (tile_delta)
+        for (int t = 0; t < plan.tiles_r * plan.tiles_c; t++) tile_delta[t] = 0.0f;
+    return hipSuccess;
+}
+hipError_t launch_follow_paths_2d(const float *, const uint32_t *, int, int, int, unsigned n_paths, const float *, float, float, unsigned, float *, unsigned *d_k,
+                                  int *d_rc, hipStream_t)
+{
+    FAKE_LAUNCH("launch_follow_paths_2d");
+    for (unsigned i = 0; i < n_paths; i++) { d_k[i] = 0; d_rc[i] = 12; }
+    return hipSuccess;
+}
+hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *, int m0, int m1, int pitch, int, int, int, int, unsigned *, hipStream_t, const Activity *, int,
+                           int)
+{
+    FAKE_LAUNCH("launch_sweep_3d");
+    check_device(in, (size_t)m0 * m1 * pitch * 4);
+    check_device(out, (size_t)m0 * m1 * pitch * 4);
+    return hipSuccess;
+}
+hipError_t launch_pack_mask_3d(const uint32_t *, int, int, int, int, uint32_t *, hipStream_t) { FAKE_LAUNCH("launch_pack_mask_3d"); return hipSuccess; }
+}  // namespace epic_hip

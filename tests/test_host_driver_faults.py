@@ -1,0 +1,65 @@
+"""The library's HOST driver under the sanitizers with fault injection (CPU container; nothing here needs or touches a GPU).
+
+epic_amd/csrc/harmonic_gpu.hip -- the registry of contexts, the device-state lifecycle with its ~20 allocation sites, the
+driver loops, the multi-device mode with its issuing threads -- is compiled UNCHANGED with g++ against a fake HIP runtime
+(tests/fake_hip/: malloc-backed memory, streams that execute at once, no-op kernels, "fail the n-th call") and driven by
+tests/fake_hip/driver.cpp:
+
+* ASan + UBSan: every fallible runtime call of fifteen call sequences fails in turn (~4 400 runs); after each, the return code
+  must be the reference's for what failed, nothing may be left behind (device / pinned memory, streams, events), the struct's
+  d_* must be null, and the same sequence must run cleanly afterwards.  The reference's own unwind leaks on several of these
+  paths (/root/reference/libepic/src/harmonic/harmonic_model_gpu.cu:50-55, harmonic_utilities_gpu.cu:81-135).
+* TSan: the scenarios in which one host thread per slab issues the launches (struct Crew: hand-over by generation counter,
+  condition variables, per-thread results), with a sample of failing calls.
+
+Test infrastructure only: none of it is compiled into, linked with or loaded by libepic.so.
+"""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "epic_amd", "csrc")
+FAKE = os.path.join(ROOT, "tests", "fake_hip")
+
+pytestmark = pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+
+
+def build(tmp_path, sanitize):
+    flags = ["-std=c++17", "-O1", "-g", "-fsanitize=" + sanitize, "-fno-omit-frame-pointer", "-ffp-contract=off",
+             "-I", FAKE, "-I", os.path.join(ROOT, "include")]
+    if "undefined" in sanitize:
+        flags.append("-fno-sanitize-recover=undefined")
+    exe = str(tmp_path / ("fault_driver_" + sanitize.split(",")[0]))
+    srcs = [os.path.join(CSRC, f) for f in ("harmonic_cpu.cpp", "harmonic_path_cpu.cpp", "harmonic_legacy_cpu.cpp", "abi_checks.cpp")]
+    # the .hip file holds host code only (the kernels live in kernels_*.hip, whose launchers the fake replaces)
+    subprocess.run(["g++", *flags, "-x", "c++", os.path.join(CSRC, "harmonic_gpu.hip"), os.path.join(FAKE, "fake_hip.cpp"),
+                    os.path.join(FAKE, "driver.cpp"), *srcs, "-lpthread", "-o", exe], check=True)
+    return exe
+
+
+def test_every_failing_runtime_call_unwinds_cleanly_under_asan_ubsan(tmp_path):
+    exe = build(tmp_path, "address,undefined")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    env.pop("LD_PRELOAD", None)
+    run = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=1500)
+    tail = run.stdout[-3000:] + run.stderr[-3000:]
+    assert run.returncode == 0, tail
+    assert "fault driver: ok" in run.stdout
+    for bad in ("AddressSanitizer", "LeakSanitizer", "runtime error", "EXPECT failed"):
+        assert bad not in run.stderr, tail
+    walked = [l for l in run.stdout.splitlines() if l.startswith("walked ")]
+    assert walked and int(walked[0].split()[1]) > 3000, walked
+
+
+def test_issuing_threads_are_clean_under_tsan(tmp_path):
+    exe = build(tmp_path, "thread")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0:second_deadlock_stack=1")
+    env.pop("LD_PRELOAD", None)
+    run = subprocess.run([exe, "threads"], capture_output=True, text=True, env=env, timeout=1500)
+    tail = run.stdout[-3000:] + run.stderr[-3000:]
+    assert run.returncode == 0, tail
+    assert "fault driver: ok" in run.stdout
+    assert "ThreadSanitizer" not in run.stderr and "EXPECT failed" not in run.stderr, tail
