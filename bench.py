@@ -98,6 +98,9 @@ def parse():
                     help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes of this command before "
                          "the timed part, N = 1); use the value recorded in profiles/hbm_traffic.json")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity object (maps, 512^2 / 1024^2, 512^3 relaxations)")
+    ap.add_argument("--no-config4", action="store_true", help="skip the 32768^2 leg (BASELINE configs[3]'s grid on one GPU: ~1 minute of host-side grid generation)")
+    ap.add_argument("--no-maps", action="store_true", help="skip the timing of the reference's maps (BASELINE configs[0] / [1])")
+    ap.add_argument("--only-config5", action="store_true", help="(internal) run only the 512^3 leg and print its object: the child of the PMC passes")
     return ap.parse_args()
 
 
@@ -177,8 +180,8 @@ def parity_object(args, E, MODES, relaxed, locked_8192):
         return {"max_rel": float("%.3e" % rel), "max_abs": float("%.3e" % float(d.max())), "bar": bar, "within_bar": bool(rel <= bar),
                 "others_equal": bool(np.array_equal(got[~reached], want[~reached]))}
 
-    def complete(h, math, scheme):
-        h.epsilon = 1e-6
+    def complete(h, math, scheme, eps=1e-6):
+        h.epsilon = eps
         h.numIterationsToStaggerCheck = 100
         prev = {k: os.environ.get(k) for k in ("EPIC_HIP_MATH", "EPIC_HIP_SCHEME")}   # (a user may have exported them for the run)
         os.environ["EPIC_HIP_MATH"], os.environ["EPIC_HIP_SCHEME"] = math, scheme
@@ -217,6 +220,27 @@ def parity_object(args, E, MODES, relaxed, locked_8192):
                 finally:
                     del os.environ["EPIC_HIP_TOL_FINISH"]
             out["configs"][cfg] = e
+        # ... and at the epsilon the reference's callers use (1e-3: src/epic_nav_core_plugin.cpp:61,85, the node, maps.py:67), where the
+        # loop stops while the field still moves and the stop iteration decides the field: the timed mode against the samples
+        # harmonic_complete_cpu left at 1e-3 (tests/golden/ref_maps.npz, 16 384 cells per map), and its iteration count
+        try:
+            rm = np.load(os.path.join(gdir, "ref_maps.npz"))
+            rj = json.load(open(os.path.join(gdir, "ref_maps.json")))["maps"]
+            for name in ("maze", "umass", "basic", "maze_4"):
+                run = rj.get(name, {}).get("runs", {}).get("0.001")
+                if run is None or name + "/samples_0.001" not in rm.files:
+                    continue
+                h = HarmonicMap().load(os.path.join(gdir, "maps", name + ".png"))
+                got, its = complete(h, args.math, args.scheme, 1e-3)
+                idx, want = rm[name + "/sample_idx"], rm[name + "/samples_0.001"]
+                e = dist(got[idx], want, h.locked_array().ravel()[idx])
+                e.update(iterations=its, reference_iterations=run["iterations"], same_iterations=bool(its == run["iterations"]),
+                         against="harmonic_complete_cpu at eps = 1e-3, 16 384 sampled cells (tests/golden/ref_maps.npz)")
+                if its != run["iterations"]:
+                    e["within_bar"] = False
+                out["configs"]["%s.png at the callers' eps = 1e-3" % name] = e
+        except (OSError, ValueError, KeyError) as exc:
+            out["callers_eps_error"] = repr(exc)
         synth = np.load(os.path.join(gdir, "synthetic_converged.npz"))
         for n in (512, 1024):
             u0, locked = synthetic_grid([n, n])
@@ -226,10 +250,11 @@ def parity_object(args, E, MODES, relaxed, locked_8192):
             e = dist(got, synth["s%d/converged" % n], locked)
             e.update(iterations=its, against="harmonic_complete_cpu's converged field (tests/golden/synthetic_converged.npz)")
             out["configs"]["configs[2] family, %dx%d" % (n, n)] = e
-        if "relax" in relaxed and "relax_default" in relaxed:
-            e = dist(relaxed["relax"], relaxed["relax_default"], locked_8192)
-            e.update(against="this run's relax_default (precise + red-black, the reference's iteration bit for bit)")
-            out["configs"]["configs[2] 8192x8192 (the timed grid)"] = e
+        for key, label in (("relax_jacobi", "configs[2] 8192x8192 (the timed grid)"), ("relax", "configs[2] 8192x8192, red-black (the `relax` leg)")):
+            if key in relaxed and "relax_default" in relaxed:
+                e = dist(relaxed[key], relaxed["relax_default"], locked_8192)
+                e.update(against="this run's relax_default (precise + red-black, the reference's iteration bit for bit)")
+                out["configs"][label] = e
         out["configs"]["configs[3] 32768x32768 on 4 / 8 GPUs"] = {"max_rel": None, "note": "not relaxed at N = 1; same arithmetic and kernels, bit-identical across slab counts (tests/test_gpu_multi_device.py)"}
         if not args.no_extra_legs:
             g3 = [512, 512, 512]
@@ -288,7 +313,7 @@ def live_traffic(args):
     if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_PATH",
                                                                  "HSA_TOOLS_LIB")):
         return {}, "this process runs under a profiler"
-    out, counts = {}, {}
+    out, counts = {}, {}   # out: kernel-name fragment -> {"traffic", "launches", "SQ_INSTS_VALU", "SQ_BUSY_CYCLES", "cycles_per_valu"}
     tmp = tempfile.mkdtemp(prefix="epic_pmc_", dir="/tmp")
     # (--develop 5000: past the point where the library measures the task height of its fused passes)
     child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "1", "--develop", "5000",
@@ -306,31 +331,50 @@ def live_traffic(args):
             if rows > 0:
                 env["EPIC_HIP_FUSED_ROWS"] = str(rows)
                 counts["fused_rows_per_task"] = rows
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
-            files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                return {}, "rocprofv3 --pmc %s pass failed (rc %d)" % (counter, r.returncode)
-            per = {}
-            for row in csv.DictReader(open(files[0])):
-                if row["Counter_Name"] != counter:
-                    continue
-                for key in ("jacobi_fused2d_kernel", "rb_tol_fused2d_kernel", "rb_fused2d_kernel", "sweep2d_kernel"):
-                    if key in row["Kernel_Name"]:
-                        per.setdefault(key, []).append(float(row["Counter_Value"]))
-                        break
-            for key, vals in per.items():
-                vals = vals[-90:]   # the steady state: the last step's launches (the library settles its task height during the develop phase)
-                # counter unit KiB; FETCH_SIZE under-reports streaming reads by 2 on gfx950 (the guide's correction)
-                out[key] = out.get(key, 0.0) + statistics.mean(vals) * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0)
-                counts[key] = min(counts.get(key, 1 << 30), len(vals))
+        kernels = ("jacobi_fused2d_kernel", "rb_tol_fused2d_kernel", "rb_fused2d_kernel", "sweep2d_kernel", "sweep3d_pair_kernel",
+                   "sweep3d_kernel")
+        # the 2-D step, then the 3-D sweeps of config5 (--only-config5: nothing but that leg), each under the same three passes:
+        # the two HBM counters in passes of their own (the guide's rule), and one pass for the two SQ counters that say how
+        # busy the VALU was (instructions issued against the cycles the shader engines were busy)
+        for what, cmd_child in (("2d", child), ("3d", child + ["--only-config5"])):
+            for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_BUSY_CYCLES")):
+                d = os.path.join(tmp, what + "_" + counters[0])
+                cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", d, "--"] + cmd_child
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
+                files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+                if r.returncode != 0 or not files:
+                    if what == "2d" and counters[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+                        return {}, "rocprofv3 --pmc %s pass failed (rc %d)" % (counters[0], r.returncode)
+                    continue   # the SQ pass and the 3-D passes are extras: the line says what it has
+                per = {}
+                for row in csv.DictReader(open(files[0])):
+                    if row["Counter_Name"] not in counters:
+                        continue
+                    for key in kernels:
+                        if key in row["Kernel_Name"]:
+                            per.setdefault((key, row["Counter_Name"]), []).append(float(row["Counter_Value"]))
+                            break
+                for (key, counter), vals in per.items():
+                    vals = vals[-90:]   # the steady state: the last step's launches (the library settles its task height during the develop phase)
+                    entry = out.setdefault(key, {})
+                    if counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                        # counter unit KiB; FETCH_SIZE under-reports streaming reads by 2 on gfx950 (the guide's correction)
+                        entry["traffic"] = entry.get("traffic", 0.0) + statistics.mean(vals) * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0)
+                        entry["launches"] = min(entry.get("launches", 1 << 30), len(vals))
+                    else:
+                        entry[counter] = statistics.mean(vals)
     except (OSError, subprocess.SubprocessError, ValueError, KeyError) as exc:
         return {}, "live PMC measurement failed: %r" % (exc,)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    return {k: int(round(v)) for k, v in out.items()}, counts
+    for entry in out.values():
+        if "traffic" in entry:
+            entry["traffic"] = int(round(entry["traffic"]))
+        if entry.get("SQ_INSTS_VALU") and entry.get("SQ_BUSY_CYCLES"):
+            # SQ_BUSY_CYCLES sums the 32 shader engines, SQ_INSTS_VALU the wave instructions of all 1024 SIMDs: cycles per VALU
+            # instruction per SIMD against the 4 a wave64 instruction occupies the SIMD for (tools/summarize_profile.py: sq)
+            entry["cycles_per_valu"] = (entry["SQ_BUSY_CYCLES"] / 32.0) / (entry["SQ_INSTS_VALU"] / 1024.0)
+    return out, counts
 
 
 def main():
@@ -468,45 +512,165 @@ def main():
                    E.harmonic_uninitialize_potential_values_gpu, E.harmonic_uninitialize_locked_gpu):
             fn(h)
 
-    def roofline(cells_per_launch, launch_us, math, scheme, single_device_full_grid, per_pass=1):
+    def roofline(cells_per_launch, launch_us, math, scheme, single_device_full_grid, per_pass=1, kernel=None, valu_bound=None):
         """cells_per_launch: grid cells one launch of the dominant kernel sweeps; per_pass: iterations it advances (2 for
         the fused passes: the algorithmic bytes of a launch are those of the iterations it performs, SURVEY.md section
-        8(d): 8 B per cell per iteration)."""
+        8(d): 8 B per cell per iteration).  `bound` names what the kernel is actually limited by, measured: "valu" where the
+        SQ counters of this run (or the round's profile) show the vector ALU issuing near its rate while HBM moves well under
+        its peak; `frac` stays the ALGORITHMIC-bytes fraction the metric defines, `hbm_frac_measured` is the physical one."""
         achieved = BYTES_PER_CELL_SWEEP * cells_per_launch * per_pass / (launch_us * 1e-6) / 1e9
         fused = per_pass == 2
-        kernel = (("jacobi_fused2d_kernel" if scheme == "jacobi" else "rb_tol_fused2d_kernel" if math == "tol" else "rb_fused2d_kernel")
-                  if fused else "sweep2d_kernel")
-        traffic, source = None, None
-        if single_device_full_grid and math == args.math and scheme == args.scheme and kernel in live:
-            traffic = live[kernel]
+        if kernel is None:
+            kernel = (("jacobi_fused2d_kernel" if scheme == "jacobi" else "rb_tol_fused2d_kernel" if math == "tol" else "rb_fused2d_kernel")
+                      if fused else "sweep2d_kernel")
+        traffic, source, sq = None, None, {}
+        mine = live.get(kernel, {}) if single_device_full_grid and math == args.math else {}
+        if "traffic" in mine:
+            traffic = mine["traffic"]
             source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + --pmc WRITE_SIZE, separate child passes of "
-                      "this command, mean over %d launches of the kernel" % live_note.get(kernel, 0)
+                      "this command, mean over %d launches of the kernel" % mine.get("launches", 0)
                       + (" at %d rows per task (the height a plain child pass saw the library measure)" % live_note["fused_rows_per_task"]
-                         if fused and "fused_rows_per_task" in live_note else ""))
-        elif single_device_full_grid:
+                         if fused and isinstance(live_note, dict) and "fused_rows_per_task" in live_note else ""))
+        elif single_device_full_grid and kernel.startswith(("jacobi_fused2d", "sweep2d", "rb_")):
             traffic = measured_traffic(n, math, scheme + ("_fused" if fused else ""))
             if traffic is not None:
                 source = ("recorded: profiles/hbm_traffic.json (an earlier PMC run of this command; live measurement: %s)"
                           % (live_note if isinstance(live_note, str) else "not for this kernel"))
+        if "cycles_per_valu" in mine:
+            sq = {"valu_issue_frac": round(4.0 / mine["cycles_per_valu"], 4),
+                  "valu_cycles_per_instruction": round(mine["cycles_per_valu"], 3),
+                  "valu_insts_per_cell_update": round(mine["SQ_INSTS_VALU"] * 64.0 / (cells_per_launch * per_pass), 2),
+                  "valu_source": "measured in this run: rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES, a child pass of this command; "
+                                 "issue frac = 4 cycles (one wave64 instruction on a SIMD) / (SQ_BUSY_CYCLES / 32 engines) x (SQ_INSTS_VALU / 1024 SIMDs)"}
         hbm_measured = None if traffic is None else traffic / (launch_us * 1e-6) / 1e9
-        return {
-            "bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        if valu_bound is None:   # decide from what was measured; without counters: what the round's profiles established
+            if sq and hbm_measured is not None:
+                valu_bound = sq["valu_issue_frac"] > hbm_measured / 6300.0   # busier than the memory side against ITS achievable rate
+            else:
+                valu_bound = fused
+        out_r = {
+            "bound": "valu" if valu_bound else "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": source, "launch_us": round(launch_us, 3),
             # `frac` prices the ALGORITHMIC bytes (SURVEY.md section 8d: 8 B per cell per iteration).  What the kernel really
             # moves through HBM is `traffic`; that rate against the same peak is this:
             "hbm_frac_measured": None if hbm_measured is None else round(hbm_measured / HBM_PEAK_GBPS, 4),
             "hbm_GBps_measured": None if hbm_measured is None else round(hbm_measured, 1),
-            "limiter": "valu" if fused else "valu+hbm",
+            "limiter": "valu" if valu_bound else "valu+hbm",
             "iterations_per_launch": per_pass,
             "bytes_per_launch": int(BYTES_PER_CELL_SWEEP * cells_per_launch * per_pass),
             "note": "frac = 8 B x grid cells x iterations per launch / mean launch-to-launch device time (HIP events on the kernel's "
-                    "stream, over a batch of plain iterations = launches of this kernel only) / 8 TB/s: an ALGORITHMIC-bytes figure"
+                    "stream, over a batch of plain iterations = launches of this kernel only) / 8 TB/s: an ALGORITHMIC-bytes figure "
+                    "(achieved, peak and unit are those of that figure); bound says what limits the kernel"
                     + ("; the fused pass performs two iterations per launch while moving the field through HBM once, so its real "
-                       "HBM rate (hbm_frac_measured) is about half of frac and the kernel is bound by VALU issue, not by HBM"
+                       "HBM rate (hbm_frac_measured) is about half of frac and the kernel is bound by VALU issue (valu_issue_frac), not by HBM"
                        if fused else "")
                     + ("; traffic = HBM bytes per launch from the PMC counters, FETCH_SIZE x2 + WRITE_SIZE (see traffic_source)"
                        if traffic is not None else "; traffic: no PMC measurement of this configuration"),
         }
+        out_r.update(sq)
+        return out_r
+
+    def config5_leg(sweeps3=300):
+        """BASELINE configs[4]: 3-D 512^3, 7-point, the timed arithmetic, on a developed field (1 500 of the ~3 800 sweeps the
+        relaxation takes), tracking off; 8 algorithmic bytes per cell per sweep as in 2-D.  With its own roofline object."""
+        g3 = [512, 512, 512]
+        u3, l3 = synthetic_grid(g3)
+        h3, _ = abi_setup(g3, u3, l3, args.math, "jacobi", False)
+        ms3 = ct.c_float(0.0)
+        assert E.epic_hip_update_n_gpu(h3, 1500, 0) == 0
+        assert E.epic_hip_timed_sweeps_gpu(h3, 100, 100, ct.byref(ms3)) == 0
+        assert E.epic_hip_timed_sweeps_gpu(h3, sweeps3, 100, ct.byref(ms3)) == 0
+        us3 = ms3.value * 1e3 / sweeps3
+        res = {"workload": "synthetic 512x512x512, 5% obstacles + 1 goal, 7-point log-space Jacobi (BASELINE configs[4])",
+               "math": args.math, "us_per_sweep": round(us3, 2), "Mcell_updates_per_s": round(int((l3 == 0).sum()) / us3, 1),
+               "frac": round(BYTES_PER_CELL_SWEEP * 512 ** 3 / (us3 * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+               "kernel": "sweep3d_pair_kernel" if args.math == "tol" and os.environ.get("EPIC_HIP_3D_PAIR", "1")[:1] != "0" else "sweep3d_kernel",
+               "developed_sweeps": 1600, "sweeps": sweeps3}
+        res["roofline"] = roofline(512 ** 3, us3, args.math, "jacobi", True, 1, kernel=res["kernel"])
+        res["roofline"]["note"] = ("8 B x 512^3 cells / mean device time per sweep of a step (99 plain sweeps + 1 check per 100, HIP events "
+                                   "on the library's stream) / 8 TB/s; traffic and the VALU figures: PMC child passes of this command "
+                                   "(--only-config5) when measured in this run")
+        if args.math != "precise" and not args.only_config5:
+            assert E.epic_hip_set_math_mode(h3, MODES["precise"]) == 0   # the bit-exact 3-D sweep beside it, same field, same run
+            assert E.epic_hip_timed_sweeps_gpu(h3, 100, 100, ct.byref(ms3)) == 0
+            assert E.epic_hip_timed_sweeps_gpu(h3, 100, 100, ct.byref(ms3)) == 0
+            res["precise"] = {"us_per_sweep": round(ms3.value * 10.0, 2),
+                              "frac": round(BYTES_PER_CELL_SWEEP * 512 ** 3 / (ms3.value * 1e-5) / 1e9 / HBM_PEAK_GBPS, 4),
+                              "kernel": "sweep3d_kernel", "note": "the library's default arithmetic (expf / logf bit-identical to glibc's), Jacobi"}
+        abi_release(h3)
+        return res
+
+    def config4_leg():
+        """BASELINE configs[3]'s grid (32768^2) on ONE GPU: 2 x 4.3 GB of u and 0.13 GB of masks resident, the timed arithmetic,
+        plain iterations on a developed field (past the iteration at which the library measures its task height)."""
+        n4 = 32768
+        t0 = time.perf_counter()
+        u4, l4 = synthetic_grid([n4, n4])
+        gen_s = time.perf_counter() - t0
+        h4, up_s = abi_setup([n4, n4], u4, l4, args.math, args.scheme, False)
+        del u4, l4
+        ms4 = ct.c_float(0.0)
+        dev4 = 17000
+        assert E.epic_hip_update_n_gpu(h4, dev4, 0) == 0
+        per4 = max(1, int(E.epic_hip_iterations_per_pass(h4)))
+        assert E.epic_hip_timed_sweeps_gpu(h4, 40, 0, ct.byref(ms4)) == 0
+        assert E.epic_hip_timed_sweeps_gpu(h4, 100, 0, ct.byref(ms4)) == 0
+        l_us = ms4.value * 1e3 / (100 // per4)
+        assert E.epic_hip_timed_sweeps_gpu(h4, 200, 100, ct.byref(ms4)) == 0   # whole steps: checks and the odd iteration included
+        step_us = ms4.value * 1e3 / 200
+        rows4 = int(E.epic_hip_fused_rows_per_task(h4))
+        abi_release(h4)
+        cells = n4 * n4 if args.scheme == "jacobi" else n4 * n4 // 2
+        return {"workload": "synthetic 32768x32768 (BASELINE configs[3]'s grid) on ONE GPU, %s %s, developed field (%d iterations)" % (args.math, args.scheme, dev4),
+                "kernel": "jacobi_fused2d_kernel" if per4 == 2 and args.scheme == "jacobi" else "sweep2d_kernel", "iterations_per_launch": per4,
+                "launch_us": round(l_us, 2), "frac": round(BYTES_PER_CELL_SWEEP * cells * per4 / (l_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                "step_us_per_iteration": round(step_us, 2), "fused_rows_per_task": rows4,
+                "host_grid_generation_seconds": round(gen_s, 1), "h2d_seconds": round(up_s, 2),
+                "note": "frac as roofline.frac: 8 B x cells x iterations per launch / launch-to-launch device time / 8 TB/s (algorithmic bytes)"}
+
+    def maps_leg():
+        """BASELINE configs[0] / [1] and the reference's 256^2 test map, relaxed as the plugin does it (harmonic_complete_gpu through
+        Harmonic.solve: initialise x 3, complete, uninitialise -- upload and download included; second of two runs).  These grids
+        take the small-grid path (epic_amd/csrc/kernels_tile2d.hip: eight iterations per launch on LDS tiles)."""
+        from epic_amd.harmonic_map import HarmonicMap
+
+        ref = {}
+        for f in ("manifest.json", "ref_maps.json"):
+            try:
+                for k, v in json.load(open(os.path.join(ROOT, "tests", "golden", f)))["maps"].items():
+                    ref.setdefault(k, {}).update(v.get("runs", {}))
+            except (OSError, ValueError, KeyError):
+                pass
+        res = {"note": "seconds: wall time of Harmonic.solve(process='gpu') incl. upload / download, best of two after a warm-up; "
+                       "reference_cpu_seconds: harmonic_complete_cpu of the reference's own sources, one core of the build container "
+                       "(tests/golden/*.json), not of this host; default = no environment (bit-identical to that CPU run)"}
+        saved = {k: os.environ.get(k) for k in ("EPIC_HIP_MATH", "EPIC_HIP_SCHEME")}
+        try:
+            for mode, (mth, sch) in (("default", (None, None)), ("tol_redblack", ("tol", "redblack")), ("tol_jacobi", ("tol", "jacobi"))):
+                for k, v in (("EPIC_HIP_MATH", mth), ("EPIC_HIP_SCHEME", sch)):
+                    os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+                for name in ("maze", "umass", "basic"):
+                    for eps in ((1e-3, 1e-6) if mode == "default" else (1e-6,)):
+                        best = None
+                        for rep in range(3):
+                            hm = HarmonicMap().load(os.path.join(ROOT, "tests", "golden", "maps", name + ".png"))
+                            t0 = time.perf_counter()
+                            hm.solve(process="gpu", epsilon=eps)
+                            dt = time.perf_counter() - t0
+                            best = dt if rep == 1 else (min(best, dt) if rep == 2 else None)
+                        r = ref.get(name, {}).get("%g" % eps, {})
+                        res["%s %s eps %g" % (name, mode, eps)] = {
+                            "seconds": round(best, 4), "iterations": int(hm.currentIteration),
+                            "us_per_iteration": round(best / hm.currentIteration * 1e6, 3),
+                            "reference_cpu_seconds": r.get("seconds"), "reference_iterations": r.get("iterations")}
+        finally:
+            for k, v in saved.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        return res
+
+    if args.only_config5:   # (internal: the child of the PMC passes for config5's roofline object)
+        print(json.dumps({"config5": config5_leg(100)}), flush=True)
+        return
 
     if args.in_library_child > 0:
         # the same 8192^2 grid through the C-ABI in ONE process on N GPUs (EPIC_HIP_DEVICES; halos by hipMemcpyPeerAsync, one
@@ -616,11 +780,14 @@ def main():
             # the complete relaxation, exactly as the plugin runs it (harmonic_execute_gpu), from the initial state: the
             # benchmarked arithmetic with each scheme (activity tracking in the library's automatic mode), with tracking off,
             # and the library as it is with NO environment (precise + red-black: bit-identical to harmonic_complete_cpu)
-            other = "redblack" if args.scheme == "jacobi" else "jacobi"
-            legs = [("relax", args.math, args.scheme, 2), ("relax_" + other, args.math, other, 2),
+            # `relax` is the fastest way to a converged field with the timed ARITHMETIC -- the red-black scheme (a Jacobi run is
+            # two red-black chains interleaved: twice the arithmetic for the same answer) --; the timed SCHEME's relaxation is
+            # relax_jacobi.  A tol Jacobi relaxation with its finishing iterations is NOT faster to a converged field than the
+            # bit-exact default (relax_default): tol is a kernel-throughput mode, and the line shows both.
+            legs = [("relax", args.math, "redblack", 2), ("relax_jacobi", args.math, "jacobi", 2),
                     ("relax_untracked", args.math, args.scheme, 0), ("relax_default", "precise", "redblack", 2)]
             if args.math == "tol" and os.environ.get("EPIC_HIP_TOL_FINISH") is None:
-                legs.append(("relax_tol_alone", args.math, args.scheme, 2))   # without the finishing iterations, for the record
+                legs.append(("relax_tol_alone", args.math, "redblack", 2))   # `relax` without the finishing iterations, for the record
             work = ct.c_double(0.0)
             for key, math, scheme, track in legs:
                 if key == "relax_tol_alone":
@@ -656,7 +823,7 @@ def main():
                             "are the reference's own (precise red-black half-sweeps, from the first check with delta < 10 eps on), "
                             "which is what puts the converged field within the parity bar on every config; relax_tol_alone is the same "
                             "leg with EPIC_HIP_TOL_FINISH=0"}
-                if key in ("relax", "relax_default"):
+                if key in ("relax", "relax_jacobi", "relax_default"):
                     relaxed[key] = h.u_array().ravel().copy()
             assert E.epic_hip_set_math_mode(h, MODES[args.math]) == 0
         abi_release(h)
@@ -669,23 +836,11 @@ def main():
             out.setdefault("kernels", {})["precise"] = {"launch_us": round(pl, 3), "frac": round(BYTES_PER_CELL_SWEEP * cells_per_launch / (pl * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
                                           "note": "default math mode of the library: expf/logf bit-identical to glibc, f64; same grid, scheme and run"}
         if not args.no_extra_legs:
-            # BASELINE configs[4]: 3-D 512^3, 7-point, same arithmetic, on a developed field (1500 of the ~3800 sweeps the
-            # relaxation takes), tracking off; 8 algorithmic bytes per cell per sweep as in 2-D
-            g3 = [512, 512, 512]
-            u3, l3 = synthetic_grid(g3)
-            h3, _ = abi_setup(g3, u3, l3, args.math, "jacobi", False)
-            ms3 = ct.c_float(0.0)
-            assert E.epic_hip_update_n_gpu(h3, 1500, 0) == 0
-            assert E.epic_hip_timed_sweeps_gpu(h3, 100, 100, ct.byref(ms3)) == 0
-            assert E.epic_hip_timed_sweeps_gpu(h3, 300, 100, ct.byref(ms3)) == 0
-            abi_release(h3)
-            us3 = ms3.value * 1e3 / 300
-            out["config5"] = {"workload": "synthetic 512x512x512, 5% obstacles + 1 goal, 7-point log-space Jacobi (BASELINE configs[4])",
-                              "math": args.math, "us_per_sweep": round(us3, 2),
-                              "Mcell_updates_per_s": round(int((l3 == 0).sum()) / us3, 1),
-                              "frac": round(BYTES_PER_CELL_SWEEP * 512 ** 3 / (us3 * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
-                              "kernel": "sweep3d_pair_kernel" if args.math == "tol" and os.environ.get("EPIC_HIP_3D_PAIR", "1")[:1] != "0" else "sweep3d_kernel", "developed_sweeps": 1600, "sweeps": 300}
-            del u3, l3
+            out["config5"] = config5_leg()
+        if not args.no_extra_legs and not args.no_config4:
+            out["config4"] = config4_leg()
+        if not args.no_maps:
+            out["maps"] = maps_leg()
         if not args.no_parity:
             out["parity"] = parity_object(args, E, MODES, relaxed, locked)
         if not args.no_cpu:
