@@ -683,14 +683,27 @@ def main():
         h = None
         try:
             devlist = os.environ.get("EPIC_BENCH_DEVLIST") or ",".join(str(d) for d in range(nd))   # (rehearsal on one GPU: "0,0,0,0")
+            if not os.environ.get("EPIC_BENCH_DEVLIST") and E.epic_hip_device_count() < nd:
+                print(json.dumps({"error": "%d devices asked for, %d visible to this process" % (nd, E.epic_hip_device_count())}), flush=True)
+                return
             h, _ = abi_setup(grid, u0, locked, args.math, "jacobi", False, devlist)
             dev = (ct.c_int * 64)()
             nsl = E.epic_hip_device_layout(h, 64, dev, None, None, None)
+            # BEFORE any timing: what the library decided per seam (peer access asked for and granted? transport; link type and
+            # hops as the runtime reports them) and how one exchange iteration actually ran under timing events -- did the
+            # second stream's bands and copies overlap the interior sweep?  (include/epic_hip.h: epic_hip_multi_report)
+            assert E.epic_hip_update_n_gpu(h, 200, 0) == 0    # a front that has left the goal's slab
+            rep = ct.create_string_buffer(1 << 16)
+            nrep = E.epic_hip_multi_report(h, rep, len(rep))
+            try:
+                res["report"] = json.loads(rep.value.decode()) if nrep > 0 else {"error": "epic_hip_multi_report returned 0 (not in multi-device mode)"}
+            except ValueError as exc:
+                res["report"] = {"error": repr(exc)}
             steps = max(2, args.steps // 2)
             iw, ims = abi_timed(h, steps, 1)
             isw = steps * args.stagger
-            res = {"devices": [dev[i] for i in range(min(nsl, 64))], "slabs": nsl, "value": round(free_cells * isw / iw / 1e6, 1),
-                   "unit": "Mcell-updates/s", "us_per_sweep": round(ims * 1e3 / isw, 3)}
+            res.update({"devices": [dev[i] for i in range(min(nsl, 64))], "slabs": nsl, "value": round(free_cells * isw / iw / 1e6, 1),
+                        "unit": "Mcell-updates/s", "us_per_sweep": round(ims * 1e3 / isw, 3)})
             # and the whole relaxation as the unchanged plugin gets it on this node: library defaults (precise, red-black,
             # work lists per slab)
             assert E.harmonic_uninitialize_gpu(h) == 0
@@ -862,6 +875,9 @@ def main():
         for _ in range(develop):
             solver.sweep(False)
         pair_rows = solver.tune_pairs() if develop >= min(grid) // 2 else 0   # on a developed field, as the library does
+        probe = solver.probe_exchange()   # BEFORE any timing: did the second stream's exchange overlap the interior sweep?
+        while solver.iteration % args.stagger:   # (back to a step boundary: a step = one check + stagger - 1 plain iterations)
+            solver.sweep(False)
         for _ in range(warmup):
             solver.timed_step()
         barrier()
@@ -878,7 +894,7 @@ def main():
             free = int(f[0])
         rows_local = solver.hi - solver.lo
         res = dict(wall=wall, dev_ms=dev_ms, free=free, halo=solver.halo, rows_local=rows_local,
-                   pairs=bool(getattr(solver.backend, "pairs", False)), pair_rows=int(pair_rows))
+                   pairs=bool(getattr(solver.backend, "pairs", False)), pair_rows=int(pair_rows), probe=probe)
         del solver
         torch.cuda.empty_cache()
         return res
@@ -915,9 +931,19 @@ def main():
                                "(HIP events on the compute stream; includes ghost rows, halo exchange waits and check iterations)")
     if world > 1:
         seen = [None] * world
+        # per rank: its device, whether it may address its neighbours' devices directly (what RCCL's P2P transport needs; with one
+        # process per GPU this is the runtime's answer for the two device ordinals, both visible to every rank of the node), and
+        # the probed exchange of the headline run (taken before its timed region)
+        peers = {}
+        for nb in (rank - 1, rank + 1):
+            if 0 <= nb < world and backend == "nccl" and nb < ndev:
+                try:
+                    peers[str(nb)] = bool(torch.cuda.can_device_access_peer(local, nb))
+                except Exception as exc:   # evidence only
+                    peers[str(nb)] = repr(exc)
         dist.all_gather_object(seen, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device": local,
                                       "device_name": torch.cuda.get_device_name(local), "devices_visible": ndev,
-                                      "pid": os.getpid()})
+                                      "pid": os.getpid(), "can_access_neighbour_device": peers, "exchange_probe": r.get("probe")})
         out["ranks"] = {"ranks_seen": dist.get_world_size(), "backend": actual_backend, "per_rank": seen}
         if not args.no_extra_legs:
             other_grid = [n, n] if weak_first else [n * world, n]

@@ -23,6 +23,7 @@
 #include <condition_variable>
 #include <functional>
 #include <map>
+#include <string>
 #include <thread>
 #include <vector>
 #include <mutex>
@@ -179,6 +180,10 @@ struct Ctx {
         int top() const { return lo - g_top; }           // global row of local row 0
     };
     std::vector<Slab> slabs;
+    // epic_hip_multi_report: timing events of ONE exchange iteration per slab (interior sweep on the compute stream; boundary
+    // bands + halo copies on the second stream), recorded only while a probe is armed
+    struct Probe { hipEvent_t int0 = nullptr, int1 = nullptr, cp0 = nullptr, cp1 = nullptr; };
+    std::vector<Probe> probe;      // empty: not armed
     bool plan_failed = false;      // multi_plan: the slabs of a usable device list could not be given their streams / events / pinned buffers
     int slab_n = 0;                // dimensionality the slabs were laid out for
     Crew *crew = nullptr;          // one issuing thread per slab (null: the caller's thread issues everything)
@@ -1304,11 +1309,15 @@ hipError_t multi_run(Ctx *c, unsigned count, unsigned first, bool check_first)
             }
             const int top_hi = sl.g_top ? sl.first() + G : sl.first();
             const int bot_lo = sl.g_bot ? sl.last() + 1 - G : sl.last() + 1;
+            const Ctx::Probe *pr = c->probe.empty() ? nullptr : &c->probe[k];
             if (fail(hipEventRecord(sl.ev_prev, sl.stream)) || fail(hipStreamWaitEvent(sl.comm, sl.ev_prev, 0))) return e;
+            if (pr && fail(hipEventRecord(pr->cp0, sl.comm))) return e;    // second stream: bands, then the incoming copies (step 2)
             if (sl.g_top && fail(slab_launch(c, sl, sl.first(), top_hi, d, -1, -1, it, sl.comm, nullptr))) return e;
             if (sl.g_bot && fail(slab_launch(c, sl, bot_lo, sl.last() + 1, d, -1, -1, it, sl.comm, nullptr))) return e;
             if (fail(hipEventRecord(sl.ev_band, sl.comm))) return e;
+            if (pr && fail(hipEventRecord(pr->int0, sl.stream))) return e;
             if (fail(slab_launch(c, sl, top_hi, bot_lo, d, -1, -1, it, sl.stream, nullptr))) return e;
+            if (pr && fail(hipEventRecord(pr->int1, sl.stream))) return e;
             return e;
         });
         if (e != hipSuccess) return e;
@@ -1328,6 +1337,7 @@ hipError_t multi_run(Ctx *c, unsigned count, unsigned first, bool check_first)
             }
             if (e == hipSuccess) e = hipSetDevice(sl.dev);
             if (e == hipSuccess) e = hipEventRecord(sl.ev_comm, sl.comm);
+            if (e == hipSuccess && !c->probe.empty() && !tracked) e = hipEventRecord(c->probe[k].cp1, sl.comm);
             return e;
         });
         if (e != hipSuccess) return e;
@@ -2425,6 +2435,82 @@ int epic_hip_get_layout(Harmonic *harmonic, unsigned int *pitch, size_t *u_bytes
 
 // Which device holds which rows (multi-device mode: one entry per slab; otherwise one entry, the whole grid on the current
 // device).  Returns the number of slabs; fills at most `cap` entries of each non-null array.
+// What the multi-device mode decided and how one exchange iteration actually ran, as one JSON object in `buf` (the first run on
+// real hardware cannot be rehearsed, so it reports on itself): per seam the two devices, what hipDeviceCanAccessPeer says in
+// both directions, whether peer access was enabled (transport "peer" / "staged" / "same-device"), link type and hop count where
+// the runtime reports them; then ONE untracked exchange iteration with timing events -- per slab the interior sweep on the
+// compute stream and the boundary bands + incoming halo copies on the second stream, in microseconds from the moment the
+// earlier of the two starts: overlap_us = the time both were running, copies_hidden = the copies ended before the interior sweep
+// did.  Advances currentIteration by up to `halo`
+// iterations (a whole stretch up to and including an exchange).  Returns the bytes written (0: not in multi-device mode).
+int epic_hip_multi_report(Harmonic *harmonic, char *buf, size_t cap)
+{
+    Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
+    if (!c || !buf || cap < 64 || !c->multi() || !ready(harmonic, c)) return 0;
+    std::string out = "{";
+    auto add = [&](const char *fmt, auto... a) { char t[256]; snprintf(t, sizeof t, fmt, a...); out += t; };
+    add("\"slabs\": %d, \"halo\": %d, \"issuing_threads\": %s, \"seams\": [", (int)c->slabs.size(), c->halo,
+        c->crew && !c->crew->threads.empty() ? "true" : "false");
+    DeviceGuard g;
+    for (size_t k = 1; k < c->slabs.size(); k++) {
+        const Ctx::Slab &up = c->slabs[k - 1], &sl = c->slabs[k];
+        int can_du = -1, can_ud = -1;
+        if (up.dev != sl.dev) {
+            if (hipDeviceCanAccessPeer(&can_du, sl.dev, up.dev) != hipSuccess) { (void)hipGetLastError(); can_du = -1; }
+            if (hipDeviceCanAccessPeer(&can_ud, up.dev, sl.dev) != hipSuccess) { (void)hipGetLastError(); can_ud = -1; }
+        }
+        uint32_t link = 0, hops = 0;
+        const bool have_link = up.dev != sl.dev && hipExtGetLinkTypeAndHopCount(up.dev, sl.dev, &link, &hops) == hipSuccess;
+        if (!have_link) (void)hipGetLastError();
+        add("%s{\"upper_device\": %d, \"lower_device\": %d, \"can_access_peer\": [%d, %d], \"transport\": \"%s\", \"link_type\": %s, \"hops\": %s}",
+            k > 1 ? ", " : "", up.dev, sl.dev, can_ud, can_du, up.dev == sl.dev ? "same-device" : sl.peer_up ? "peer" : "staged",
+            have_link ? std::to_string(link).c_str() : "null", have_link ? std::to_string(hops).c_str() : "null");
+    }
+    out += "], \"link_type_legend\": \"hipExtGetLinkTypeAndHopCount: 1 HyperTransport, 2 QPI, 3 PCIe, 4 InfiniBand, 5 xGMI\", \"exchange\": [";
+    // one stretch ending with an exchange, untracked, with the probe armed
+    const bool track0 = c->track;
+    c->track = false;
+    multi_sync(c);
+    c->probe.assign(c->slabs.size(), Ctx::Probe{});
+    bool ok = true;
+    for (size_t k = 0; k < c->slabs.size() && ok; k++) {
+        ok = hipSetDevice(c->slabs[k].dev) == hipSuccess && hipEventCreate(&c->probe[k].int0) == hipSuccess && hipEventCreate(&c->probe[k].int1) == hipSuccess &&
+             hipEventCreate(&c->probe[k].cp0) == hipSuccess && hipEventCreate(&c->probe[k].cp1) == hipSuccess;
+    }
+    const unsigned n = (unsigned)std::max(1, c->halo - c->since);
+    if (ok) ok = multi_run(c, n, harmonic->currentIteration, false) == hipSuccess;
+    if (ok) {
+        harmonic->currentIteration += n;
+        harmonic->d_u = current_u(c);
+        multi_sync(c);
+        for (size_t k = 0; k < c->slabs.size(); k++) {
+            const Ctx::Probe &p = c->probe[k];
+            float i0 = 0, i1 = 0, c1 = 0;
+            if (hipSetDevice(c->slabs[k].dev) != hipSuccess || hipEventElapsedTime(&i0, p.cp0, p.int0) != hipSuccess ||
+                hipEventElapsedTime(&i1, p.cp0, p.int1) != hipSuccess || hipEventElapsedTime(&c1, p.cp0, p.cp1) != hipSuccess) {
+                (void)hipGetLastError();
+                add("%s{\"slab\": %d, \"error\": \"no timing\"}", k ? ", " : "", (int)k);
+                continue;
+            }
+            // both intervals from the earlier of the two starts (the two streams of a slab start independently)
+            const float base = std::min(0.0f, i0), is = (i0 - base) * 1e3f, ie = (i1 - base) * 1e3f, cs = (0.0f - base) * 1e3f, ce = (c1 - base) * 1e3f;
+            const float both = std::max(0.0f, std::min(ie, ce) - std::max(is, cs));
+            add("%s{\"slab\": %d, \"device\": %d, \"interior_us\": [%.1f, %.1f], \"bands_and_copies_us\": [%.1f, %.1f], \"overlap_us\": %.1f, \"copies_hidden\": %s}",
+                k ? ", " : "", (int)k, c->slabs[k].dev, is, ie, cs, ce, both, ce <= ie ? "true" : "false");
+        }
+    }
+    for (auto &p : c->probe)
+        for (hipEvent_t e : {p.int0, p.int1, p.cp0, p.cp1})
+            if (e) (void)hipEventDestroy(e);
+    c->probe.clear();
+    c->track = track0;
+    force_all(c);
+    out += ok ? "]}" : "], \"error\": \"the probed exchange failed\"}";
+    if (out.size() + 1 > cap) return 0;
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return (int)out.size();
+}
+
 int epic_hip_device_layout(Harmonic *harmonic, int cap, int *devices, unsigned int *row_begin, unsigned int *row_end,
                            unsigned int *ghost_rows)
 {

@@ -140,6 +140,7 @@ _SIGNATURES = {
     "epic_hip_eval_math": (ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_int, ct.c_void_p),
     "epic_hip_get_layout": (_H, _UP, ct.POINTER(ct.c_size_t), ct.POINTER(ct.c_size_t)),
     "epic_hip_device_layout": (_H, ct.c_int, ct.POINTER(ct.c_int), _UP, _UP, _UP),
+    "epic_hip_multi_report": (_H, ct.c_char_p, ct.c_size_t),
     "epic_hip_pack_mask_2d": (ct.c_void_p, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_int, ct.c_int, ct.c_void_p,
                               ct.c_void_p),
     "epic_hip_sweep_2d": (ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_uint,

@@ -346,14 +346,28 @@ class SlabSolver:
                 rows(bot_lo, self.last + 1, d)
 
             if self.cuda:
+                pr = getattr(self, "_probe", None)   # probe_exchange(): timing events around the two concurrent halves
                 self.ev_boundary.record()          # everything the previous sweep wrote is visible after this point
                 with torch.cuda.stream(self.comm_stream):
                     self.comm_stream.wait_event(self.ev_boundary)
+                    if pr:
+                        pr["cp0"].record()
                     boundary_bands()
+                # the interior sweep is ENQUEUED before the exchange is issued: issuing send / recv costs host time (a group of
+                # P2P operations; with gloo it blocks until the rows have gone through the host), and the interior must already be
+                # in its queue by then (round 4: the first probe of this path showed the interior starting 300 us late, behind a
+                # host that was still inside the exchange call)
+                if pr:
+                    pr["int0"].record()
+                rows(top_hi, bot_lo, d)
+                if pr:
+                    pr["int1"].record()
+                with torch.cuda.stream(self.comm_stream):
                     for w in self._exchange(dst):
                         w.wait()                   # stream-ordered for NCCL/RCCL: makes comm_stream wait, not the host
                     self.ev_comm.record()
-                rows(top_hi, bot_lo, d)
+                    if pr:
+                        pr["cp1"].record()
                 torch.cuda.current_stream().wait_event(self.ev_comm)
             else:
                 boundary_bands()
@@ -365,6 +379,30 @@ class SlabSolver:
         if not self.redblack:
             self.cur ^= 1
         self.iteration += 1
+
+    def probe_exchange(self):
+        """One exchange iteration under timing events (GPU, world > 1): the boundary bands + the halo send / recv on the second
+        stream against the interior sweep on the compute stream, in microseconds from the earlier of the two starts -- the
+        N > 1 bench line carries it per rank, so that the first run on real xGMI says whether the overlap the design rests on
+        happened.  Advances the iteration count up to and including the next exchange; returns None where there is nothing to
+        probe."""
+        if not self.cuda or self.world == 1:
+            return None
+        while self.since + 1 < self.halo:       # the plain iterations before the one that ends with an exchange
+            self.sweep(False)
+        self._probe = {k: torch.cuda.Event(enable_timing=True) for k in ("cp0", "cp1", "int0", "int1")}
+        try:
+            self.sweep(False)
+            torch.cuda.synchronize()
+            p = self._probe
+            i0, i1, c1 = p["cp0"].elapsed_time(p["int0"]), p["cp0"].elapsed_time(p["int1"]), p["cp0"].elapsed_time(p["cp1"])
+        finally:
+            self._probe = None
+        base = min(0.0, i0)
+        is_, ie, cs, ce = (i0 - base) * 1e3, (i1 - base) * 1e3, -base * 1e3, (c1 - base) * 1e3
+        return {"interior_us": [round(is_, 1), round(ie, 1)], "bands_and_exchange_us": [round(cs, 1), round(ce, 1)],
+                "overlap_us": round(max(0.0, min(ie, ce) - max(is_, cs)), 1), "exchange_hidden": bool(ce <= ie),
+                "halo_rows": self.halo, "bytes_each_way": int(self.halo * self.pitch * 4)}
 
     PAIR_HEIGHTS = (20, 23, 26, 29, 32, 35, 38, 40, 41, 43, 46, 49, 52, 58, 64, 80, 96, 128)
 

@@ -154,6 +154,14 @@ int epic_hip_eval_math(const float *d_in, float *d_out, size_t n, int which, voi
 int epic_hip_device_layout(EpicHarmonicT *harmonic, int cap, int *devices, unsigned int *row_begin, unsigned int *row_end,
                            unsigned int *ghost_rows);
 
+/* Multi-device mode reporting on itself (the first run on real hardware cannot be rehearsed): one JSON object in buf -- per seam
+ * the two devices, hipDeviceCanAccessPeer in both directions, the transport chosen (peer / staged / same-device), link type and
+ * hops where the runtime reports them; then ONE exchange iteration under timing events: per slab the interior sweep (compute
+ * stream) and the boundary bands + incoming halo copies (second stream), in microseconds from the earlier of the two starts,
+ * the time both were running (overlap_us) and whether the copies ended before the interior did (copies_hidden).  Runs the iterations up to and including the next exchange (currentIteration advances).  Returns the
+ * number of bytes written, 0 when the Harmonic is not in multi-device mode or buf is too small. */
+int epic_hip_multi_report(EpicHarmonicT *harmonic, char *buf, size_t cap);
+
 /* Geometry of the device-resident state: pitch in floats, bytes of one u buffer, bytes of the packed mask. */
 int epic_hip_get_layout(EpicHarmonicT *harmonic, unsigned int *pitch, size_t *u_bytes, size_t *mask_bytes);
 

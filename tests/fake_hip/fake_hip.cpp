@@ -123,6 +123,7 @@ hipError_t hipSetDevice(int dev)
 hipError_t hipDeviceGetAttribute(int *value, hipDeviceAttribute_t, int) { *value = 256; return hipSuccess; }
 hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = 1; return hipSuccess; }
 hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
+hipError_t hipExtGetLinkTypeAndHopCount(int, int, uint32_t *linktype, uint32_t *hops) { *linktype = 5; *hops = 1; return hipSuccess; }
 
 hipError_t hipMalloc(void **p, size_t bytes)
 {

@@ -50,6 +50,7 @@ hipError_t hipSetDevice(int dev);
 hipError_t hipDeviceGetAttribute(int *value, hipDeviceAttribute_t attr, int dev);
 hipError_t hipDeviceCanAccessPeer(int *can, int dev, int peer);
 hipError_t hipDeviceEnablePeerAccess(int peer, unsigned flags);
+hipError_t hipExtGetLinkTypeAndHopCount(int d1, int d2, uint32_t *linktype, uint32_t *hops);
 hipError_t hipMalloc(void **p, size_t bytes);
 hipError_t hipFree(void *p);
 hipError_t hipHostMalloc(void **p, size_t bytes, unsigned flags);

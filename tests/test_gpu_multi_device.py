@@ -343,3 +343,47 @@ def test_redblack_fused_pairs_on_slabs(every_list, m, rpt):
 @pytest.mark.parametrize("m,seed,dens", [g for g in T.FUSED_GRIDS if g[0] in ([257, 513], [1200, 3000])])
 def test_tol_fused_redblack_pairs_on_slabs(every_list, m, seed, dens, monkeypatch):
     T.test_tol_fused_redblack_pairs_equal_the_checker_bit_for_bit(m, seed, dens, 6, monkeypatch)
+
+
+def test_multi_report_describes_the_seams_and_times_one_exchange(devices):
+    """epic_hip_multi_report (include/epic_hip.h): the mode reporting on itself -- seams, transport, one exchange iteration under
+    timing events -- and leaving the relaxation bit-identical to one that was never probed (it advances by whole iterations)."""
+    import json
+
+    m = [2048, 1100]
+    u0, locked = P.synthetic_grid(m, 9, 0.05)
+    h = P.make(m, u0, locked)
+    P.gpu_init(h)
+    assert E.epic_hip_set_math_mode(h, eh.MATH_TOL) == 0
+    assert E.epic_hip_update_n_gpu(h, 37, 0) == 0
+    buf = ct.create_string_buffer(1 << 16)
+    n = E.epic_hip_multi_report(h, buf, len(buf))
+    assert n > 0
+    rep = json.loads(buf.value.decode())
+    assert rep["slabs"] == devices and len(rep["seams"]) == devices - 1 and len(rep["exchange"]) == devices
+    for seam in rep["seams"]:
+        assert seam["transport"] in ("same-device", "peer", "staged")
+        if seam["upper_device"] == seam["lower_device"]:
+            assert seam["transport"] == "same-device"
+    for ex in rep["exchange"]:
+        assert ex["interior_us"][1] > ex["interior_us"][0] >= 0.0 and ex["bands_and_copies_us"][1] > ex["bands_and_copies_us"][0] >= 0.0
+        assert min(ex["interior_us"][0], ex["bands_and_copies_us"][0]) == 0.0 and ex["overlap_us"] >= 0.0
+        assert isinstance(ex["copies_hidden"], bool)
+    done = int(h.currentIteration)
+    assert 37 < done <= 37 + rep["halo"]
+    assert E.epic_hip_update_n_gpu(h, 100 - done, 1) in (0, 1)
+    assert E.harmonic_get_potential_values_gpu(h) == 0
+    got, gdelta = h.u_array().ravel().copy(), float(h.delta)
+    P.gpu_fini(h)
+    p = O.Problem(m, u0, locked)
+    assert O.oracle().oracle_tol_run(ct.byref(p.h), 100, 0) == 0
+    assert np.array_equal(got, p.u) and gdelta == float(p.h.delta)
+    # one device: nothing to report
+    del os.environ["EPIC_HIP_DEVICES"]
+    try:
+        h = P.make(m, u0, locked)
+        P.gpu_init(h)
+        assert E.epic_hip_multi_report(h, buf, len(buf)) == 0
+        P.gpu_fini(h)
+    finally:
+        os.environ["EPIC_HIP_DEVICES"] = "0,0"
