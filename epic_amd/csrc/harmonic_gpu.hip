@@ -151,6 +151,13 @@ struct Ctx {
     int track_mode = 2;            // 0 off, 1 on, 2 automatic (on for grids above 4 Mcell): EPIC_HIP_TRACK / epic_hip_set_activity_tracking
     bool track = false;            // the mode resolved for the current dimensions (resolve_tracking)
     Track trk;
+    // Red-black, precise / fast math, 2-D, one device: tracked relaxations run PAIRS of iterations as list-driven fused passes
+    // (rb_fused2d_kernel<.., TRACK>), whose tiles are not the plain sweep's: their own lists.  last_lists says whose lists
+    // describe the field as it is: 0 nobody's (the next tracked launch of either kind runs every tile), 1 the plain sweep's,
+    // 2 the fused pass's.
+    Track trk_f;
+    int last_lists = 0;
+    int pair_rows = 0;             // task height of the tracked pass in use (0: not chosen yet); see rb_pairs_choose_rows
     static constexpr size_t kL = Track::kL, kCS = Track::kCS;
     // Work accounting (epic_hip_work_done): whole-grid iterations' worth of cells recomputed since the last reset.  Launches
     // that run every tile count 1 (a fused pass 2) on the host; list-driven launches add their tile counts on the device.
@@ -252,7 +259,7 @@ bool dims_into_ctx(const Harmonic *h, Ctx *c)
     const int rows0 = c->rows, cols0 = c->cols, n0 = c->n;
     if (!dims_from(h, c)) return false;
     // the measured task heights belong to ONE grid (the context survives a re-initialisation with other dimensions)
-    if (c->rows != rows0 || c->cols != cols0 || c->n != n0) c->tuned_rows[0] = c->tuned_rows[1] = c->tuned_rows[2] = 0;
+    if (c->rows != rows0 || c->cols != cols0 || c->n != n0) c->tuned_rows[0] = c->tuned_rows[1] = c->tuned_rows[2] = c->pair_rows = 0;
     if (!c->devices.empty()) multi_plan(c);
     return true;
 }
@@ -346,6 +353,7 @@ void drop_ctx_if_empty(Harmonic *h)
     drop_graphs(c);
     if (c->multi()) multi_destroy(c);
     c->trk.release();
+    c->trk_f.release();
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->h_delta) (void)hipHostFree(c->h_delta);
     if (c->h_tile_delta) (void)hipHostFree(c->h_tile_delta);
@@ -419,7 +427,9 @@ hipError_t enqueue_sweep(Ctx *c, bool check, unsigned iteration)
             drop_graphs(c);       // captured sequences hold the old lists (never reached during a capture: force > 0)
             fold_listed_work(c);  // the sum kept in the old block
         }
+        if (c->last_lists == 2) c->trk.force = std::max(c->trk.force, 1);   // fused passes have run since these lists were made
         act = c->trk.next(tiles, rpt, c->stream, nullptr);
+        c->last_lists = act.list_out ? 1 : 0;
     }
     if (!act.list_in) c->work_full += 1.0;  // every tile runs (untracked, or a forced iteration of a tracked run)
     auto advance = [&](hipError_t e) {
@@ -460,6 +470,7 @@ void fold_listed_work(Ctx *c)
     };
     if (!c->multi()) {
         fold(c->trk, c->stream, 1.0);
+        fold(c->trk_f, c->stream, 2.0);   // a listed tile of a fused pass is recomputed twice
         return;
     }
     DeviceGuard g;
@@ -681,6 +692,74 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first, bool check_
     for (; i < count; i++) {
         hipError_t e = enqueue_sweep(c, false, first + i);
         if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// Tracked red-black relaxations with the precise / fast math on one device (2-D, from 4 Mcell up -- EPIC_HIP_FUSE_MIN_CELLS): the
+// iterations between two checks AND the check run as pairs, each one list-driven fused pass (kernels_2d.hip: rb_fused2d_kernel
+// with TRACK; the check is the second iteration of the last pair).  Against in-place half-sweeps with lists: half the launches
+// (10-12 us each with next to nothing due, a quarter of all iterations of the 8192^2 relaxation), and a listed tile moves through
+// HBM once for two iterations instead of twice.  EPIC_HIP_TRACK_PAIRS=0: the half-sweeps, as before round 4.
+bool rb_pairs_tracked(const Ctx *c)
+{
+    if (!c->track || !c->redblack || c->n != 2 || c->multi() || c->math == 4 || c->math == 2) return false;
+    if (getenv("EPIC_HIP_NO_FUSE") != nullptr) return false;
+    const char *e = getenv("EPIC_HIP_TRACK_PAIRS");
+    if (e && e[0] == '0') return false;
+    e = getenv("EPIC_HIP_FUSE_MIN_CELLS");
+    return (long long)c->rows * c->pitch >= (e ? atoll(e) : (1ll << 22));
+}
+// rows per task of the tracked pass: the unit of skipping, and every task recomputes the first colour of one row above and one
+// below its chunk (2 / rows extra arithmetic).  EPIC_HIP_TRACK_PAIR_ROWS overrides.
+int rb_pairs_rows_per_task(const Ctx *c)
+{
+    const char *e = getenv("EPIC_HIP_TRACK_PAIR_ROWS");
+    if (e && atoi(e) > 0) return std::max(atoi(e), 2);
+    if (c->rows_per_task > 0) return std::max(c->rows_per_task, 2);
+    return c->pair_rows > 0 ? c->pair_rows : 16;
+}
+// Two task heights.  While a good part of the grid is active the tall tasks (16 rows: 2 extra first-colour rows per task, 12 %)
+// are right.  With next to nothing due a pass costs the march of ONE task by a wave that is alone on its SIMD -- ~1.4 us per
+// row, 26 us per pass at 16 rows (measured: profiles/r04_experiments.txt) -- and the tail of a relaxation is thousands of such
+// passes: there 4 rows per task make the pass three times shorter, and recomputing 1.5 x the few cells that are due costs
+// nothing.  Changing the height means new lists: the next pass runs every tile once (~0.2 ms), so the decision is taken at a
+// check, from the share of tiles that check listed, with a wide hysteresis.
+void rb_pairs_choose_rows(Ctx *c)
+{
+    if (getenv("EPIC_HIP_TRACK_PAIR_ROWS") != nullptr || c->rows_per_task > 0) return;
+    if (c->pair_rows == 0) c->pair_rows = 16;
+    if (c->last_lists != 2) return;
+    unsigned long long due = 0, tiles = 0;
+    if (!due_tiles(c, &due, &tiles, false) || tiles == 0) return;
+    const double share = (double)due / (double)tiles;
+    if (c->pair_rows == 16 && share < 0.04) c->pair_rows = 4;
+    else if (c->pair_rows == 4 && share > 0.20) c->pair_rows = 16;
+}
+// `npairs` pairs of iterations starting at iteration `first`; check_last: the second iteration of the last pair is a check (the
+// device delta word is zeroed and filled).  bypass: without the lists (every tile; the untracked pass's own task height).
+hipError_t enqueue_rb_pairs_tracked(Ctx *c, unsigned npairs, unsigned first, bool check_last, bool bypass)
+{
+    const int rpt = bypass ? fused_rows_per_task(c) : rb_pairs_rows_per_task(c);
+    const size_t tiles = epic_hip::rb_fused_2d_tiles(c->rows, c->pitch, rpt);
+    for (unsigned p = 0; p < npairs; ++p) {
+        const bool check = check_last && p + 1 == npairs;
+        hipError_t e;
+        if (check && (e = hipMemsetAsync(c->d_delta, 0, sizeof(unsigned), c->stream)) != hipSuccess) return e;
+        epic_hip::Activity act = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (!bypass) {
+            if (tiles != c->trk_f.tiles || rpt != c->trk_f.rpt) fold_listed_work(c);   // the sum kept in the old block
+            if (c->last_lists != 2) c->trk_f.force = std::max(c->trk_f.force, 1);     // something else has touched the field since
+            act = c->trk_f.next(tiles, rpt, c->stream, nullptr);
+        }
+        e = epic_hip::launch_rb_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch, rpt, c->math,
+                                         (int)((first + 2 * p) & 1u), c->stream, c->maskf(), act.list_out ? &act : nullptr,
+                                         check ? c->d_delta : nullptr);
+        if (e != hipSuccess) return e;
+        if (!act.list_in) c->work_full += 2.0;   // every tile ran
+        if (act.list_out) { c->trk_f.advance(); c->last_lists = 2; }
+        else c->last_lists = 0;
+        c->cur ^= 1;
     }
     return hipSuccess;
 }
@@ -1451,6 +1530,8 @@ int multi_set_cells(Ctx *c, unsigned k, const unsigned *v, const unsigned *types
 void force_all(Ctx *c)
 {
     c->trk.force = 2;
+    c->trk_f.force = std::max(c->trk_f.force, 1);   // (one pass of two iterations, in -> out, rewrites every tile of the other buffer)
+    c->last_lists = 0;
     for (auto &sl : c->slabs) sl.trk.force = 2;
 }
 
@@ -1473,7 +1554,7 @@ bool due_tiles(Ctx *c, unsigned long long *due, unsigned long long *tiles, bool 
         *tiles += t.tiles;
         return true;
     };
-    if (!c->multi()) return one(c->trk);
+    if (!c->multi()) return one(c->last_lists == 2 ? c->trk_f : c->trk);
     DeviceGuard g;
     for (auto &sl : c->slabs)
         if (hipSetDevice(sl.dev) != hipSuccess || hipStreamSynchronize(sl.stream) != hipSuccess || !one(sl.trk)) return false;
@@ -1840,10 +1921,11 @@ int harmonic_get_potential_values_gpu(Harmonic *harmonic)  // harmonic_gpu.cu:41
 }
 
 // harmonic_execute_gpu: should the plain batch that follows a check run without the work lists?  (see the call site)
-static bool bypass_lists_for_batch(Ctx *c)
+static bool bypass_lists_for_batch(Ctx *c, bool pairs = false)
 {
     // (a forced iteration runs every tile but still lists the tiles it changed)
     if (!c->track || c->track_mode != 2 || c->n != 2) return false;
+    if (pairs && c->last_lists != 2) return false;   // no lists of the fused tiling yet: the next pass runs every tile and makes them
     const char *e = getenv("EPIC_HIP_TRACK_SWITCH");   // share of due tiles above which lists are bypassed (tests: 0 / 2)
     // The break-even share is where a list-driven iteration costs what an iteration of the untracked path costs -- and that path
     // differs: fused pairs for everything but precise Jacobi, and a red-black pair recomputes each cell once where two list-driven
@@ -1852,7 +1934,9 @@ static bool bypass_lists_for_batch(Ctx *c)
     //   tol red-black      2.02 / 2.02 / 2.11 / 2.14 / 2.24 / 2.45        precise red-black   2.57 / 2.51 / 2.49 / 2.49 / 2.57 / 2.75
     //   tol Jacobi           -  / 2.53 / 2.49 / 2.48 / 2.51 / 2.61        precise Jacobi        -  / 4.08 / 3.94 / 3.82 / 3.74 / 3.73
     const bool tol = c->math == 4;
-    const double rule = c->redblack ? (tol ? 0.45 : 0.6) : (tol ? 0.7 : 0.85);
+    // (tracked PAIRS, round 4: a list-driven fused pass costs what the untracked one costs plus the lists and the shorter tasks'
+    //  extra rows -- the lists only lose where nearly every tile is due)
+    const double rule = pairs ? 0.85 : c->redblack ? (tol ? 0.45 : 0.6) : (tol ? 0.7 : 0.85);
     const double limit = e ? atof(e) : rule;
     // the counter sets the next launches would consume were filled by the check iteration that has just been read back
     unsigned long long due = 0, tiles = 0;
@@ -1974,6 +2058,35 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
                 report(fn, "Failed to perform the Jacobi update and check step.");
                 return result;
             }
+            after_check();
+        } else if (rb_pairs_tracked(c) && has_delta(c)) {
+            // Tracked red-black with the precise math on a large grid (the library's defaults at the benchmark's size): the plain
+            // iterations up to the next check AND that check as PAIRS, each one list-driven fused pass; the check is the second
+            // iteration of the last pair (an odd count starts with one plain half-sweep).  Same iterations, same order, same bits.
+            const unsigned batch = stagger - harmonic->currentIteration % stagger;
+            const unsigned total = batch + 1;
+            unsigned done = 0;
+            hipError_t pe = hipSuccess;
+            if (total & 1u) {
+                pe = enqueue_sweep(c, false, harmonic->currentIteration);
+                done = 1;
+            }
+            if (pe == hipSuccess) {
+                rb_pairs_choose_rows(c);
+                const bool bypass = bypass_lists_for_batch(c, true);
+                if (bypass) tune_fused_rows(c, 2, harmonic->currentIteration);   // the untracked pass's task height, measured once per grid
+                pe = enqueue_rb_pairs_tracked(c, (total - done) / 2, harmonic->currentIteration + done, true, bypass);
+            }
+            if (pe != hipSuccess) {
+                report(fn, "Failed to perform the Jacobi update step.");
+                return EPIC_ERROR_KERNEL_EXECUTION;
+            }
+            harmonic->d_u = current_u(c);
+            harmonic->currentIteration += batch;
+            result = read_delta(harmonic, c, fn);
+            if (result != EPIC_SUCCESS) return result;
+            harmonic->currentIteration++;
+            result = harmonic->delta < harmonic->epsilon ? EPIC_SUCCESS_AND_CONVERGED : EPIC_SUCCESS;
             after_check();
         } else if (tile_checks(c, tile_plan(c))) {
             // Small grids (kernels_tile2d.hip): the plain iterations up to the next check AND that check are one sequence of tile

@@ -56,8 +56,15 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, i
 // Wake tiles [t_lo, t_hi) for the launch that will consume the lists given as next_as_out->list_out / count_out / queued_out.
 hipError_t launch_wake_tile_range(const Activity *next_as_out, size_t tiles, int t_lo, int t_hi, hipStream_t stream);
 // two red-black iterations fused into one in -> out pass (first colour = parity); see kernels_2d.hip
+// act (may be null): work lists of THIS pass's tiling, rb_fused_2d_tiles() tiles; delta_bits (may be null): max |du| of the second
+// of the two iterations (zero it first).
 hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
-                              int math, int parity, hipStream_t stream, const uint32_t *maskf = nullptr);
+                              int math, int parity, hipStream_t stream, const uint32_t *maskf = nullptr, const Activity *act = nullptr,
+                              unsigned *delta_bits = nullptr);
+inline size_t rb_fused_2d_tiles(int rows, int pitch, int rows_per_task)
+{
+    return (size_t)((pitch + 247) / 248) * (size_t)((rows + rows_per_task - 1) / rows_per_task);
+}
 // Two iterations in one pass (tol math only): in = u_k, out = u_{k+2}; in != out.  parity < 0: Jacobi; 0 / 1: the reference's
 // red-black scheme, parity = the first iteration's number & 1 (both colours are swept, the first one first).
 // maskf (may be null): the masks in the fused layout below -- saves the pass a funnel shift of two mask words per row.

@@ -446,7 +446,16 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (SweepOcc<CHECK, MATH, RB, 
 // (and, with the precise math, to two iterations of the reference CPU solver).
 constexpr int kFusedOut = 248;  // owned columns per wave
 
-template <int MATH, bool FMASK>
+// TRACK (round 4): the pass with work lists, as the plain sweep has them (wake.h) -- a tile is one task of THIS kernel
+// (rows_per_task rows x 248 owned columns); it runs in a pass only if the previous pass changed a value it reads, and two
+// iterations reach two cells far: its own cells, the two nearest rows of the tiles above and below, the two nearest columns
+// of the tiles left and right, and the one corner cell of each diagonal neighbour.  A tile that is skipped holds, in BOTH
+// buffers, the values the pass would have written (it did not change in the previous pass, and nothing it reads did).  The
+// lists of this tiling are separate from the plain sweep's (different tiles): harmonic_gpu.hip runs every tile in the first
+// pass after anything else has touched the field.
+// CHECK: max |du| of the SECOND iteration of the pass (the one a check iteration is when the host makes it the last of a
+// batch): |level B - level A| over the cells level B recomputes, owned lanes only.
+template <int MATH, bool FMASK, bool TRACK, bool CHECK>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Sweep2dArgs a)
 {
     __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];
@@ -454,8 +463,30 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
     if (MATH == kMathPrecise) lds = math_tables_load(math_lds);
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int task = xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
-    if (task >= a.ntasks) return;
+    if (TRACK) wake_reset_next(a.wake);
+    const bool listed = TRACK && a.wake.list_in != nullptr;
+    WakeCursor cursor = {};
+    if (listed && !wake_begin(a.wake, lane, wave, kWavesPerBlock, cursor)) return;
+    float dmax = 0.0f;
+    const int rlast = a.rows - 1;
+    const size_t pitch = (size_t)a.pitch;
+    const int it = a.parity;  // colour A = cells with (row + col + it) odd; col is even for .x
+    typedef unsigned vu4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) uint64_t cu64;
+    const int nstd = a.pitch >> 8;
+
+    int vb = blockIdx.x;
+    for (;;) {  // one pass per task: exactly one unless the launch is list-driven
+    int task;
+    if (listed) task = wake_tile(a.wake, cursor);
+    else task = xcd_contiguous_block(vb, a.nblocks) * kWavesPerBlock + wave;
+    if (task >= a.ntasks) {
+        if (listed) break;
+        vb += gridDim.x;
+        if (vb >= a.nblocks) break;
+        continue;
+    }
+    if (TRACK && lane == 0) a.wake.queued_in[task] = 0;
     const int strip = task % a.nstrips;
     const int chunk = task / a.nstrips;
     const int r0 = a.row_begin + chunk * a.rows_per_task;
@@ -463,10 +494,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
     const int col = strip * kFusedOut - kColsPerLane + lane * kColsPerLane;  // lane 0 = left halo lane
     const int lcol = min(max(col, 0), a.pitch - kColsPerLane);
     const bool owner = lane >= 1 && lane <= kWave - 2 && col < a.pitch;
-    const int rlast = a.rows - 1;
-    const size_t pitch = (size_t)a.pitch;
-    const int it = a.parity;  // colour A = cells with (row + col + it) odd; col is even for .x
-    typedef unsigned vu4 __attribute__((ext_vector_type(4)));
+    const lmask owners = (TRACK || CHECK) ? __builtin_amdgcn_ballot_w64(owner) : 0;
 
     // rows through buffer descriptors with scalar row offsets, as in the plain sweep (no VALU address arithmetic)
     const int rlo = max(r0 - 2, 0);  // rows r0 - 2 .. r1 + 2 are touched
@@ -492,10 +520,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
     // is stored or reaches an unlocked cell.
     // In two phases, as in tol_fused_pass below: the words are FETCHED a step before they are CUT (no scalar-memory round trip
     // in the middle of a step); FMASK: the library's second copy of the masks, already cut for this mapping (kernels.h).
-    typedef const __attribute__((address_space(4))) uint64_t cu64;
     struct RowMask { lmask m0, m1, m2, m3; };
     struct RowMaskRaw { lmask lo0, lo1, lo2, lo3, hi0, hi1, hi2, hi3; };
-    const int nstd = a.pitch >> 8;
     const int g0 = strip * (kFusedOut / kColsPerLane) - 1;
     const int sw = max(g0, 0) >> 6, sh = max(g0, 0) & 63, sw1 = min(sw + 1, nstd - 1);
     auto mask_fetch = [&](int r) -> RowMaskRaw {
@@ -516,22 +542,45 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
         return RowMask{cut(w.lo0, w.hi0), cut(w.lo1, w.hi1), cut(w.lo2, w.hi2), cut(w.lo3, w.hi3)};
     };
     auto row_mask = [&](int r) -> RowMask { return mask_cut(mask_fetch(r)); };
+    // what this task changed, as the tiles around it need to know it (TRACK): lane masks and flags in scalar registers
+    lmask chg_any = 0, chg_top = 0, chg_bot = 0;
+    bool chg_left = false, chg_right = false, c_tl = false, c_tr = false, c_bl = false, c_br = false;
+    constexpr lmask kFirstOwned = 2ull, kLastOwned = 1ull << (kWave - 2);   // lanes 1 and 62
     // One colour of one row.  second = false: colour A (iteration it), true: colour B (iteration it + 1).
-    auto stage = [&](int r, bool second, const float4 &up, const float4 &c, const float4 &dn, const RowMask &k) -> float4 {
+    // owned: the row belongs to this task (level A is also computed for the row above and the row below the chunk).
+    auto stage = [&](int r, bool second, bool owned, const float4 &up, const float4 &c, const float4 &dn, const RowMask &k) -> float4 {
         float4 o = c;
         const bool odd_cols = ((((r + it) & 1) == 0) != second);  // scalar
+        lmask e0 = 0, e1 = 0;   // lanes whose first / second recomputed cell changed its bits
         if (odd_cols) {
             const float rt = wave_from_right(c.x, 0.0f);
             const float ny = cell_update_2d<MATH>(up.y, dn.y, c.x, c.z, lds);
             const float nw = cell_update_2d<MATH>(up.w, dn.w, c.z, rt, lds);
             o.y = sel(k.m1, c.y, ny);
             o.w = sel(k.m3, c.w, nw);
+            if (TRACK) { e0 = lanes_ne(o.y, c.y); e1 = lanes_ne(o.w, c.w); }
+            if (CHECK && second) dmax = max2(dmax, sel(owners, max2(fabsf(c.y - o.y), fabsf(c.w - o.w)), 0.0f));
         } else {
             const float lf = wave_from_left(c.w, 0.0f);
             const float nx = cell_update_2d<MATH>(up.x, dn.x, lf, c.y, lds);
             const float nz = cell_update_2d<MATH>(up.z, dn.z, c.y, c.w, lds);
             o.x = sel(k.m0, c.x, nx);
             o.z = sel(k.m2, c.z, nz);
+            if (TRACK) { e0 = lanes_ne(o.x, c.x); e1 = lanes_ne(o.z, c.z); }
+            if (CHECK && second) dmax = max2(dmax, sel(owners, max2(fabsf(c.x - o.x), fabsf(c.z - o.z)), 0.0f));
+        }
+        if (TRACK && owned) {   // (scalar throughout)
+            const lmask rc = (e0 | e1) & owners;
+            chg_any |= rc;
+            if (r < r0 + 2) chg_top |= rc;
+            if (r >= r1 - 2) chg_bot |= rc;
+            // the two owned columns next to the left neighbour are lane 1's x and y (e0 in either case), next to the right one
+            // lane 62's z and w (e1); the corner cells are lane 1's x (even columns) and lane 62's w (odd columns)
+            const bool l = (e0 & kFirstOwned) != 0, rr = (e1 & kLastOwned & owners) != 0;
+            chg_left |= l;
+            chg_right |= rr;
+            if (r == r0) { c_tl |= l && !odd_cols; c_tr |= rr && odd_cols; }
+            if (r == r1 - 1) { c_bl |= l && !odd_cols; c_br |= rr && odd_cols; }
         }
         return o;
     };
@@ -540,15 +589,15 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
     const float4 om2 = ld(r0 - 2), om1 = ld(r0 - 1), o0 = ld(r0);
     float4 oa = ld(r0 + 1), ob = ld(r0 + 2), oc;  // old rows r+1, r+2, r+3
     RowMask kcur = row_mask(r0), knext = row_mask(r0 + 1);
-    float4 ma = stage(r0 - 1, false, om2, om1, o0, row_mask(r0 - 1)), mb = stage(r0, false, om1, o0, oa, kcur), mc;
+    float4 ma = stage(r0 - 1, false, false, om2, om1, o0, row_mask(r0 - 1)), mb = stage(r0, false, true, om1, o0, oa, kcur), mc;
     // One row r: `mp`, `mq` = colour A of rows r-1, r; `o1`, `o2` = old rows r+1, r+2.  Leaves colour A of row r+1 in
     // `mr` and old row r+3 in `o3`.  The three A rows and the three old rows rotate through fixed registers (the loop
     // is unrolled by three), so nothing is moved.
     auto step = [&](int r, const float4 &mp, const float4 &mq, float4 &mr, const float4 &o1, const float4 &o2, float4 &o3) {
         o3 = ld(r + 3);
         const RowMaskRaw kraw = mask_fetch(r + 2);             // cut at the end of the step
-        mr = stage(r + 1, false, mq, o1, o2, knext);           // colour A of row r+1: up = row r (its B cells still old)
-        const float4 x = stage(r, true, mp, mq, mr, kcur);    // colour B of row r from the fresh A cells around it
+        mr = stage(r + 1, false, r + 1 < r1, mq, o1, o2, knext);           // colour A of row r+1: up = row r (its B cells still old)
+        const float4 x = stage(r, true, true, mp, mq, mr, kcur);    // colour B of row r from the fresh A cells around it
         kcur = knext;
         knext = mask_cut(kraw);
         store_row(rout, x.x, x.y, x.z, x.w, store_off, row_off(r));  // non-temporal, as in the plain sweep
@@ -562,6 +611,32 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
     for (; r < r1; ++r) {  // at most two rows
         step(r, ma, mb, mc, oa, ob, oc);
         ma = mb; mb = mc; oa = ob; ob = oc;
+    }
+
+    if (TRACK) {
+        // wake the tiles that read what this task changed: itself, the four across its edges, the four across its corners
+        const bool up_ok = chunk > 0, dn_ok = chunk + 1 < a.nchunks, lf_ok = strip > 0, rt_ok = strip + 1 < a.nstrips;
+        int t = task;
+        bool want = chg_any != 0;                                                        // lane 0: the tile itself
+        if (lane == 1) { t = task - 1; want = lf_ok && chg_left; }
+        if (lane == 2) { t = task + 1; want = rt_ok && chg_right; }
+        if (lane == 3) { t = task - a.nstrips; want = up_ok && chg_top != 0; }
+        if (lane == 4) { t = task + a.nstrips; want = dn_ok && chg_bot != 0; }
+        if (lane == 5) { t = task - a.nstrips - 1; want = up_ok && lf_ok && c_tl; }
+        if (lane == 6) { t = task - a.nstrips + 1; want = up_ok && rt_ok && c_tr; }
+        if (lane == 7) { t = task + a.nstrips - 1; want = dn_ok && lf_ok && c_bl; }
+        if (lane == 8) { t = task + a.nstrips + 1; want = dn_ok && rt_ok && c_br; }
+        wake_push(a.wake, t, want && lane < 9);
+    }
+    if (listed) { if (!wake_next(cursor)) break; }
+    else { vb += gridDim.x; if (vb >= a.nblocks) break; }
+    }  // task loop
+
+    if (CHECK) {
+        dmax = wave_max(dmax);
+        if (lane == 0 && dmax > 0.0f &&
+            __float_as_uint(dmax) > __hip_atomic_load(a.delta_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(a.delta_bits, __float_as_uint(dmax));
     }
 }
 
@@ -984,11 +1059,30 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, i
 }
 
 // Two consecutive red-black iterations (first one = `parity`) in one pass, in -> out (in != out).
+// act (may be null): the work lists of THIS kernel's tiling (tiles = rb_fused_2d_tiles(rows, pitch, rows_per_task)); delta_bits (may
+// be null): max |du| of the SECOND of the two iterations (zero it first).
+namespace {
+template <int MATH>
+void launch_rb_fused_2d_math(const Sweep2dArgs &a, bool fmask, hipStream_t stream)
+{
+    const bool track = a.wake.list_out != nullptr, check = a.delta_bits != nullptr;
+    void (*kernel)(Sweep2dArgs);
+    if (track) kernel = check ? (fmask ? rb_fused2d_kernel<MATH, true, true, true> : rb_fused2d_kernel<MATH, false, true, true>)
+                              : (fmask ? rb_fused2d_kernel<MATH, true, true, false> : rb_fused2d_kernel<MATH, false, true, false>);
+    else kernel = check ? (fmask ? rb_fused2d_kernel<MATH, true, false, true> : rb_fused2d_kernel<MATH, false, false, true>)
+                        : (fmask ? rb_fused2d_kernel<MATH, true, false, false> : rb_fused2d_kernel<MATH, false, false, false>);
+    int nblocks = a.nblocks;
+    if (track && a.wake.list_in) nblocks = sweep_2d_list_blocks((size_t)a.ntasks, resident_blocks_of((const void *)kernel));   // persistent waves
+    hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(kWave * kWavesPerBlock), 0, stream, a);
+}
+}  // namespace
+
 hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
-                              int math, int parity, hipStream_t stream, const uint32_t *maskf)
+                              int math, int parity, hipStream_t stream, const uint32_t *maskf, const Activity *act, unsigned *delta_bits)
 {
     if (pitch <= 0 || (pitch % 256) != 0 || rows <= 0 || rows_per_task <= 0 || in == out) return hipErrorInvalidValue;
     if (math != kMathPrecise && math != kMathFast && math != kMathTraffic) return hipErrorInvalidValue;  // (tol: in-place half-sweeps)
+    if (math == kMathTraffic && (act || delta_bits)) return hipErrorInvalidValue;
     // the kernel addresses a task's rows with 32-bit byte offsets from a base 2 rows above it (rows_per_task + 5 rows)
     const long long max_rows = 0x7fffffffLL / ((long long)pitch * 4) - 8;
     if (max_rows < 1) return hipErrorInvalidValue;
@@ -997,27 +1091,26 @@ hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw
     a.in = in;
     a.out = out;
     a.maskw = maskw;
-    a.maskf = nullptr;
+    a.maskf = maskf;
     a.check_lo = a.check_hi = 0;
-    a.delta_bits = nullptr;
+    a.delta_bits = delta_bits;
     a.rows = rows;
     a.pitch = pitch;
     a.row_begin = 0;
     a.row_end = rows;
     a.rows_per_task = rows_per_task;
     a.nstrips = (pitch + kFusedOut - 1) / kFusedOut;
-    a.ntasks = a.nstrips * ((rows + rows_per_task - 1) / rows_per_task);
+    a.nchunks = (rows + rows_per_task - 1) / rows_per_task;
+    a.ntasks = a.nstrips * a.nchunks;
     a.parity = parity & 1;
     a.flags = sweep_flags();
-    a.nchunks = 0;
-    a.wake = wake_args(nullptr, 0);
+    a.wake = wake_args(act, (size_t)a.ntasks);
     a.nblocks = (a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock;
-    const dim3 grid(a.nblocks), block(kWave * kWavesPerBlock);
-    a.maskf = maskf;
-    void (*kernel)(Sweep2dArgs) = math == kMathFast      ? (maskf ? rb_fused2d_kernel<kMathFast, true> : rb_fused2d_kernel<kMathFast, false>)
-                                  : math == kMathTraffic ? (maskf ? rb_fused2d_kernel<kMathTraffic, true> : rb_fused2d_kernel<kMathTraffic, false>)
-                                                         : (maskf ? rb_fused2d_kernel<kMathPrecise, true> : rb_fused2d_kernel<kMathPrecise, false>);
-    hipLaunchKernelGGL(kernel, grid, block, 0, stream, a);
+    if (math == kMathFast) launch_rb_fused_2d_math<kMathFast>(a, maskf != nullptr, stream);
+    else if (math == kMathTraffic) {
+        void (*kernel)(Sweep2dArgs) = maskf ? rb_fused2d_kernel<kMathTraffic, true, false, false> : rb_fused2d_kernel<kMathTraffic, false, false, false>;
+        hipLaunchKernelGGL(kernel, dim3(a.nblocks), dim3(kWave * kWavesPerBlock), 0, stream, a);
+    } else launch_rb_fused_2d_math<kMathPrecise>(a, maskf != nullptr, stream);
     return hipGetLastError();
 }
 

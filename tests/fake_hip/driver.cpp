@@ -162,6 +162,8 @@ int main(int argc, char **argv)
         {"node, 2-D", {16, 18}, 1e-3f, 4, seq_node, {}},
         {"node, 3-D", {5, 6, 7}, 1e-3f, 4, seq_node, {}},
         {"plugin, 2-D, work lists", {40, 300}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_TRACK", "1"}}},
+        {"plugin, 2-D, tracked pairs of fused passes", {40, 300}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_TRACK", "1"}, {"EPIC_HIP_FUSE_MIN_CELLS", "0"}}},
+        {"plugin, 2-D, tracked pairs, odd count", {40, 300}, 1e-3f, 7, seq_plugin, {{"EPIC_HIP_TRACK", "1"}, {"EPIC_HIP_FUSE_MIN_CELLS", "0"}}},
         {"plugin, 2-D, tol Jacobi (handover and finish rules)", {20, 30}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_MATH", "tol"}, {"EPIC_HIP_SCHEME", "jacobi"}}},
         {"plugin, 2-D, tol fused pairs", {24, 300}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_MATH", "tol"}, {"EPIC_HIP_SCHEME", "jacobi"}, {"EPIC_HIP_FUSE_MIN_CELLS", "0"}}},
         {"plugin, 2-D, three slabs, caller's thread", {48, 40}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_DEVICES", "0,0,0"}, {"EPIC_HIP_THREADS", "0"}, {"EPIC_HIP_HALO", "3"}}},
@@ -228,7 +230,7 @@ int main(int argc, char **argv)
         {"hipMalloc", {0, EPIC_ERROR_DEVICE_MALLOC}}, {"hipHostMalloc", {0, EPIC_ERROR_DEVICE_MALLOC}},
         {"hipStreamCreateWithFlags", {EPIC_ERROR_DEVICE_MALLOC}}, {"hipEventCreateWithFlags", {EPIC_ERROR_DEVICE_MALLOC}},
         {"hipEventCreate", {0}},   // (only the timing of candidate task heights uses it: the rule's height serves)
-        {"hipMemcpy", {EPIC_ERROR_MEMCPY_TO_DEVICE, EPIC_ERROR_MEMCPY_TO_HOST}},
+        {"hipMemcpy", {0, EPIC_ERROR_MEMCPY_TO_DEVICE, EPIC_ERROR_MEMCPY_TO_HOST}},   // (0: reading the list counters is advisory -- which tiling, bypass or not)
         {"hipMemcpy2D", {EPIC_ERROR_MEMCPY_TO_DEVICE, EPIC_ERROR_MEMCPY_TO_HOST}},
         {"hipMemcpyAsync", {EPIC_ERROR_MEMCPY_TO_DEVICE, EPIC_ERROR_MEMCPY_TO_HOST, EPIC_ERROR_KERNEL_EXECUTION}},
         {"hipMemcpyPeerAsync", {EPIC_ERROR_KERNEL_EXECUTION}},

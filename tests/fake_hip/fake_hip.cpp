@@ -242,7 +242,11 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *, int ro
     return hipSuccess;
 }
 hipError_t launch_wake_tile_range(const Activity *, size_t, int, int, hipStream_t) { FAKE_LAUNCH("launch_wake_tile_range"); return hipSuccess; }
-hipError_t launch_rb_fused_2d(const float *, float *, const uint32_t *, int, int, int, int, int, hipStream_t, const uint32_t *) { FAKE_LAUNCH("launch_rb_fused_2d"); return hipSuccess; }
+hipError_t launch_rb_fused_2d(const float *, float *, const uint32_t *, int, int, int, int, int, hipStream_t, const uint32_t *, const Activity *, unsigned *)
+{
+    FAKE_LAUNCH("launch_rb_fused_2d");
+    return hipSuccess;
+}
 hipError_t launch_jacobi_fused_2d(const float *, float *, const uint32_t *, int, int, int, int, hipStream_t, int, const uint32_t *) { FAKE_LAUNCH("launch_jacobi_fused_2d"); return hipSuccess; }
 hipError_t launch_fuse_masks_2d(const uint32_t *, int, int, uint32_t *, hipStream_t) { FAKE_LAUNCH("launch_fuse_masks_2d"); return hipSuccess; }
 hipError_t launch_eval_math(const float *, float *, size_t, int, hipStream_t) { FAKE_LAUNCH("launch_eval_math"); return hipSuccess; }

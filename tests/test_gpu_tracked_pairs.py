@@ -1,0 +1,121 @@
+"""Tracked red-black relaxations as PAIRS of iterations (round 4): list-driven fused passes, the check as the second iteration
+of the last pair (epic_amd/csrc/kernels_2d.hip: rb_fused2d_kernel with TRACK / CHECK; harmonic_gpu.hip: enqueue_rb_pairs_tracked).
+
+It is the path the library's DEFAULTS take on a large grid (precise math, red-black, activity tracking from 4 Mcell up), i.e. what
+the unchanged plugin gets at the benchmark's size, so the bar is the reference's bits: iteration count, final delta and the whole
+field of harmonic_complete_cpu (/root/reference/libepic/src/harmonic/harmonic_cpu.cpp:136-184), from the committed goldens."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from conftest import scheme_env
+from epic_amd import epic_harmonic as eh
+from epic_amd.harmonic import Harmonic
+from epic_amd.harmonic_map import HarmonicMap
+from epic_amd.synthetic import synthetic_grid
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+
+E = eh._epic
+GOLD = os.path.join(O.ROOT, "tests", "golden")
+
+
+class env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.prev = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, str(v))
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        return False
+
+
+def complete(h, **kv):
+    """harmonic_complete_gpu with the library's defaults plus: work lists on, the fused passes allowed on a grid of any size."""
+    base = dict(EPIC_HIP_MATH=None, EPIC_HIP_TILE="0", EPIC_HIP_TRACK="1", EPIC_HIP_FUSE_MIN_CELLS="0", EPIC_HIP_TRACK_PAIRS=None,
+                EPIC_HIP_TRACK_PAIR_ROWS=None, EPIC_HIP_TRACK_SWITCH=None)
+    base.update(kv)
+    with scheme_env(None), env(**base):
+        assert E.harmonic_complete_gpu(h, 1024) == 0
+    return h
+
+
+@pytest.mark.parametrize("rows", [None, 4, 7, 33])
+@pytest.mark.parametrize("switch", [None, "0", "2"])
+@pytest.mark.parametrize("n", [512, 1024])
+def test_benchmark_family_through_tracked_pairs_equals_the_reference(n, switch, rows):
+    """The benchmark's grid family against fields the reference converged (tests/golden/synthetic_converged.npz): any task height,
+    lists always bypassed ("0": every pass runs every tile), never bypassed ("2"), or by the library's rule."""
+    synth = np.load(os.path.join(GOLD, "synthetic_converged.npz"))
+    u0, locked = synthetic_grid([n, n])
+    h = Harmonic()
+    h.set_grid([n, n], u0, locked)
+    h.epsilon, h.numIterationsToStaggerCheck = 1e-6, 100
+    complete(h, EPIC_HIP_TRACK_SWITCH=switch, EPIC_HIP_TRACK_PAIR_ROWS=rows)
+    info = json.load(open(os.path.join(GOLD, "manifest.json")))["synthetic"]["grids"][str(n)]   # harmonic_complete_cpu's run
+    assert h.currentIteration == info["iterations"] and float(h.delta) == info["delta"]
+    assert hashlib.sha256(h.u_array().tobytes()).hexdigest() == info["sha_u"]
+    assert np.array_equal(h.u_array().ravel(), synth["s%d/converged" % n].ravel())
+
+
+@pytest.mark.parametrize("name,eps", [("maze", "1e-06"), ("umass", "0.001"), ("umass", "1e-06"), ("basic", "0.001")])
+def test_maps_through_tracked_pairs_equal_the_reference(name, eps, goldens):
+    run = goldens["manifest"]["maps"][name]["runs"][eps]
+    h = HarmonicMap().load(os.path.join(GOLD, "maps", name + ".png"))
+    h.epsilon, h.numIterationsToStaggerCheck = float(eps), 100
+    complete(h)
+    assert h.currentIteration == run["iterations"] and float(h.delta) == run["delta"]
+    assert hashlib.sha256(h.u_array().tobytes()).hexdigest() == run["sha_u"]
+
+
+@pytest.mark.parametrize("stagger", [7, 10, 2, 1, 33])
+@pytest.mark.parametrize("name", ["g2d_64", "g2d_70x66_dense", "g2d_8x300", "g2d_23x37"])
+def test_any_check_interval_pairs_or_not(goldens, name, stagger):
+    """Odd and even numbers of iterations between two checks (an odd count starts with one plain half-sweep), a check at every
+    iteration: field, iteration count and delta are the checker's statement of harmonic_complete_cpu at that stagger."""
+    import ctypes as ct
+
+    g = goldens["small"]
+    m = [int(x) for x in g[name + "/m"]]
+    p = O.Problem(m, g[name + "/u0"], g[name + "/locked"], 1e-6, stagger)
+    assert O.oracle().oracle_complete(ct.byref(p.h)) == 0
+    h = Harmonic()
+    h.set_grid(m, g[name + "/u0"], g[name + "/locked"])
+    h.epsilon, h.numIterationsToStaggerCheck = 1e-6, stagger
+    complete(h)
+    assert h.currentIteration == p.h.currentIteration and float(h.delta) == float(p.h.delta)
+    assert np.array_equal(h.u_array().ravel(), p.u)
+
+
+def test_8192_default_relaxation_pairs_against_half_sweeps(record_property):
+    """The library's defaults at the benchmark's size, with nothing in the environment: 45 001 iterations, delta 2.384e-07, and the
+    same field bit for bit as the same relaxation through list-driven half-sweeps (EPIC_HIP_TRACK_PAIRS=0, round 3's path, which
+    tests/test_gpu_bench_parity.py ties to the reference's iteration)."""
+    import time
+
+    n = 8192
+    u0, locked = synthetic_grid([n, n])
+    fields, secs = {}, {}
+    for pairs in (None, "0"):
+        h = Harmonic()
+        h.set_grid([n, n], u0, locked)
+        h.epsilon, h.numIterationsToStaggerCheck = 1e-6, 100
+        t0 = time.perf_counter()
+        with scheme_env(None), env(EPIC_HIP_MATH=None, EPIC_HIP_TRACK=None, EPIC_HIP_TRACK_PAIRS=pairs, EPIC_HIP_FUSE_MIN_CELLS=None):
+            assert E.harmonic_complete_gpu(h, 1024) == 0
+        secs[pairs] = time.perf_counter() - t0
+        assert h.currentIteration == 45001 and float(h.delta) == 2.384185791015625e-07
+        fields[pairs] = hashlib.sha256(h.u_array().tobytes()).hexdigest()
+    assert fields[None] == fields["0"]
+    record_property("seconds_pairs", secs[None])
+    record_property("seconds_half_sweeps", secs["0"])
+    print("8192^2 default relaxation incl. upload: pairs %.3f s, half-sweeps %.3f s" % (secs[None], secs["0"]))
