@@ -133,7 +133,11 @@ struct Ctx {
     float *h_delta = nullptr;      // pinned
     // small grids (kernels_tile2d.hip): max |du| per tile of a check iteration, written by the kernel straight into pinned host
     // memory -- no zeroing, no atomics on one word, no copy: the check costs the wait for the stream and nothing else
-    float *h_tile_delta = nullptr;
+    float *h_tile_delta = nullptr;   // 2 x kTileDeltaCap floats: two blocks of iterations may be in flight (tiles_pipelined)
+    // small grids, harmonic_execute_gpu: a THIRD buffer of u and two events, so that the block of iterations after a check can be
+    // enqueued before the check's result is known without destroying the state that check refers to (tiles_pipelined)
+    float *spare = nullptr;
+    hipEvent_t ev_blk[2] = {nullptr, nullptr};
     hipStream_t stream = nullptr;
     int rows_per_task = 0;         // 0 = automatic
     // Task height of the fused passes, measured on this grid (tune_fused_rows): [0] two Jacobi iterations (tol), [1] two
@@ -228,6 +232,12 @@ bool multi_ready(const Ctx *c);
 
 void report(const char *fn, const char *msg) { fprintf(stderr, "Error[%s]: %s\n", fn, msg); }
 
+void free_spare(Ctx *c)   // the third u buffer of the small-grid path goes wherever the two others go
+{
+    if (c->spare) (void)hipFree(c->spare);
+    c->spare = nullptr;
+}
+
 Ctx *find_ctx(Harmonic *h)
 {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -286,6 +296,7 @@ Ctx *get_ctx(Harmonic *h, bool create)
             drop_graphs(c);
             if (c->multi()) multi_destroy(c);
             for (float *&b : c->buf) { if (b) (void)hipFree(b); b = nullptr; }
+            free_spare(c);
             if (c->maskw) (void)hipFree(c->maskw);
             if (c->d_m) (void)hipFree(c->d_m);
             if (c->d_delta) (void)hipFree(c->d_delta);
@@ -306,7 +317,7 @@ Ctx *get_ctx(Harmonic *h, bool create)
         delete c;
         return nullptr;
     }
-    if (hipHostMalloc((void **)&c->h_tile_delta, kTileDeltaCap * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc((void **)&c->h_tile_delta, 2 * kTileDeltaCap * sizeof(float), hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();   // (the tile path then checks with the plain sweep)
         c->h_tile_delta = nullptr;
     }
@@ -357,6 +368,8 @@ void drop_ctx_if_empty(Harmonic *h)
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->h_delta) (void)hipHostFree(c->h_delta);
     if (c->h_tile_delta) (void)hipHostFree(c->h_tile_delta);
+    free_spare(c);
+    for (hipEvent_t &e : c->ev_blk) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     delete c;
     g_ctx.erase(it);
 }
@@ -500,6 +513,14 @@ int fused_rows_per_task(const Ctx *c)
     return (int)std::min<long long>(64, std::max<long long>(16, r));
 }
 
+// Red-black with the precise / fast math: from how many cells (rows x pitch) on two plain iterations run as one fused pass
+// (rb_fused2d_kernel).  EPIC_HIP_FUSE_MIN_CELLS overrides (the tests set 0).
+long long rb_fuse_min_cells()
+{
+    const char *e = getenv("EPIC_HIP_FUSE_MIN_CELLS");
+    return e ? atoll(e) : (1ll << 22);
+}
+
 // Whether two consecutive plain Jacobi iterations run as one fused pass in the context's current configuration.
 // EPIC_HIP_FUSE_MIN_CELLS: grids below it keep the single sweeps (default 4 Mcell: below, a sweep is launch-bound and the
 // fused pass's extra rows cost more than the second launch; read per batch, not cached -- the tests switch it).
@@ -597,7 +618,7 @@ hipError_t multi_run(Ctx *c, unsigned count, unsigned first, bool check_first);
 // Small 2-D grids (one device, no work lists): the plain iterations between two checks run several per launch on tiles that
 // stay in LDS (kernels_tile2d.hip) -- the ROS maps are launch-bound, 2.5-3 us per half-sweep whatever it computes.  halo == 0:
 // not for this context.  Knobs (read per batch; the tests switch them): EPIC_HIP_TILE=0 off; EPIC_HIP_TILE_HALO = ghost rings =
-// iterations per launch (default 8); EPIC_HIP_TILE_ROWS = owned rows per tile; EPIC_HIP_TILE_MAX_CELLS (default 0.5 Mcell).
+// iterations per launch (default: 8 to 14, by a cost model of the launch); EPIC_HIP_TILE_ROWS = owned rows per tile; EPIC_HIP_TILE_MAX_CELLS (default 0.5 Mcell).
 // Where it pays (tools/tile_probe.py, us per iteration, tiles / per-iteration kernels, bit-exact mode): 256^2 1.3 / 2.8, 482^2 1.4 / 3.5,
 // 310 x 940 1.5 / 3.2 -- one tile per CU; 1024^2 3.8 / 4.3 and 962^2 3.8 / 4.2 (four rounds of tiles: break-even); 954 x 1280 5.5 / 4.7,
 // 1442^2 7.1 / 6.7 (lost: every tile recomputes 2.3 cells per cell it owns).  Hence the limit.
@@ -609,12 +630,26 @@ epic_hip::TilePlan tile_plan(const Ctx *c)
     const char *e = getenv("EPIC_HIP_TILE");
     if (e && e[0] == '0') return none;
     e = getenv("EPIC_HIP_TILE_MAX_CELLS");
-    const long long max_cells = e ? atoll(e) : (1ll << 19);
+    const long long max_cells = e ? atoll(e) : (1ll << 20);
     if ((long long)c->rows * c->cols > max_cells) return none;
+    const char *rows_env = getenv("EPIC_HIP_TILE_ROWS");
     e = getenv("EPIC_HIP_TILE_HALO");
-    const int halo = e && atoi(e) > 0 ? atoi(e) : 8;
-    e = getenv("EPIC_HIP_TILE_ROWS");
-    return epic_hip::tile_2d_plan(c->rows, c->cols, halo, e ? atoi(e) : 0);
+    if (e && atoi(e) > 0) return epic_hip::tile_2d_plan(c->rows, c->cols, atoi(e), rows_env ? atoi(rows_env) : 0);
+    // How many ghost rings = iterations per launch.  Measured on the reference's maps (tools/tile_probe.py, profiles/r04_experiments.txt):
+    // a launch costs 2.7 us + rings x (0.84 + 0.0069 x LDS rows) us as long as every tile has a CU of its own, and 60 % more as soon
+    // as one CU has to take two; more rings amortise the launch but leave fewer owned columns (64 - 2 rings), hence more tile columns,
+    // hence taller tiles for the same number of CUs.  The model is evaluated for a few depths; what it picks is within 2 % of the
+    // best measured configuration on basic / maze / umass (10 or 12 rings).
+    epic_hip::TilePlan best = none;
+    double best_cost = 0.0;
+    for (int halo : {8, 10, 12, 14}) {
+        const epic_hip::TilePlan p = epic_hip::tile_2d_plan(c->rows, c->cols, halo, rows_env ? atoi(rows_env) : 0);
+        if (p.halo == 0) continue;
+        const double rounds = std::max(1.0, (double)p.tiles_r * p.tiles_c / 256.0);
+        const double cost = rounds * (2.7 / halo + 0.84 + 0.0069 * (p.tile_rows + 2 * halo));
+        if (best.halo == 0 || cost < best_cost) { best = p; best_cost = cost; }
+    }
+    return best;
 }
 
 // Whether a check iteration may run as the LAST step of a tile launch (its max |du| per tile into Ctx::h_tile_delta).
@@ -647,7 +682,7 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first, bool check_
     // (the fused passes have their own 248-column tiling and no work lists: they are used when tracking is off -- or
     //  bypassed for the batch, harmonic_execute_gpu; rb_fused2d_kernel for the precise / fast arithmetic, the RB instance of
     //  the tol pass for tol)
-    const bool fuse = c->redblack && c->n == 2 && !no_fuse && !c->track && !c->multi() && c->math != 4 && (long long)c->rows * c->pitch >= (1ll << 22);
+    const bool fuse = c->redblack && c->n == 2 && !no_fuse && !c->track && !c->multi() && c->math != 4 && (long long)c->rows * c->pitch >= rb_fuse_min_cells();
     unsigned i = 0;
     // Jacobi, tol math, 2-D: two consecutive plain iterations run as one pass as well (kernels_2d.hip,
     // jacobi_fused2d_kernel: 4 B of HBM traffic per cell-update instead of 8, bit-identical to two sweeps).
@@ -818,6 +853,33 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first, bool chec
     c->work_full += it->second.work;
     if (c->track) c->trk.phase = (int)((c->trk.phase + count) % 6);
     return hipSuccess;
+}
+
+// The pipelined form of the small-grid path needs a third buffer of u (padding columns seeded like the two others) and two
+// events; both are made on first use and go with the potential values / the context.  EPIC_HIP_TILE_PIPELINE=0: the plain form.
+bool tiles_pipeline_ready(Ctx *c)
+{
+    const char *e = getenv("EPIC_HIP_TILE_PIPELINE");
+    if (e && e[0] == '0') return false;
+    for (hipEvent_t &ev : c->ev_blk)
+        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            ev = nullptr;
+            return false;
+        }
+    if (!c->spare) {
+        if (hipMalloc((void **)&c->spare, c->u_bytes()) != hipSuccess) {
+            (void)hipGetLastError();
+            c->spare = nullptr;
+            return false;
+        }
+        if (epic_hip::launch_fill(c->spare, (size_t)c->rows * c->pitch, -1e6f, c->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            free_spare(c);
+            return false;
+        }
+    }
+    return true;
 }
 
 // max |du| of a check iteration that ran as the last step of a tile launch (enqueue_plain_run, check_last): wait for the
@@ -1641,6 +1703,7 @@ int harmonic_initialize_potential_values_gpu(Harmonic *harmonic)  // harmonic_mo
     }
     drop_graphs(c);
     for (float *&b : c->buf) { if (b) (void)hipFree(b); b = nullptr; }
+    free_spare(c);
     if (c->multi()) { DeviceGuard g; multi_free_u(c); }
     dims_into_ctx(harmonic, c);
     if (c->plan_failed) {   // (EPIC_HIP_DEVICES: not silently on one device instead -- the caller asked for the node)
@@ -1693,6 +1756,7 @@ int harmonic_uninitialize_potential_values_gpu(Harmonic *harmonic)  // harmonic_
             }
             b = nullptr;
         }
+        free_spare(c);
     }
     harmonic->d_u = nullptr;
     drop_ctx_if_empty(harmonic);
@@ -2088,6 +2152,80 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
             harmonic->currentIteration++;
             result = harmonic->delta < harmonic->epsilon ? EPIC_SUCCESS_AND_CONVERGED : EPIC_SUCCESS;
             after_check();
+        } else if (tile_checks(c, tile_plan(c)) && tiles_pipeline_ready(c)) {
+            // Small grids, pipelined (round 4).  A block = the plain iterations up to the next check and that check, as tile launches.
+            // The host does not wait for a check's result before enqueueing the NEXT block: it enqueues it from the state the
+            // check refers to, into the two buffers that state is not in (three buffers rotate), and only then waits for the
+            // check (an event; the per-tile maxima are in pinned memory).  If the check ends the loop -- or changes the mode
+            // (Jacobi handover, the tol mode's finishing phase) -- the block enqueued ahead is let run and ignored: the state the
+            // check refers to is intact.  The GPU never waits for the host between blocks (that wait was 12 % of a map's
+            // relaxation: profiles/r04_experiments.txt); iterations, checks and results are those of the plain loop.
+            struct Blk { float *final_buf; unsigned it_end, steps; int slot; };
+            float *bufs[3] = {c->buf[0], c->buf[1], c->spare};
+            int slot = 0;
+            auto enqueue_block = [&](float *in, unsigned first, Blk *out) -> hipError_t {
+                const epic_hip::TilePlan tp = tile_plan(c);
+                const unsigned total = (stagger - first % stagger) + 1;   // the plain iterations and the check
+                float *o1 = nullptr, *o2 = nullptr;
+                for (float *b : bufs)
+                    if (b != in) (o1 ? o2 : o1) = b;
+                float *src = in;
+                for (unsigned i = 0; i < total;) {
+                    const unsigned k = std::min<unsigned>(total - i, (unsigned)tp.halo);
+                    float *dst = src == o1 ? o2 : o1;
+                    hipError_t e = epic_hip::launch_tile_2d(src, dst, c->maskw, c->rows, c->pitch, tp, (int)k, c->math,
+                                                            c->redblack ? (int)((first + i) & 1u) : -1, nullptr, c->stream,
+                                                            i + k == total ? c->h_tile_delta + (size_t)slot * kTileDeltaCap : nullptr);
+                    if (e != hipSuccess) return e;
+                    src = dst;
+                    i += k;
+                }
+                hipError_t e = hipEventRecord(c->ev_blk[slot], c->stream);
+                *out = Blk{src, first + total, total, slot};
+                slot ^= 1;
+                return e;
+            };
+            auto adopt = [&](const Blk &b) {   // the state after block b becomes the context's current buffer
+                if (b.final_buf == c->spare) { std::swap(c->spare, c->buf[c->cur]); drop_graphs(c); }   // (captured sequences hold addresses)
+                else c->cur = b.final_buf == c->buf[0] ? 0 : 1;
+                harmonic->d_u = current_u(c);
+            };
+            Blk prev, next;
+            hipError_t pe = enqueue_block(c->buf[c->cur], harmonic->currentIteration, &prev);
+            bool leave = false;
+            while (pe == hipSuccess && !leave) {
+                pe = enqueue_block(prev.final_buf, prev.it_end, &next);   // ahead of prev's check
+                if (pe != hipSuccess) break;
+                if (hipEventSynchronize(c->ev_blk[prev.slot]) != hipSuccess) {
+                    report(fn, "Failed to synchronize the device after the 'update and check' kernel.");
+                    return EPIC_ERROR_DEVICE_SYNCHRONIZE;
+                }
+                const epic_hip::TilePlan tp = tile_plan(c);
+                float d = 0.0f;
+                const float *tile_max = c->h_tile_delta + (size_t)prev.slot * kTileDeltaCap;
+                for (int t = 0, n = tp.tiles_r * tp.tiles_c; t < n; ++t) d = std::max(d, tile_max[t]);
+                harmonic->delta = d;
+                harmonic->currentIteration = prev.it_end;
+                c->work_full += (double)prev.steps;
+                result = d < harmonic->epsilon ? EPIC_SUCCESS_AND_CONVERGED : EPIC_SUCCESS;
+                const int math0 = c->math;
+                const bool rb0 = c->redblack;
+                after_check();
+                const bool stop = result == EPIC_SUCCESS_AND_CONVERGED && harmonic->currentIteration >= mMax;
+                const bool changed = c->math != math0 || c->redblack != rb0;
+                if (stop || changed) {
+                    // the block enqueued ahead ran (or runs) in a mode, or past an end, that the check has just ruled out
+                    if (hipStreamSynchronize(c->stream) != hipSuccess) return EPIC_ERROR_DEVICE_SYNCHRONIZE;
+                    adopt(prev);
+                    leave = true;   // the outer loop ends (stop) or goes on from here in the new mode
+                } else {
+                    prev = next;
+                }
+            }
+            if (pe != hipSuccess) {
+                report(fn, "Failed to perform the Jacobi update step.");
+                return EPIC_ERROR_KERNEL_EXECUTION;
+            }
         } else if (tile_checks(c, tile_plan(c))) {
             // Small grids (kernels_tile2d.hip): the plain iterations up to the next check AND that check are one sequence of tile
             // launches (one captured graph); the check is the last step of the last launch and leaves its max |du| per tile in
@@ -2338,7 +2476,7 @@ int epic_hip_iterations_per_pass(Harmonic *harmonic)
     if (fuses_jacobi(c) || fuses_rb_tol(c)) return 2;
     const bool no_fuse = getenv("EPIC_HIP_NO_FUSE") != nullptr;   // (read per call: the tests switch it)
     const bool rb_fused = c->redblack && c->n == 2 && !no_fuse && !c->track && c->math != 4 &&
-                          (long long)c->rows * c->pitch >= (1ll << 22);
+                          (long long)c->rows * c->pitch >= rb_fuse_min_cells();
     return rb_fused ? 2 : 1;
 }
 

@@ -101,11 +101,14 @@ inline TilePlan tile_2d_plan(int rows, int cols, int halo, int tile_rows = 0)
     const int max_tr = kTile2dMaxRows - 2 * halo;
     int tr = tile_rows;
     if (tr <= 0) {
-        int cus = 256, dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
-            (void)hipGetLastError();
-            cus = 256;
-        }
+        static const int cus = [] {   // (asked once per process: the devices of a node are alike)
+            int n = 256, dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) {
+                (void)hipGetLastError();
+                n = 256;
+            }
+            return n;
+        }();
         const int tiles_r_max = cus / tiles_c > 1 ? cus / tiles_c : 1;   // rows of tiles the chip takes in one round
         tr = (rows + tiles_r_max - 1) / tiles_r_max;
         tr = (tr + 1) / 2 * 2;                                           // (even: the LDS tile is walked in row pairs)

@@ -228,7 +228,8 @@ int main(int argc, char **argv)
     // what failed must surface as the reference's code for it (error_codes.h:31-46; 0 where the library has a fallback)
     const std::map<std::string, std::set<int>> allowed = {
         {"hipMalloc", {0, EPIC_ERROR_DEVICE_MALLOC}}, {"hipHostMalloc", {0, EPIC_ERROR_DEVICE_MALLOC}},
-        {"hipStreamCreateWithFlags", {EPIC_ERROR_DEVICE_MALLOC}}, {"hipEventCreateWithFlags", {EPIC_ERROR_DEVICE_MALLOC}},
+        {"hipStreamCreateWithFlags", {EPIC_ERROR_DEVICE_MALLOC}},
+        {"hipEventCreateWithFlags", {0, EPIC_ERROR_DEVICE_MALLOC}},   // (0: the events of the pipelined small-grid loop -- the plain loop serves)
         {"hipEventCreate", {0}},   // (only the timing of candidate task heights uses it: the rule's height serves)
         {"hipMemcpy", {0, EPIC_ERROR_MEMCPY_TO_DEVICE, EPIC_ERROR_MEMCPY_TO_HOST}},   // (0: reading the list counters is advisory -- which tiling, bypass or not)
         {"hipMemcpy2D", {EPIC_ERROR_MEMCPY_TO_DEVICE, EPIC_ERROR_MEMCPY_TO_HOST}},
@@ -237,11 +238,12 @@ int main(int argc, char **argv)
         {"hipMemsetAsync", {0, EPIC_ERROR_KERNEL_EXECUTION}}, {"hipMemset", {0}},
         {"hipStreamSynchronize", {0, EPIC_ERROR_MEMCPY_TO_HOST, EPIC_ERROR_KERNEL_EXECUTION, EPIC_ERROR_DEVICE_SYNCHRONIZE}},
         {"hipStreamWaitEvent", {EPIC_ERROR_KERNEL_EXECUTION}}, {"hipEventRecord", {EPIC_ERROR_KERNEL_EXECUTION}},
-        {"hipEventSynchronize", {0}},
+        {"hipEventSynchronize", {0, EPIC_ERROR_DEVICE_SYNCHRONIZE}},
     };
     for (auto &kv : codes) {
         auto it = allowed.find(kv.first);
         for (int c : kv.second) {
+            if (kv.first == "launch_fill" && c == 0) continue;   // (seeding the third buffer of the pipelined small-grid loop: the plain loop serves)
             if (kv.first.rfind("launch_", 0) == 0) EXPECT(c == EPIC_ERROR_KERNEL_EXECUTION, "%s failing gave code %d", kv.first.c_str(), c);
             else if (it == allowed.end()) EXPECT(false, "no expectation for %s (code %d)", kv.first.c_str(), c);
             else EXPECT(it->second.count(c) == 1, "%s failing gave code %d", kv.first.c_str(), c);
