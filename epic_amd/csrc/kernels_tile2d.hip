@@ -42,6 +42,19 @@ constexpr int kTileThreads = 64 * kTileWaves;
 // trips in it (~0.8 us for a wave alone on its SIMD, measured): the tile's row pairs are therefore spread over SIXTEEN
 // waves -- one or two passes each -- and the four waves of a SIMD cover each other's latencies (4 waves per workgroup: 18.3 us
 // per launch of 8 iterations on maps/maze.png, 16 waves: 10.8; tools/tile_probe.py, profiles/r04_experiments.txt).
+// Build knob, OFF: between two iterations a wave waits not for the whole workgroup but for the two waves that hold the rows next
+// to its own (rows are dealt to the waves in turn, so the neighbours of wave w's rows belong to waves w - 1 and w + 1,
+// cyclically; w may start iteration j + 1 once both have FINISHED iteration j -- then what it reads there is written and what it
+// overwrites has been read).  The idea: with a barrier per iteration all sixteen waves read LDS, wait, compute and wait again in
+// lockstep -- the SQ counters have the VALU issuing 45 % of the time and the waves at s_waitcnt for half of it
+// (profiles/r04_sq_counters_maze_tiles.txt) -- and staggered waves would fill each other's waits.  Built, bit-identical (the
+// whole tile suite), and SLOWER: maze 0.0823 s against 0.0762 s, umass 0.1564 against 0.1447, same call -- polling two LDS words
+// per iteration costs more than the barrier, and neighbours one iteration apart do not stagger far.  Kept as the measured
+// alternative (profiles/r04_experiments.txt item 1h).
+#ifndef EPIC_TILE_WAVE_SYNC
+#define EPIC_TILE_WAVE_SYNC 0
+#endif
+constexpr bool kTileWaveSync = EPIC_TILE_WAVE_SYNC != 0;
 constexpr int kRbPasses = (kTileMaxRows / 2 + kTileWaves - 1) / kTileWaves;   // row pairs per wave
 constexpr int kJcPasses = (kTileMaxRows + kTileWaves - 1) / kTileWaves;       // rows per wave
 constexpr lmask kOddLanes = 0xaaaaaaaaaaaaaaaaull;
@@ -71,6 +84,7 @@ __global__ __launch_bounds__(kTileThreads) void tile2d_kernel(Tile2dArgs a)
     __shared__ float q_lds[TOL ? kBufs * kPlane : 1];
     __shared__ uint32_t n_lds[TOL ? kBufs * kPlane : 1];
     __shared__ unsigned wg_delta;
+    __shared__ int step_done[kTileWaves];   // iterations each wave has finished (kTileWaveSync)
     __shared__ __attribute__((aligned(16))) char math_lds_bytes[TOL ? TolLn<4>::kLdsBytes : kMathLdsDoubles * (int)sizeof(double)];
     const TolLnEntry *const tl = reinterpret_cast<const TolLnEntry *>(math_lds_bytes);
     const MathTab tab = math_tables_at(reinterpret_cast<double *>(math_lds_bytes));
@@ -121,6 +135,7 @@ __global__ __launch_bounds__(kTileThreads) void tile2d_kernel(Tile2dArgs a)
         }
     }
     if (threadIdx.x == 0) wg_delta = 0;
+    if (threadIdx.x < kTileWaves) step_done[threadIdx.x] = 0;
     if (MATH == kMathPrecise) math_tables_commit(tab_regs, reinterpret_cast<double *>(math_lds_bytes));
     if (TOL) TolLn<4>::stage(reinterpret_cast<TolLnEntry *>(math_lds_bytes));   // ends with a workgroup barrier
     else __syncthreads();
@@ -131,7 +146,13 @@ __global__ __launch_bounds__(kTileThreads) void tile2d_kernel(Tile2dArgs a)
     const int odd_lane = lane & 1;
     const bool want_delta = a.delta_bits != nullptr || a.tile_delta != nullptr;
     float dmax = 0.0f;
+    const int wave_up = (wave + kTileWaves - 1) % kTileWaves, wave_dn = (wave + 1) % kTileWaves;
     for (int j = 0; j < a.steps; ++j) {
+        if (kTileWaveSync && j > 0) {   // the two waves next to this one have finished iteration j - 1
+            while (__hip_atomic_load(&step_done[wave_up], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < j ||
+                   __hip_atomic_load(&step_done[wave_dn], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < j)
+                __builtin_amdgcn_s_sleep(1);
+        }
         // cells that still have four valid neighbours: local rows [lo, hi_r], columns [lo, 63 - lo]
         const int lo = j + 1, hi_r = Sr - 2 - j;
         const lmask cols_ok = (~0ull << lo) & (~0ull >> lo);
@@ -179,8 +200,13 @@ __global__ __launch_bounds__(kTileThreads) void tile2d_kernel(Tile2dArgs a)
             }
             if (check) dmax = max2(dmax, sel(own, fabsf(c - o), 0.0f));   // (wave-uniform branch)
         }
-        __syncthreads();
+        if (kTileWaveSync) {
+            if (lane == 0) __hip_atomic_store(&step_done[wave], j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            __syncthreads();
+        }
     }
+    if (kTileWaveSync) __syncthreads();   // every wave has finished: the owned cells may leave
 
     // ---- store the owned cells (locked ones included: `out` is the other buffer)
     const int fin = RB ? 0 : (a.steps & 1) * kPlane;

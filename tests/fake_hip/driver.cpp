@@ -26,6 +26,8 @@
 #include <epic/epic_abi.h>
 #include <epic_hip.h>
 
+#include "../../epic_amd/csrc/kernels.h"   // tile_2d_plan (host logic of the small-grid path)
+
 using namespace epic;
 
 static int failures = 0;
@@ -173,6 +175,24 @@ int main(int argc, char **argv)
         {"plugin, 2-D, four slabs, issuing threads", {64, 40}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_DEVICES", "0,0,0,0"}, {"EPIC_HIP_HALO", "4"}}},
         {"node, 2-D, three slabs, issuing threads, work lists", {48, 300}, 1e-3f, 4, seq_node, {{"EPIC_HIP_DEVICES", "0,0,0"}, {"EPIC_HIP_TRACK", "1"}}},
     };
+    // host logic of the small-grid path: whatever the grid and the ring depth, the tiles cover the grid, fit the LDS tile and
+    // leave at least two owned rows and columns; a plan that cannot be made says so (halo == 0)
+    if (!threads_only) {
+        long plans = 0;
+        for (int rows : {3, 4, 17, 64, 256, 310, 482, 1000, 1024})
+            for (int cols : {3, 5, 48, 49, 256, 482, 940, 1024})
+                for (int halo : {1, 2, 5, 8, 12, 14, 27, 28, 40})
+                    for (int want : {0, 2, 7, 20, 64}) {
+                        const epic_hip::TilePlan p = epic_hip::tile_2d_plan(rows, cols, halo, want);
+                        if (p.halo == 0) { EXPECT(2 * halo >= epic_hip::kTile2dCols - 8, "no plan for %d x %d, halo %d", rows, cols, halo); continue; }
+                        plans++;
+                        EXPECT(p.halo == halo && p.tile_cols == epic_hip::kTile2dCols - 2 * halo && p.tile_cols >= 8, "columns: %d x %d halo %d", rows, cols, halo);
+                        EXPECT(p.tile_rows >= 2 && p.tile_rows % 2 == 0 && p.tile_rows + 2 * halo <= epic_hip::kTile2dMaxRows, "rows: %d x %d halo %d -> %d", rows, cols, halo, p.tile_rows);
+                        EXPECT((long)p.tiles_r * p.tile_rows >= rows && (long)(p.tiles_r - 1) * p.tile_rows < rows, "row cover: %d x %d halo %d", rows, cols, halo);
+                        EXPECT((long)p.tiles_c * p.tile_cols >= cols && (long)(p.tiles_c - 1) * p.tile_cols < cols, "column cover: %d x %d halo %d", rows, cols, halo);
+                    }
+        printf("tile plans checked: %ld\n", plans);
+    }
     long walked = 0, tolerated = 0;
     std::map<std::string, std::set<int>> codes;   // failing call -> return codes seen
     for (const Scenario &sc : scenarios) {

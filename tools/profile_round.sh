@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiles kept under profiles/ for a round (run on the GPU box through gpurun; TAG = r01, r02, ...):
-#   bash tools/profile_round.sh r03
+#   bash tools/profile_round.sh r04
 # rocprofv3 passes, each with the program itself after `--` (python3 <script>), counters in their own runs:
 #   1. --kernel-trace --stats of the bench.py command (default math = tol, untracked Jacobi, developed field: pairs of
 #      iterations as jacobi_fused2d_kernel, the check and the odd iteration as sweep2d_kernel) and of
@@ -10,7 +10,7 @@
 #   4. --kernel-trace --stats of whole relaxations with activity tracking (tools/time_relax.py): tol Jacobi, and the library
 #      default (precise, red-black) -- the list-driven kernels and the bypassed batches
 #   bash tools/profile_round.sh r03 3d      only the passes whose name contains "3d" (after a change to the 3-D kernel)
-TAG=${1:-r03}
+TAG=${1:-r04}
 ONLY=${2:-}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
@@ -30,7 +30,13 @@ run stats_3d_tol          rocprofv3 --kernel-trace --stats --output-format csv -
 run stats_3d_precise      rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_3d_precise" -- python3 $C --math precise --sweeps 300
 R="$ROOT/tools/time_relax.py --track 2"
 run stats_relax_tol      rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_relax_tol" -- python3 $R --math tol --scheme jacobi
+run stats_relax_tol_rb   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_relax_tol_rb" -- python3 $R --math tol --scheme redblack
 run stats_relax_default  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_relax_default" -- python3 $R --math precise --scheme redblack
+#   5. (round 4) the reference's maps through harmonic_complete_gpu with the library's defaults: tile2d_kernel (several iterations per
+#      launch on LDS tiles) -- kernel stats, and the SQ counters of the same command
+M="$ROOT/tools/time_maps.py --modes default --tile 1 --repeat 1"
+run stats_maps  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_maps" -- python3 $M
+run sq_maps     rocprofv3 --pmc $SQ --output-format csv -d "$OUT/sq_maps" -- python3 $M --maps maze
 run fetch_tol   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_tol_jacobi" -- python3 $B --steps 1 --warmup 1 --develop 5000
 run write_tol   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write_tol_jacobi" -- python3 $B --steps 1 --warmup 1 --develop 5000
 run fetch_3d_tol   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_3d_tol" -- python3 $C --math tol --sweeps 100
@@ -51,6 +57,9 @@ $S stats "$OUT/stats_3d_tol" > "$OUT/${TAG}_kernel_stats_3d_tol.txt"
 $S stats "$OUT/stats_3d_precise" > "$OUT/${TAG}_kernel_stats_3d_precise.txt"
 $S stats "$OUT/stats_relax_tol" > "$OUT/${TAG}_kernel_stats_relax_tol_tracked.txt"
 $S stats "$OUT/stats_relax_default" > "$OUT/${TAG}_kernel_stats_relax_default.txt"
+$S stats "$OUT/stats_relax_tol_rb" > "$OUT/${TAG}_kernel_stats_relax_tol_redblack.txt"
+$S stats "$OUT/stats_maps" > "$OUT/${TAG}_kernel_stats_maps_tiles.txt"
+PROFILE_KERNEL=tile2d $S sq "$OUT/sq_maps" 232324 > "$OUT/${TAG}_sq_counters_maze_tiles.txt" 2>&1
 PROFILE_LAST=90 PROFILE_KERNEL=jacobi_fused2d $S pmc "$OUT/fetch_tol_jacobi" "$OUT/write_tol_jacobi" > "$OUT/${TAG}_hbm_traffic_tol_jacobi_fused.txt"
 PROFILE_KERNEL=sweep2d $S pmc "$OUT/fetch_tol_jacobi" "$OUT/write_tol_jacobi" > "$OUT/${TAG}_hbm_traffic_tol_jacobi.txt"
 $S pmc "$OUT/fetch_3d_tol" "$OUT/write_3d_tol" > "$OUT/${TAG}_hbm_traffic_3d_tol.txt"
