@@ -215,6 +215,7 @@ struct Ctx {
 };
 
 constexpr float kTolFinishOptionalBelow = 1e-5f;   // EPIC_HIP_TOL_FINISH=0 is honoured for epsilon <= this (harmonic_execute_gpu)
+constexpr long long kTileMaxCellsDefault = 3ll << 20;   // EPIC_HIP_TILE_MAX_CELLS: grids up to this many cells take the tile path
 constexpr size_t kTileDeltaCap = 4096;   // tiles of a launch whose check may go through Ctx::h_tile_delta
 
 std::mutex g_mu;
@@ -616,12 +617,12 @@ void tune_fused_rows(Ctx *c, int kind, unsigned iteration)
 hipError_t multi_run(Ctx *c, unsigned count, unsigned first, bool check_first);
 
 // Small 2-D grids (one device, no work lists): the plain iterations between two checks run several per launch on tiles that
-// stay in LDS (kernels_tile2d.hip) -- the ROS maps are launch-bound, 2.5-3 us per half-sweep whatever it computes.  halo == 0:
-// not for this context.  Knobs (read per batch; the tests switch them): EPIC_HIP_TILE=0 off; EPIC_HIP_TILE_HALO = ghost rings =
-// iterations per launch (default: 8 to 14, by a cost model of the launch); EPIC_HIP_TILE_ROWS = owned rows per tile; EPIC_HIP_TILE_MAX_CELLS (default 0.5 Mcell).
-// Where it pays (tools/tile_probe.py, us per iteration, tiles / per-iteration kernels, bit-exact mode): 256^2 1.3 / 2.8, 482^2 1.4 / 3.5,
-// 310 x 940 1.5 / 3.2 -- one tile per CU; 1024^2 3.8 / 4.3 and 962^2 3.8 / 4.2 (four rounds of tiles: break-even); 954 x 1280 5.5 / 4.7,
-// 1442^2 7.1 / 6.7 (lost: every tile recomputes 2.3 cells per cell it owns).  Hence the limit.
+// stay in LDS (kernels_tile2d.hip) -- the reference's maps are launch-bound, 2.5-3 us per half-sweep whatever it computes.
+// halo == 0: not for this context.  Knobs (read per batch; the tests switch them): EPIC_HIP_TILE=0 off; EPIC_HIP_TILE_HALO = ghost
+// rings = iterations per launch, EPIC_HIP_TILE_WIDTH = 64 | 128 (default for both: a cost model of the launch, below);
+// EPIC_HIP_TILE_ROWS = owned rows per tile; EPIC_HIP_TILE_MAX_CELLS (default 3 Mcell; from 4 Mcell up the fused passes take over).
+// Where it pays (tools/tile_probe.py, tools/time_maps.py; profiles/r04_experiments.txt items 1f, 1i): 2.0-2.4 x on the maps up to
+// 0.3 Mcell (one narrow tile per CU), 1.1-1.3 x on the 1-2.5 Mcell fixtures (wide tiles).
 epic_hip::TilePlan tile_plan(const Ctx *c)
 {
     epic_hip::TilePlan none = {0, 0, 0, 0, 0};
@@ -630,24 +631,41 @@ epic_hip::TilePlan tile_plan(const Ctx *c)
     const char *e = getenv("EPIC_HIP_TILE");
     if (e && e[0] == '0') return none;
     e = getenv("EPIC_HIP_TILE_MAX_CELLS");
-    const long long max_cells = e ? atoll(e) : (1ll << 20);
+    const long long max_cells = e ? atoll(e) : kTileMaxCellsDefault;
     if ((long long)c->rows * c->cols > max_cells) return none;
     const char *rows_env = getenv("EPIC_HIP_TILE_ROWS");
+    const int want_rows = rows_env ? atoi(rows_env) : 0;
+    e = getenv("EPIC_HIP_TILE_WIDTH");   // 64 | 128: one width only (experiments, tests)
+    const int only_width = e ? atoi(e) : 0;
     e = getenv("EPIC_HIP_TILE_HALO");
-    if (e && atoi(e) > 0) return epic_hip::tile_2d_plan(c->rows, c->cols, atoi(e), rows_env ? atoi(rows_env) : 0);
-    // How many ghost rings = iterations per launch.  Measured on the reference's maps (tools/tile_probe.py, profiles/r04_experiments.txt):
-    // a launch costs 2.7 us + rings x (0.84 + 0.0069 x LDS rows) us as long as every tile has a CU of its own, and 60 % more as soon
-    // as one CU has to take two; more rings amortise the launch but leave fewer owned columns (64 - 2 rings), hence more tile columns,
-    // hence taller tiles for the same number of CUs.  The model is evaluated for a few depths; what it picks is within 2 % of the
-    // best measured configuration on basic / maze / umass (10 or 12 rings).
+    const int only_halo = e && atoi(e) > 0 ? atoi(e) : 0;
+    // Which LDS tile (64 or 128 columns wide), and how many ghost rings = iterations per launch.  Measured (tools/tile_probe.py,
+    // profiles/r04_experiments.txt items 1d, 1i): a launch costs ~2.7 us + 0.06 us per 1000 LDS cells to load and store, plus per
+    // iteration the larger of a latency chain -- 0.84 us + 0.055 us per pass and SIMD: the barrier, three LDS round trips, one
+    // cell update's dependent instructions -- and the issue of the passes themselves (0.21 us per pass and SIMD with the
+    // bit-exact arithmetic -- 67 % of full VALU issue --, 0.17 us with tol), as long as every tile has a CU of its own (+60 % as
+    // soon as one CU takes two).
+    // More rings amortise the launch but leave fewer owned cells per tile; wide tiles waste fewer cells on rings (1.3-1.5 per
+    // owned cell instead of 2.3) but give each CU 3-6 times the passes.  The model is evaluated for both widths and a few depths.
     epic_hip::TilePlan best = none;
     double best_cost = 0.0;
-    for (int halo : {8, 10, 12, 14}) {
-        const epic_hip::TilePlan p = epic_hip::tile_2d_plan(c->rows, c->cols, halo, rows_env ? atoi(rows_env) : 0);
-        if (p.halo == 0) continue;
-        const double rounds = std::max(1.0, (double)p.tiles_r * p.tiles_c / 256.0);
-        const double cost = rounds * (2.7 / halo + 0.84 + 0.0069 * (p.tile_rows + 2 * halo));
-        if (best.halo == 0 || cost < best_cost) { best = p; best_cost = cost; }
+    for (int width : {epic_hip::kTile2dCols, epic_hip::kTile2dWideCols}) {
+        if (only_width && width != only_width) continue;
+        const int max_rows = epic_hip::tile_2d_max_rows(c->math, c->redblack, width);
+        if (max_rows == 0) continue;
+        for (int halo : {8, 10, 12, 14, 16}) {
+            if (only_halo && halo != only_halo && halo != 8) continue;
+            const int h = only_halo ? only_halo : halo;
+            const epic_hip::TilePlan p = epic_hip::tile_2d_plan(c->rows, c->cols, h, want_rows, width, max_rows);
+            if (p.halo == 0) continue;
+            const int s_r = p.tile_rows + 2 * h;
+            const double units = (c->redblack ? s_r / 2.0 : (double)s_r) * (width / 64), per_simd = units / 4.0;
+            const double rounds = std::max(1.0, (double)p.tiles_r * p.tiles_c / 256.0);
+            const double step = std::max(0.84 + 0.055 * per_simd, 0.2 + (c->math == 4 ? 0.17 : 0.21) * per_simd);
+            const double cost = (rounds > 1.0 ? 1.6 * rounds / 2.0 + 0.2 : 1.0) * ((2.7 + 0.00006 * s_r * width) / h + step);
+            if (best.halo == 0 || cost < best_cost) { best = p; best_cost = cost; }
+            if (only_halo) break;
+        }
     }
     return best;
 }

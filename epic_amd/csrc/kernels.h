@@ -88,17 +88,28 @@ hipError_t launch_set_cells_2d(float *u, uint32_t *maskw, int rows, int cols, in
 // ---- small grids: several iterations per launch on LDS tiles (kernels_tile2d.hip) ----------------
 // A tile owns tile_rows x tile_cols cells and carries `halo` ghost rings; a launch performs up to `halo` iterations.
 struct TilePlan { int halo, tile_rows, tile_cols, tiles_r, tiles_c; };   // halo == 0: no plan (grid or halo out of range)
-constexpr int kTile2dCols = 64, kTile2dMaxRows = 64;   // the LDS tile: one lane per column, at most 64 rows with the ghost rings
-// How a grid is cut into tiles for `halo` ghost rings: owned columns 64 - 2 halo; owned rows as tall as the LDS tile allows, but
-// not taller than what gives every CU of the chip a tile (the tiles of a launch run side by side: its time is the time of ONE
-// tile, so smaller tiles are faster until the chip is full).  tile_rows > 0: that height (clamped).
-inline TilePlan tile_2d_plan(int rows, int cols, int halo, int tile_rows = 0)
+constexpr int kTile2dCols = 64, kTile2dMaxRows = 64;   // the narrow LDS tile: one lane per column, at most 64 rows with the ghost rings
+constexpr int kTile2dWideCols = 128;                   // the wide one: two column blocks of 64 lanes (width of a plan: tile_cols + 2 halo)
+// Tallest LDS tile (rows, ghost rings included) the kernels have for this arithmetic, scheme and width; 0: no such kernel.
+// (What fits 160 KB of LDS: u, and for the tol math q and n beside it, once for red-black and twice for Jacobi.)
+inline int tile_2d_max_rows(int math, bool redblack, int width)
+{
+    if (width == kTile2dCols) return kTile2dMaxRows;
+    if (width != kTile2dWideCols) return 0;
+    if (math == 4) return redblack ? 64 : 0;   // tol
+    return 128;
+}
+// How a grid is cut into tiles for `halo` ghost rings: owned columns width - 2 halo; owned rows as tall as the LDS tile allows
+// (max_rows, ghost rings included), but not taller than what gives every CU of the chip a tile (the tiles of a launch run side
+// by side: its time is the time of ONE tile, so smaller tiles are faster until the chip is full).  tile_rows > 0: that height
+// (clamped).
+inline TilePlan tile_2d_plan(int rows, int cols, int halo, int tile_rows = 0, int width = kTile2dCols, int max_rows = kTile2dMaxRows)
 {
     TilePlan p = {0, 0, 0, 0, 0};
-    if (halo < 1 || 2 * halo >= kTile2dCols - 8 || rows < 3 || cols < 3) return p;
-    const int tc = kTile2dCols - 2 * halo;
+    if (halo < 1 || 2 * halo >= width - 8 || 2 * halo >= max_rows - 1 || rows < 3 || cols < 3) return p;
+    const int tc = width - 2 * halo;
     const int tiles_c = (cols + tc - 1) / tc;
-    const int max_tr = kTile2dMaxRows - 2 * halo;
+    const int max_tr = max_rows - 2 * halo;
     int tr = tile_rows;
     if (tr <= 0) {
         static const int cus = [] {   // (asked once per process: the devices of a node are alike)

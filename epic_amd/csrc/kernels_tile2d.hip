@@ -34,8 +34,6 @@ namespace {
 #ifndef EPIC_TILE_WAVES  // build knob (A/B): waves per workgroup
 #define EPIC_TILE_WAVES 16
 #endif
-constexpr int kTileCols = kTile2dCols;        // LDS tile width = lanes of a wave
-constexpr int kTileMaxRows = kTile2dMaxRows;  // S_r <= 64
 constexpr int kTileWaves = EPIC_TILE_WAVES;
 constexpr int kTileThreads = 64 * kTileWaves;
 // A step is as long as its slowest wave, and a cell's update is one chain of ~80 dependent instructions with three LDS round
@@ -55,8 +53,6 @@ constexpr int kTileThreads = 64 * kTileWaves;
 #define EPIC_TILE_WAVE_SYNC 0
 #endif
 constexpr bool kTileWaveSync = EPIC_TILE_WAVE_SYNC != 0;
-constexpr int kRbPasses = (kTileMaxRows / 2 + kTileWaves - 1) / kTileWaves;   // row pairs per wave
-constexpr int kJcPasses = (kTileMaxRows + kTileWaves - 1) / kTileWaves;       // rows per wave
 constexpr lmask kOddLanes = 0xaaaaaaaaaaaaaaaaull;
 
 struct Tile2dArgs {
@@ -66,19 +62,26 @@ struct Tile2dArgs {
     unsigned *delta_bits;    // null, or: max |du| of the LAST iteration of the launch over the owned cells (atomicMax on float bits)
     float *tile_delta;       // null, or: the same maximum per tile, one plain store each (no zeroing, no atomics; may be host memory)
     int rows, pitch;
-    int halo, tile_rows;     // H, T_r; owned columns per tile = 64 - 2 H
+    int halo, tile_rows;     // H, T_r; owned columns per tile = LDS tile width - 2 H
     int tiles_c;
     int steps;               // iterations of this launch, <= halo
     int parity;              // red-black: number of the first iteration & 1
 };
 
-template <int MATH, bool RB>
+// CW, RMAX: the LDS tile is 64 CW columns wide and at most RMAX rows tall.  (1, 64): the maps up to ~0.3 Mcell, where a tile of
+// ~1000 owned cells gives every CU one.  (2, 128): grids of 1-4 Mcell (the reference's batch fixtures: willow_garage, the mines,
+// maze_2 / maze_3) -- tiles of up to 100 x 100 owned cells, whose ghost rings cost 1.3-1.5 cells per owned cell instead of 2.3; a
+// row (pair) is then two units of 64 lanes, dealt to the waves like the rest.
+template <int MATH, bool RB, int CW, int RMAX>
 __global__ __launch_bounds__(kTileThreads) void tile2d_kernel(Tile2dArgs a)
 {
     constexpr bool TOL = MATH == kMathTol;
     constexpr int kBufs = RB ? 1 : 2;
-    constexpr int kPasses = RB ? kRbPasses : kJcPasses;
-    constexpr int kSlots = RB ? 2 * kRbPasses : kJcPasses;   // rows a lane may update
+    constexpr int kTileCols = 64 * CW;
+    constexpr int kTileMaxRows = RMAX;
+    constexpr int kUnits = (RB ? RMAX / 2 : RMAX) * CW;                 // (row pair | row) x column block
+    constexpr int kPasses = (kUnits + kTileWaves - 1) / kTileWaves;    // units per wave
+    constexpr int kSlots = RB ? 2 * kPasses : kPasses;                 // rows a lane may update
     constexpr int kPlane = (kTileMaxRows + 2) * kTileCols;   // one pad row above and below: the neighbours of a stale edge cell stay inside
     __shared__ float u_lds[kBufs * kPlane];
     __shared__ float q_lds[TOL ? kBufs * kPlane : 1];
@@ -96,22 +99,24 @@ __global__ __launch_bounds__(kTileThreads) void tile2d_kernel(Tile2dArgs a)
     const int tr = blockIdx.x / a.tiles_c, tc = blockIdx.x % a.tiles_c;
     const int H = a.halo, Sr = a.tile_rows + 2 * H, Tc = kTileCols - 2 * H;
     const int R0 = tr * a.tile_rows - H, C0 = tc * Tc - H;   // global position of local cell (0, 0)
-    const int gc = C0 + lane;
-    const bool col_in = gc >= 0 && gc < a.pitch;
     auto at = [](int lr, int lc) { return (lr + 1) * kTileCols + lc; };
-    // local row of slot k of this wave -- red-black: the two rows of row pair wave + W i are slots 2 i, 2 i + 1; Jacobi: row wave + W k
-    auto slot_row = [&](int k) { return RB ? 2 * (wave + kTileWaves * (k >> 1)) + (k & 1) : wave + kTileWaves * k; };
+    // unit of pass i of this wave: wave + W i = (row pair | row) x CW + column block
+    auto unit_row = [&](int i) { return (wave + kTileWaves * i) / CW; };   // row pair (red-black) or row (Jacobi)
+    auto unit_blk = [&](int i) { return (wave + kTileWaves * i) % CW; };   // column block: local columns 64 blk .. 64 blk + 63
+    // local row of slot k of this wave -- red-black: the two rows of pass i's row pair are slots 2 i, 2 i + 1; Jacobi: slot = pass
+    auto slot_row = [&](int k) { return RB ? 2 * unit_row(k >> 1) + (k & 1) : unit_row(k); };
+    auto slot_blk = [&](int k) { return unit_blk(RB ? k >> 1 : k); };
 
     // ---- load: the tile with its ghost ring; cells outside the grid never change and are never read by a cell that does
     // (the grid's border is locked).  The locks of the rows a wave will update stay with it as LANE MASKS in scalar registers.
     lmask lockm[kSlots];
 #pragma unroll
     for (int k = 0; k < kSlots; ++k) {
-        const int lr = slot_row(k);
+        const int lr = slot_row(k), lc = 64 * slot_blk(k) + lane;
         lockm[k] = ~0ull;
         if (lr >= Sr) continue;   // wave-uniform
-        const int gr = R0 + lr;
-        const bool inside = col_in && gr >= 0 && gr < a.rows;
+        const int gr = R0 + lr, gc = C0 + lc;
+        const bool inside = gc >= 0 && gc < a.pitch && gr >= 0 && gr < a.rows;
         float v = -1e6f;
         uint32_t lk = 1;
         if (inside) {
@@ -119,19 +124,19 @@ __global__ __launch_bounds__(kTileThreads) void tile2d_kernel(Tile2dArgs a)
             lk = (a.maskw[mask_word_2d((unsigned)gr, (unsigned)gc, (unsigned)a.pitch)] >> mask_bit_2d((unsigned)gc)) & 1u;
         }
         lockm[k] = __builtin_amdgcn_ballot_w64(lk != 0);
-        u_lds[at(lr, lane)] = v;
+        u_lds[at(lr, lc)] = v;
         if (TOL) {
             const Split1 sp = tol_split1(v);
-            q_lds[at(lr, lane)] = sp.q;
-            n_lds[at(lr, lane)] = f2u(sp.zm);
+            q_lds[at(lr, lc)] = sp.q;
+            n_lds[at(lr, lc)] = f2u(sp.zm);
         }
     }
     if (threadIdx.x < 2 * kTileCols) {   // the pad rows: read by the (discarded) updates of the outermost ring only
-        const int lr = threadIdx.x < kTileCols ? -1 : Sr;
+        const int lr = threadIdx.x < kTileCols ? -1 : Sr, lc = threadIdx.x % kTileCols;
 #pragma unroll
         for (int b = 0; b < kBufs; ++b) {
-            u_lds[b * kPlane + at(lr, lane)] = -1e6f;
-            if (TOL) { q_lds[b * kPlane + at(lr, lane)] = 1.0f; n_lds[b * kPlane + at(lr, lane)] = kTolMagicBits; }
+            u_lds[b * kPlane + at(lr, lc)] = -1e6f;
+            if (TOL) { q_lds[b * kPlane + at(lr, lc)] = 1.0f; n_lds[b * kPlane + at(lr, lc)] = kTolMagicBits; }
         }
     }
     if (threadIdx.x == 0) wg_delta = 0;
@@ -141,8 +146,9 @@ __global__ __launch_bounds__(kTileThreads) void tile2d_kernel(Tile2dArgs a)
     else __syncthreads();
 
     // ---- K iterations on the tile
-    const int own_r0 = H, own_r1 = H + a.tile_rows;   // owned local rows [own_r0, own_r1), columns [H, 64 - H)
-    const lmask own_cols = (~0ull << H) & (~0ull >> H);
+    const int own_r0 = H, own_r1 = H + a.tile_rows;   // owned local rows [own_r0, own_r1), columns [H, width - H)
+    // lanes of column block blk whose local column lies in [lo, width - lo): the first block loses its first lo lanes, the last its last lo
+    auto cols_from = [&](int blk, int lo) -> lmask { return (blk == 0 ? ~0ull << lo : ~0ull) & (blk == CW - 1 ? ~0ull >> lo : ~0ull); };
     const int odd_lane = lane & 1;
     const bool want_delta = a.delta_bits != nullptr || a.tile_delta != nullptr;
     float dmax = 0.0f;
@@ -155,31 +161,33 @@ __global__ __launch_bounds__(kTileThreads) void tile2d_kernel(Tile2dArgs a)
         }
         // cells that still have four valid neighbours: local rows [lo, hi_r], columns [lo, 63 - lo]
         const int lo = j + 1, hi_r = Sr - 2 - j;
-        const lmask cols_ok = (~0ull << lo) & (~0ull >> lo);
         const bool check = want_delta && j == a.steps - 1;
         const int src = RB ? 0 : (j & 1) * kPlane, dst = RB ? 0 : ((j & 1) ^ 1) * kPlane;
         // red-black: the active cell of column gc in global row gr has (gr + gc + iteration) odd (harmonic_cpu.cpp:46-51); in a row
-        // pair that starts at an even local row the lanes with (lane + b) odd take the first row, the others the second
+        // pair that starts at an even local row the lanes with (lane + b) odd take the first row, the others the second (a column
+        // block starts at an even column)
         const int b = (R0 + C0 + a.parity + j) & 1;
         const lmask first_row = b ? ~kOddLanes : kOddLanes;
 #pragma unroll
         for (int i = 0; i < kPasses; ++i) {
             lmask upd, own;
             int p;
+            const int blk = unit_blk(i);
+            const lmask cols_ok = cols_from(blk, lo), own_cols = cols_from(blk, H);
             if (RB) {
-                const int r2 = 2 * (wave + kTileWaves * i);
+                const int r2 = 2 * unit_row(i);
                 const bool v0 = r2 >= lo && r2 <= hi_r, v1 = r2 + 1 >= lo && r2 + 1 <= hi_r;
                 if (!(v0 || v1)) continue;   // wave-uniform: the pair has gone stale (or lies beyond the tile)
                 const lmask lock = (lockm[2 * i] & first_row) | (lockm[2 * i + 1] & ~first_row);
                 upd = ((v0 ? first_row : 0ull) | (v1 ? ~first_row : 0ull)) & cols_ok & ~lock;
                 own = ((r2 >= own_r0 && r2 < own_r1 ? first_row : 0ull) | (r2 + 1 >= own_r0 && r2 + 1 < own_r1 ? ~first_row : 0ull)) & own_cols;
-                p = at(r2, lane) + ((odd_lane ^ b) ? 0 : kTileCols);
+                p = at(r2, 64 * blk + lane) + ((odd_lane ^ b) ? 0 : kTileCols);
             } else {
-                const int lr = wave + kTileWaves * i;
+                const int lr = unit_row(i);
                 if (lr < lo || lr > hi_r) continue;   // wave-uniform
                 upd = cols_ok & ~lockm[i];
                 own = lr >= own_r0 && lr < own_r1 ? own_cols : 0ull;
-                p = at(lr, lane);
+                p = at(lr, 64 * blk + lane);
             }
             const float c = u_lds[src + p];
             const float uu = u_lds[src + p - kTileCols], ud = u_lds[src + p + kTileCols], ul = u_lds[src + p - 1], ur = u_lds[src + p + 1];
@@ -210,11 +218,11 @@ __global__ __launch_bounds__(kTileThreads) void tile2d_kernel(Tile2dArgs a)
 
     // ---- store the owned cells (locked ones included: `out` is the other buffer)
     const int fin = RB ? 0 : (a.steps & 1) * kPlane;
-    const bool own_col = lane >= H && lane < kTileCols - H;
-    for (int lr = own_r0 + wave; lr < own_r1; lr += kTileWaves) {
-        const int gr = R0 + lr;
+    for (int unit = own_r0 * CW + wave; unit < own_r1 * CW; unit += kTileWaves) {   // (row, column block) units of the owned rows
+        const int lr = unit / CW, lc = 64 * (unit % CW) + lane;
+        const int gr = R0 + lr, gc = C0 + lc;
         if (gr >= a.rows) break;   // wave-uniform
-        if (own_col && gc < a.pitch) a.out[(size_t)gr * a.pitch + gc] = u_lds[fin + at(lr, lane)];
+        if (lc >= H && lc < kTileCols - H && gc < a.pitch) a.out[(size_t)gr * a.pitch + gc] = u_lds[fin + at(lr, lc)];
     }
     if (want_delta) {
         dmax = wave_max(dmax);
@@ -234,11 +242,12 @@ hipError_t launch_tile_2d(const float *in, float *out, const uint32_t *maskw, in
 {
     if (steps <= 0) return hipSuccess;
     if (!in || !out || in == out || !maskw || pitch <= 0 || (pitch % 256) != 0 || rows <= 0) return hipErrorInvalidValue;
-    if (plan.halo < 1 || steps > plan.halo || plan.tile_rows < 2 || plan.tile_rows + 2 * plan.halo > kTileMaxRows ||
-        plan.tile_cols != kTileCols - 2 * plan.halo || plan.tiles_r < 1 || plan.tiles_c < 1 ||
-        (long long)plan.tiles_r * plan.tile_rows < rows)
-        return hipErrorInvalidValue;
     if (math != kMathPrecise && math != kMathFast && math != kMathTol) return hipErrorInvalidValue;
+    const bool rb = parity >= 0;
+    const int width = plan.tile_cols + 2 * plan.halo, max_rows = tile_2d_max_rows(math, rb, width);
+    if (plan.halo < 1 || steps > plan.halo || plan.tile_rows < 2 || max_rows == 0 || plan.tile_rows + 2 * plan.halo > max_rows ||
+        plan.tile_cols < 8 || plan.tiles_r < 1 || plan.tiles_c < 1 || (long long)plan.tiles_r * plan.tile_rows < rows)
+        return hipErrorInvalidValue;
     Tile2dArgs a;
     a.in = in;
     a.out = out;
@@ -252,10 +261,15 @@ hipError_t launch_tile_2d(const float *in, float *out, const uint32_t *maskw, in
     a.tiles_c = plan.tiles_c;
     a.steps = steps;
     a.parity = parity < 0 ? 0 : (parity & 1);
-    const bool rb = parity >= 0;
-    void (*kernel)(Tile2dArgs) = math == kMathTol    ? (rb ? tile2d_kernel<kMathTol, true> : tile2d_kernel<kMathTol, false>)
-                                 : math == kMathFast ? (rb ? tile2d_kernel<kMathFast, true> : tile2d_kernel<kMathFast, false>)
-                                                     : (rb ? tile2d_kernel<kMathPrecise, true> : tile2d_kernel<kMathPrecise, false>);
+    void (*kernel)(Tile2dArgs);
+    if (width == kTile2dCols)
+        kernel = math == kMathTol    ? (rb ? tile2d_kernel<kMathTol, true, 1, 64> : tile2d_kernel<kMathTol, false, 1, 64>)
+                 : math == kMathFast ? (rb ? tile2d_kernel<kMathFast, true, 1, 64> : tile2d_kernel<kMathFast, false, 1, 64>)
+                                     : (rb ? tile2d_kernel<kMathPrecise, true, 1, 64> : tile2d_kernel<kMathPrecise, false, 1, 64>);
+    else
+        kernel = math == kMathTol    ? tile2d_kernel<kMathTol, true, 2, 64>   // (tol Jacobi has no wide tile: tile_2d_max_rows)
+                 : math == kMathFast ? (rb ? tile2d_kernel<kMathFast, true, 2, 128> : tile2d_kernel<kMathFast, false, 2, 128>)
+                                     : (rb ? tile2d_kernel<kMathPrecise, true, 2, 128> : tile2d_kernel<kMathPrecise, false, 2, 128>);
     hipLaunchKernelGGL(kernel, dim3((unsigned)(plan.tiles_r * plan.tiles_c)), dim3(kTileThreads), 0, stream, a);
     return hipGetLastError();
 }

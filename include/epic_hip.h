@@ -49,7 +49,7 @@ int epic_hip_timed_sweeps_gpu(EpicHarmonicT *harmonic, unsigned int sweeps, unsi
  * every check iteration run singly -- 1 otherwise, 0 without device state.  EPIC_HIP_NO_FUSE=1 switches the fusion off. */
 int epic_hip_iterations_per_pass(EpicHarmonicT *harmonic);
 
-/* Small 2-D grids (at most 0.5 Mcell, one device, activity tracking off -- the maps the reference's callers relax): the plain
+/* Small 2-D grids (at most 3 Mcell, one device, activity tracking off -- the maps the reference's callers relax): the plain
  * iterations between two checks run SEVERAL PER LAUNCH on tiles that stay in LDS with that many ghost rings
  * (epic_amd/csrc/kernels_tile2d.hip); bit-identical to single iterations.  Returns the iterations one such launch advances
  * (8 to 14, chosen per grid), 0 where the path is not used.  EPIC_HIP_TILE=0 switches it off; EPIC_HIP_TILE_HALO / _ROWS / _MAX_CELLS tune it. */

@@ -105,10 +105,30 @@ def test_any_halo_and_tile_height_gives_the_same_bits(halo, tile_rows, math, sch
     with env(EPIC_HIP_TILE="0"):
         want, wdelta = run_gpu(m, u0, locked, 31, math, scheme)
     for graph in (None, "1"):
-        with env(EPIC_HIP_TILE_HALO=halo, EPIC_HIP_TILE_ROWS=tile_rows or None, EPIC_HIP_NO_GRAPH=graph):
+        with env(EPIC_HIP_TILE_HALO=halo, EPIC_HIP_TILE_ROWS=tile_rows or None, EPIC_HIP_NO_GRAPH=graph, EPIC_HIP_TILE_WIDTH=64):
             got, gdelta = run_gpu(m, u0, locked, 31, math, scheme, expect_tile=True)
         assert np.array_equal(got, want), (halo, tile_rows, int((got != want).sum()))
         assert gdelta == wdelta
+
+
+@pytest.mark.parametrize("halo,tile_rows", [(1, 0), (3, 100), (8, 0), (8, 40), (14, 0), (16, 96), (30, 60), (55, 10)])
+@pytest.mark.parametrize("math,scheme", MODES)
+@pytest.mark.parametrize("m,seed", [([150, 203], 21), ([300, 130], 5), ([257, 513], 9)])
+def test_wide_tiles_give_the_same_bits(m, seed, halo, tile_rows, math, scheme):
+    """The 128-column LDS tile of the 1-4 Mcell grids (two column blocks of 64 lanes, up to 128 rows; the tol math has it for
+    red-black only, up to 64 rows): the same bits as the per-iteration kernels for any ring depth and tile height."""
+    wide = not (math == eh.MATH_TOL and scheme == eh.SCHEME_JACOBI)
+    if math == eh.MATH_TOL and tile_rows + 2 * halo > 64:
+        tile_rows = 0
+    if math == eh.MATH_TOL and halo > 27:
+        halo = 27
+    u0, locked = seeded(m, seed, 0.08)
+    with env(EPIC_HIP_TILE="0"):
+        want, wdelta = run_gpu(m, u0, locked, 33, math, scheme)
+    with env(EPIC_HIP_TILE_HALO=halo, EPIC_HIP_TILE_ROWS=tile_rows or None, EPIC_HIP_TILE_WIDTH=128):
+        got, gdelta = run_gpu(m, u0, locked, 33, math, scheme, expect_tile=wide)
+    assert np.array_equal(got, want), (halo, tile_rows, int((got != want).sum()))
+    assert gdelta == wdelta
 
 
 @pytest.mark.parametrize("m,seed,dens", [([23, 37], 4, 0.10), ([130, 256], 11, 0.05), ([257, 513], 9, 0.05)])

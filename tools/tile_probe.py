@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--mode", default="default")
     ap.add_argument("--halo", default="1,2,4,8,12")
     ap.add_argument("--rows", default="0")
+    ap.add_argument("--width", default="0", help="64 | 128: the LDS tile's width (0: the library's choice)")
     ap.add_argument("--iters", type=int, default=4800)
     ap.add_argument("--develop", type=int, default=3000)
     args = ap.parse_args()
@@ -42,6 +43,8 @@ def main():
     assert E.epic_hip_timed_sweeps_gpu(h, args.iters, 0, ct.byref(ms)) == 0
     print(f"{args.map} {list(h.shape)} {args.mode}: per-iteration kernels (eager) {ms.value / args.iters * 1e3:.3f} us/iteration", flush=True)
     os.environ["EPIC_HIP_TILE"] = "1"
+    if args.width != "0":
+        os.environ["EPIC_HIP_TILE_WIDTH"] = args.width
     for halo in [int(x) for x in args.halo.split(",")]:
         for rows in [int(x) for x in args.rows.split(",")]:
             os.environ["EPIC_HIP_TILE_HALO"] = str(halo)
