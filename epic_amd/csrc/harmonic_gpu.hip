@@ -754,9 +754,10 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first, bool check_
 // with TRACK; the check is the second iteration of the last pair).  Against in-place half-sweeps with lists: half the launches
 // (10-12 us each with next to nothing due, a quarter of all iterations of the 8192^2 relaxation), and a listed tile moves through
 // HBM once for two iterations instead of twice.  EPIC_HIP_TRACK_PAIRS=0: the half-sweeps, as before round 4.
-bool rb_pairs_tracked(const Ctx *c)
+bool rb_pairs_tracked(const Ctx *c)   // (the name is round 4's first form: red-black, precise; the tol passes -- both schemes -- followed)
 {
-    if (!c->track || !c->redblack || c->n != 2 || c->multi() || c->math == 4 || c->math == 2) return false;
+    if (!c->track || c->n != 2 || c->multi() || c->math == 2) return false;
+    if (!c->redblack && c->math != 4) return false;   // precise Jacobi has no fused pass
     if (getenv("EPIC_HIP_NO_FUSE") != nullptr) return false;
     const char *e = getenv("EPIC_HIP_TRACK_PAIRS");
     if (e && e[0] == '0') return false;
@@ -793,7 +794,8 @@ void rb_pairs_choose_rows(Ctx *c)
 // device delta word is zeroed and filled).  bypass: without the lists (every tile; the untracked pass's own task height).
 hipError_t enqueue_rb_pairs_tracked(Ctx *c, unsigned npairs, unsigned first, bool check_last, bool bypass)
 {
-    const int rpt = bypass ? fused_rows_per_task(c) : rb_pairs_rows_per_task(c);
+    const bool tol = c->math == 4;
+    const int rpt = !bypass ? rb_pairs_rows_per_task(c) : tol ? jacobi_fused_rows_per_task(c) : fused_rows_per_task(c);
     const size_t tiles = epic_hip::rb_fused_2d_tiles(c->rows, c->pitch, rpt);
     for (unsigned p = 0; p < npairs; ++p) {
         const bool check = check_last && p + 1 == npairs;
@@ -805,9 +807,11 @@ hipError_t enqueue_rb_pairs_tracked(Ctx *c, unsigned npairs, unsigned first, boo
             if (c->last_lists != 2) c->trk_f.force = std::max(c->trk_f.force, 1);     // something else has touched the field since
             act = c->trk_f.next(tiles, rpt, c->stream, nullptr);
         }
-        e = epic_hip::launch_rb_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch, rpt, c->math,
-                                         (int)((first + 2 * p) & 1u), c->stream, c->maskf(), act.list_out ? &act : nullptr,
-                                         check ? c->d_delta : nullptr);
+        const int parity = (int)((first + 2 * p) & 1u);
+        e = tol ? epic_hip::launch_jacobi_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch, rpt, c->math, c->stream,
+                                                   c->redblack ? parity : -1, c->maskf(), act.list_out ? &act : nullptr, check ? c->d_delta : nullptr)
+                : epic_hip::launch_rb_fused_2d(c->buf[c->cur], c->buf[c->cur ^ 1], c->maskw, c->rows, c->pitch, rpt, c->math, parity, c->stream,
+                                               c->maskf(), act.list_out ? &act : nullptr, check ? c->d_delta : nullptr);
         if (e != hipSuccess) return e;
         if (!act.list_in) c->work_full += 2.0;   // every tile ran
         if (act.list_out) { c->trk_f.advance(); c->last_lists = 2; }
@@ -2156,7 +2160,7 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
             if (pe == hipSuccess) {
                 rb_pairs_choose_rows(c);
                 const bool bypass = bypass_lists_for_batch(c, true);
-                if (bypass) tune_fused_rows(c, 2, harmonic->currentIteration);   // the untracked pass's task height, measured once per grid
+                if (bypass) tune_fused_rows(c, c->math != 4 ? 2 : c->redblack ? 1 : 0, harmonic->currentIteration);   // the untracked pass's task height, measured once per grid
                 pe = enqueue_rb_pairs_tracked(c, (total - done) / 2, harmonic->currentIteration + done, true, bypass);
             }
             if (pe != hipSuccess) {

@@ -68,8 +68,11 @@ inline size_t rb_fused_2d_tiles(int rows, int pitch, int rows_per_task)
 // Two iterations in one pass (tol math only): in = u_k, out = u_{k+2}; in != out.  parity < 0: Jacobi; 0 / 1: the reference's
 // red-black scheme, parity = the first iteration's number & 1 (both colours are swept, the first one first).
 // maskf (may be null): the masks in the fused layout below -- saves the pass a funnel shift of two mask words per row.
+// act (may be null): work lists of THIS pass's tiling (rb_fused_2d_tiles() tiles; needs maskf); delta_bits (may be null): max |du| of
+// the second of the two iterations (zero it first; needs maskf).
 hipError_t launch_jacobi_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
-                                  int math, hipStream_t stream, int parity = -1, const uint32_t *maskf = nullptr);
+                                  int math, hipStream_t stream, int parity = -1, const uint32_t *maskf = nullptr,
+                                  const Activity *act = nullptr, unsigned *delta_bits = nullptr);
 // Fused layout: a fused pass cuts a row into strips of 248 columns, lane L of strip S holding columns 248 S - 4 + 4 L .. + 3
 // (lanes 0 and 63 are halo lanes); per row and such strip four 64-bit words as in the standard layout (bit L of word j =
 // cell 4 L + j of that mapping).  Derived from the standard masks after every upload and every edit.

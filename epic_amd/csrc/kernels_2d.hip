@@ -664,17 +664,33 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
 // with (row + col + it + 1) odd from the level-A rows; a cell that a level does not touch passes through it.  Every
 // cell is recomputed once per pass (4 B of HBM traffic per cell-update against 16 for the in-place half-sweep), the rows
 // are split twice (before level A, and after it for level B).  Bit-identical to two in-place half-sweeps.
-template <bool RB, bool FMASK>
+template <bool RB, bool FMASK, bool TRACK = false, bool CHECK = false>
 __device__ __forceinline__ void tol_fused_pass(const Sweep2dArgs &a, TolLnEntry *math_lds)
 {
     TolLn<4>::stage(math_lds);  // the whole workgroup, one barrier: before any wave may find itself without a task
     const TolLnEntry *const tl = math_lds;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // the launch holds as many workgroups as the chip keeps resident; each walks its share of the logical blocks
-    for (int vb = blockIdx.x; vb < a.nblocks; vb += gridDim.x) {
-    const int task = xcd_contiguous_block(vb, a.nblocks) * kWavesPerBlock + wave;
-    if (task >= a.ntasks) continue;
+    // TRACK (round 4): the pass with work lists of its own tiling, exactly as rb_fused2d_kernel has them (see there: which tiles
+    // a task wakes, why a skipped tile holds the right values in both buffers); CHECK: max |du| of the pass's SECOND iteration.
+    if (TRACK) wake_reset_next(a.wake);
+    const bool listed = TRACK && a.wake.list_in != nullptr;
+    WakeCursor cursor = {};
+    float dmax = 0.0f;
+    const bool have_work = !listed || wake_begin(a.wake, lane, wave, kWavesPerBlock, cursor);
+    // the launch holds as many workgroups as the chip keeps resident; each walks its share of the logical blocks (or of the lists)
+    if (have_work)
+    for (int vb = blockIdx.x;;) {
+    int task;
+    if (listed) task = wake_tile(a.wake, cursor);
+    else task = xcd_contiguous_block(vb, a.nblocks) * kWavesPerBlock + wave;
+    if (task >= a.ntasks) {
+        if (listed) break;
+        vb += gridDim.x;
+        if (vb >= a.nblocks) break;
+        continue;
+    }
+    if (TRACK && lane == 0) a.wake.queued_in[task] = 0;
     const int strip = task % a.nstrips;
     const int chunk = task / a.nstrips;
     const int r0 = a.row_begin + chunk * a.rows_per_task;
@@ -682,6 +698,10 @@ __device__ __forceinline__ void tol_fused_pass(const Sweep2dArgs &a, TolLnEntry 
     const int col = strip * kFusedOut - kColsPerLane + lane * kColsPerLane;  // lane 0 = left halo lane
     const int lcol = min(max(col, 0), a.pitch - kColsPerLane);
     const bool owner = lane >= 1 && lane <= kWave - 2 && col < a.pitch;
+    const lmask owners = (TRACK || CHECK) ? __builtin_amdgcn_ballot_w64(owner) : 0;
+    lmask chg_any = 0, chg_top = 0, chg_bot = 0;   // what this task changed (TRACK): lane masks and flags in scalar registers
+    bool chg_left = false, chg_right = false, c_tl = false, c_tr = false, c_bl = false, c_br = false;
+    constexpr lmask kFirstOwned = 2ull, kLastOwned = 1ull << (kWave - 2);   // lanes 1 and 62
     const int rlast = a.rows - 1;
     const size_t pitch = (size_t)a.pitch;
     typedef unsigned vu4 __attribute__((ext_vector_type(4)));
@@ -741,8 +761,9 @@ __device__ __forceinline__ void tol_fused_pass(const Sweep2dArgs &a, TolLnEntry 
     auto shl = [](float v) { return u2f(__builtin_amdgcn_mov_dpp(f2u(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true)); };  // from the left
     auto shr = [](float v) { return u2f(__builtin_amdgcn_mov_dpp(f2u(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true)); };  // from the right
     // (red-black: `odd_cols` says which half of the row this level recomputes -- .y / .w or .x / .z; scalar)
+    // row: the row this level recomputes; second: level B (the pass's second iteration); owned: the row belongs to this task
     auto level = [&](const float4 &up, const float4 &c, const float4 &dn, const Split4 &su, const Split4 &sc, const Split4 &sd,
-                     const RowMask &k, bool odd_cols) -> float4 {
+                     const RowMask &k, bool odd_cols, int row, bool second, bool owned) -> float4 {
         float4 o = c;
         // the cells this level updates, two at a time in the three phases of cell_update.h: the table reads of one pair are in
         // flight while the other pair is worked on
@@ -786,6 +807,25 @@ __device__ __forceinline__ void tol_fused_pass(const Sweep2dArgs &a, TolLnEntry 
             o.y = sel(k.m1, c.y, ny);
             o.w = sel(k.m3, c.w, nw);
         }
+        if (CHECK && second) {
+            const float d = max2(max2(fabsf(c.x - o.x), fabsf(c.y - o.y)), max2(fabsf(c.z - o.z), fabsf(c.w - o.w)));
+            dmax = max2(dmax, sel(owners, d, 0.0f));
+        }
+        if (TRACK && owned) {   // (scalar throughout; a cell the level does not touch compares equal)
+            const lmask e0 = lanes_ne(o.x, c.x) | lanes_ne(o.y, c.y), e1 = lanes_ne(o.z, c.z) | lanes_ne(o.w, c.w);
+            const lmask rc = (e0 | e1) & owners;
+            chg_any |= rc;
+            if (row < r0 + 2) chg_top |= rc;
+            if (row >= r1 - 2) chg_bot |= rc;
+            // next to the left neighbour: lane 1's x and y; next to the right one: lane 62's z and w; corner cells: lane 1's x, lane 62's w
+            chg_left |= (e0 & kFirstOwned) != 0;
+            chg_right |= (e1 & kLastOwned & owners) != 0;
+            if (row == r0 || row == r1 - 1) {
+                const bool cl = (lanes_ne(o.x, c.x) & kFirstOwned) != 0, cr = (lanes_ne(o.w, c.w) & kLastOwned & owners) != 0;
+                if (row == r0) { c_tl |= cl; c_tr |= cr; }
+                if (row == r1 - 1) { c_bl |= cl; c_br |= cr; }
+            }
+        }
         return o;
     };
     // which half a level recomputes in row `row`: level A belongs to iteration a.parity, level B to the one after it; the
@@ -802,10 +842,10 @@ __device__ __forceinline__ void tol_fused_pass(const Sweep2dArgs &a, TolLnEntry 
     for (int x = 0; x < 6; ++x) u[x] = ld(min(r0 - 2 + x, r1 + 1));
     k[0] = row_mask(r0 - 1); k[1] = row_mask(r0); k[2] = row_mask(r0 + 1);
     su[0] = tol_split4(u[0]); su[1] = tol_split4(u[1]); su[2] = tol_split4(u[2]);
-    m[0] = level(u[0], u[1], u[2], su[0], su[1], su[2], k[0], odd_cols_of(r0 - 1, 0));   // level A of row r0 - 1
+    m[0] = level(u[0], u[1], u[2], su[0], su[1], su[2], k[0], odd_cols_of(r0 - 1, 0), r0 - 1, false, false);   // level A of row r0 - 1
     sm[0] = tol_split4(m[0]);
     su[0] = tol_split4(u[3]);                                    // the split of row r0 - 2 is done with
-    m[1] = level(u[1], u[2], u[3], su[1], su[2], su[0], k[1], odd_cols_of(r0, 0));   // level A of row r0
+    m[1] = level(u[1], u[2], u[3], su[1], su[2], su[0], k[1], odd_cols_of(r0, 0), r0, false, true);   // level A of row r0
     sm[1] = tol_split4(m[1]);
     const int nrows = r1 - r0;
     // (red-black: the half a level recomputes is a scalar test per level.  Two straight-line versions of the trip, chosen by
@@ -820,17 +860,41 @@ __device__ __forceinline__ void tol_fused_pass(const Sweep2dArgs &a, TolLnEntry 
                 const RowMaskRaw kraw = mask_fetch(r + 2);                       // cut at the end of the step
                 su[(j + 1) % 3] = tol_split4(u[(j + 4) % 6]);                    // row r + 2 (slot of row r - 1's split)
                 m[(j + 2) % 3] = level(u[(j + 2) % 6], u[(j + 3) % 6], u[(j + 4) % 6], su[(j + 2) % 3], su[j % 3],
-                                       su[(j + 1) % 3], k[(j + 2) % 3], odd_cols_of(r + 1, 0));   // level A of row r + 1
+                                       su[(j + 1) % 3], k[(j + 2) % 3], odd_cols_of(r + 1, 0), r + 1, false, r + 1 < r1);   // level A of row r + 1
                 sm[(j + 2) % 3] = tol_split4(m[(j + 2) % 3]);
                 const float4 x = level(m[j % 3], m[(j + 1) % 3], m[(j + 2) % 3], sm[j % 3], sm[(j + 1) % 3], sm[(j + 2) % 3],
-                                       k[(j + 1) % 3], odd_cols_of(r, 1));       // level B of row r
+                                       k[(j + 1) % 3], odd_cols_of(r, 1), r, true, true);       // level B of row r
                 k[j % 3] = mask_cut(kraw);                                       // slot of row r - 1's masks
                 store_row(rout, x.x, x.y, x.z, x.w, store_off, row_off(r));
             }
         };
         unrolled<kTrip>(step);
     }
-    }  // logical blocks
+    if (TRACK) {
+        // wake the tiles that read what this task changed: itself, the four across its edges, the four across its corners
+        const int nchunks = a.nchunks;
+        const bool up_ok = chunk > 0, dn_ok = chunk + 1 < nchunks, lf_ok = strip > 0, rt_ok = strip + 1 < a.nstrips;
+        int t = task;
+        bool want = chg_any != 0;
+        if (lane == 1) { t = task - 1; want = lf_ok && chg_left; }
+        if (lane == 2) { t = task + 1; want = rt_ok && chg_right; }
+        if (lane == 3) { t = task - a.nstrips; want = up_ok && chg_top != 0; }
+        if (lane == 4) { t = task + a.nstrips; want = dn_ok && chg_bot != 0; }
+        if (lane == 5) { t = task - a.nstrips - 1; want = up_ok && lf_ok && c_tl; }
+        if (lane == 6) { t = task - a.nstrips + 1; want = up_ok && rt_ok && c_tr; }
+        if (lane == 7) { t = task + a.nstrips - 1; want = dn_ok && lf_ok && c_bl; }
+        if (lane == 8) { t = task + a.nstrips + 1; want = dn_ok && rt_ok && c_br; }
+        wake_push(a.wake, t, want && lane < 9);
+    }
+    if (listed) { if (!wake_next(cursor)) break; }
+    else { vb += gridDim.x; if (vb >= a.nblocks) break; }
+    }  // tasks
+    if (CHECK) {
+        dmax = wave_max(dmax);
+        if (lane == 0 && dmax > 0.0f &&
+            __float_as_uint(dmax) > __hip_atomic_load(a.delta_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(a.delta_bits, __float_as_uint(dmax));
+    }
 }
 
 template <int MATH, bool FMASK>
@@ -847,6 +911,16 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, EPIC_FUSED_MIN_WAVES) void 
 {
     __shared__ TolLnEntry math_lds[TolLn<4>::kEntries];
     tol_fused_pass<true, FMASK>(a, math_lds);
+}
+
+// the same passes with work lists (TRACK) and / or the max |du| of their second iteration (CHECK): instantiations of their own, so
+// that the plain ones keep their registers (these ask for three waves per SIMD instead of four: the change masks and the running
+// maximum need a few registers more, and no sweep kernel may use scratch)
+template <bool RB, bool TRACK, bool CHECK>
+__global__ __launch_bounds__(kWave * kWavesPerBlock, 3) void tol_fused2d_tracked_kernel(Sweep2dArgs a)
+{
+    __shared__ TolLnEntry math_lds[TolLn<4>::kEntries];
+    tol_fused_pass<RB, true, TRACK, CHECK>(a, math_lds);   // (needs the fused mask layout: the library always has it)
 }
 
 // The masks of a grid cut for the fused passes' lane -> column mapping (kernels.h: fused layout), from the standard lane
@@ -1140,10 +1214,11 @@ hipError_t launch_fuse_masks_2d(const uint32_t *maskw, int rows, int pitch, uint
 }
 
 hipError_t launch_jacobi_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
-                                  int math, hipStream_t stream, int parity, const uint32_t *maskf)
+                                  int math, hipStream_t stream, int parity, const uint32_t *maskf, const Activity *act, unsigned *delta_bits)
 {
     if (pitch <= 0 || (pitch % 256) != 0 || rows <= 0 || rows_per_task <= 0 || in == out) return hipErrorInvalidValue;
     if (math != kMathTol) return hipErrorInvalidValue;
+    if ((act || delta_bits) && !maskf) return hipErrorInvalidValue;   // the tracked / checked instantiations take the fused mask layout
     // 32-bit byte offsets from a base 2 rows above the task (rows_per_task + 7 rows): as launch_sweep_2d clamps its tasks
     const long long max_rows = 0x7fffffffLL / ((long long)pitch * 4) - 8;
     if (max_rows < 1) return hipErrorInvalidValue;
@@ -1154,24 +1229,35 @@ hipError_t launch_jacobi_fused_2d(const float *in, float *out, const uint32_t *m
     a.maskw = maskw;
     a.maskf = nullptr;
     a.check_lo = a.check_hi = 0;
-    a.delta_bits = nullptr;
+    a.delta_bits = delta_bits;
     a.rows = rows;
     a.pitch = pitch;
     a.row_begin = 0;
     a.row_end = rows;
     a.rows_per_task = rows_per_task;
     a.nstrips = (pitch + kFusedOut - 1) / kFusedOut;
-    a.ntasks = a.nstrips * ((rows + rows_per_task - 1) / rows_per_task);
+    a.nchunks = (rows + rows_per_task - 1) / rows_per_task;
+    a.ntasks = a.nstrips * a.nchunks;
     a.parity = parity < 0 ? 0 : parity & 1;
     a.flags = sweep_flags();
-    a.nchunks = 0;
-    a.wake = wake_args(nullptr, 0);
+    a.wake = wake_args(act, (size_t)a.ntasks);
     a.nblocks = (a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock;
     a.maskf = maskf;
-    void (*kernel)(Sweep2dArgs) = parity < 0 ? (maskf ? jacobi_fused2d_kernel<kMathTol, true> : jacobi_fused2d_kernel<kMathTol, false>)
-                                             : (maskf ? rb_tol_fused2d_kernel<true> : rb_tol_fused2d_kernel<false>);
-    const dim3 grid(resident_grid(a.nblocks, (const void *)kernel)), block(kWave * kWavesPerBlock);
-    hipLaunchKernelGGL(kernel, grid, block, 0, stream, a);
+    const bool track = a.wake.list_out != nullptr, check = delta_bits != nullptr, rb = parity >= 0;
+    void (*kernel)(Sweep2dArgs);
+    if (!track && !check)
+        kernel = !rb ? (maskf ? jacobi_fused2d_kernel<kMathTol, true> : jacobi_fused2d_kernel<kMathTol, false>)
+                     : (maskf ? rb_tol_fused2d_kernel<true> : rb_tol_fused2d_kernel<false>);
+    else if (rb)
+        kernel = track ? (check ? tol_fused2d_tracked_kernel<true, true, true> : tol_fused2d_tracked_kernel<true, true, false>)
+                       : tol_fused2d_tracked_kernel<true, false, true>;
+    else
+        kernel = track ? (check ? tol_fused2d_tracked_kernel<false, true, true> : tol_fused2d_tracked_kernel<false, true, false>)
+                       : tol_fused2d_tracked_kernel<false, false, true>;
+    // resident workgroups walk the logical blocks (every workgroup stages the table once); with lists: persistent waves
+    const int nblocks = track && a.wake.list_in ? sweep_2d_list_blocks((size_t)a.ntasks, resident_blocks_of((const void *)kernel))
+                                                : resident_grid(a.nblocks, (const void *)kernel);
+    hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(kWave * kWavesPerBlock), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -165,6 +165,8 @@ int main(int argc, char **argv)
         {"node, 3-D", {5, 6, 7}, 1e-3f, 4, seq_node, {}},
         {"plugin, 2-D, work lists", {40, 300}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_TRACK", "1"}}},
         {"plugin, 2-D, tracked pairs of fused passes", {40, 300}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_TRACK", "1"}, {"EPIC_HIP_FUSE_MIN_CELLS", "0"}}},
+        {"plugin, 2-D, tracked pairs, tol red-black", {40, 300}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_TRACK", "1"}, {"EPIC_HIP_FUSE_MIN_CELLS", "0"}, {"EPIC_HIP_MATH", "tol"}}},
+        {"plugin, 2-D, tracked pairs, tol Jacobi", {40, 300}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_TRACK", "1"}, {"EPIC_HIP_FUSE_MIN_CELLS", "0"}, {"EPIC_HIP_MATH", "tol"}, {"EPIC_HIP_SCHEME", "jacobi"}}},
         {"plugin, 2-D, tracked pairs, odd count", {40, 300}, 1e-3f, 7, seq_plugin, {{"EPIC_HIP_TRACK", "1"}, {"EPIC_HIP_FUSE_MIN_CELLS", "0"}}},
         {"plugin, 2-D, tol Jacobi (handover and finish rules)", {20, 30}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_MATH", "tol"}, {"EPIC_HIP_SCHEME", "jacobi"}}},
         {"plugin, 2-D, tol fused pairs", {24, 300}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_MATH", "tol"}, {"EPIC_HIP_SCHEME", "jacobi"}, {"EPIC_HIP_FUSE_MIN_CELLS", "0"}}},

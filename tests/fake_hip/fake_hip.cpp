@@ -247,7 +247,11 @@ hipError_t launch_rb_fused_2d(const float *, float *, const uint32_t *, int, int
     FAKE_LAUNCH("launch_rb_fused_2d");
     return hipSuccess;
 }
-hipError_t launch_jacobi_fused_2d(const float *, float *, const uint32_t *, int, int, int, int, hipStream_t, int, const uint32_t *) { FAKE_LAUNCH("launch_jacobi_fused_2d"); return hipSuccess; }
+hipError_t launch_jacobi_fused_2d(const float *, float *, const uint32_t *, int, int, int, int, hipStream_t, int, const uint32_t *, const Activity *, unsigned *)
+{
+    FAKE_LAUNCH("launch_jacobi_fused_2d");
+    return hipSuccess;
+}
 hipError_t launch_fuse_masks_2d(const uint32_t *, int, int, uint32_t *, hipStream_t) { FAKE_LAUNCH("launch_fuse_masks_2d"); return hipSuccess; }
 hipError_t launch_eval_math(const float *, float *, size_t, int, hipStream_t) { FAKE_LAUNCH("launch_eval_math"); return hipSuccess; }
 hipError_t launch_pack_mask_2d(const uint32_t *locked, int rows, int cols, int, int, int, uint32_t *, hipStream_t)

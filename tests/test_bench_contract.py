@@ -7,7 +7,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = ["profiles/r03_bench_line_n1.json", "profiles/r03_bench_line_n2_gloo_one_gpu.json"]
+LINES = ["profiles/r04_bench_line_n1.json", "profiles/r04_bench_line_n2_gloo_one_gpu.json"]
 
 
 def load(rel):
@@ -35,7 +35,9 @@ def test_line_has_the_contract_keys(rel):
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    # `bound` names what limits the kernel as MEASURED ("valu" for the fused pass: the SQ counters of the run); achieved / peak / unit
+    # / frac stay the algorithmic-bytes figure the metric defines, the physical one is hbm_frac_measured
+    assert r["bound"] in ("valu", "hbm") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # achieved = algorithmic bytes per launch / launch duration
     assert abs(r["achieved"] - r["bytes_per_launch"] / (r["launch_us"] * 1e-6) / 1e9) < 0.01 * r["achieved"]
@@ -56,7 +58,12 @@ def test_single_gpu_line_roofline_is_the_fused_pass_and_has_a_cpu_baseline():
     # the algorithmic figure never travels without the measured one: HBM bytes per launch (PMC) / launch duration / peak
     assert abs(r["hbm_GBps_measured"] - r["traffic"] / (r["launch_us"] * 1e-6) / 1e9) < 0.01 * r["hbm_GBps_measured"]
     assert abs(r["hbm_frac_measured"] - r["hbm_GBps_measured"] / r["peak"]) < 1e-3 and r["hbm_frac_measured"] < r["frac"]
-    assert r["limiter"] == "valu"
+    assert r["limiter"] == "valu" and r["bound"] == "valu"
+    # ... and evidenced in the line itself: VALU instructions issued against the cycles the shader engines were busy, a child pass
+    # of this command under rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES
+    assert 0.80 < r["valu_issue_frac"] <= 1.0 and r["valu_issue_frac"] > r["hbm_frac_measured"] / 0.7875   # busier than HBM against its achievable 6.3 TB/s
+    assert abs(r["valu_issue_frac"] - 4.0 / r["valu_cycles_per_instruction"]) < 1e-3 and 30 < r["valu_insts_per_cell_update"] < 45
+    assert r["valu_source"].startswith("measured in this run")
     # traffic is measured in the run itself (two rocprofv3 --pmc child passes) and agrees with the profiling round's summary
     recorded = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))["8192_tol_jacobi_fused"]
     assert r["traffic_source"].startswith("measured in this run") and abs(r["traffic"] - recorded) < 0.03 * recorded
@@ -74,7 +81,9 @@ def test_relaxation_legs_separate_recomputed_from_effective_rates():
     free = d["config"]["free_cells"] if "free_cells" in d["config"] else None
     assert d["relax"]["finishing_iterations"] > 0 and d["relax_tol_alone"]["finishing_iterations"] == 0
     assert d["relax_default"]["finishing_iterations"] == 0          # the default IS the reference's iteration from the start
-    for leg in ("relax", "relax_redblack", "relax_untracked", "relax_default", "relax_tol_alone"):
+    # `relax` is the fastest way to a converged field with the timed arithmetic (red-black); the timed scheme's is relax_jacobi
+    assert d["relax"]["scheme"] == "redblack" and d["relax_jacobi"]["scheme"] == "jacobi" and d["relax"]["seconds"] < d["relax_jacobi"]["seconds"]
+    for leg in ("relax", "relax_jacobi", "relax_untracked", "relax_default", "relax_tol_alone"):
         x = d[leg]
         for key in ("math", "scheme", "activity_tracking", "iterations", "seconds", "delta", "grid_iterations_run",
                     "recomputed_Mcell_updates_per_s", "effective_Mcell_updates_per_s"):
@@ -117,3 +126,32 @@ def test_parity_object_names_every_baseline_config_and_its_misses():
     assert um["max_rel"] < 3e-6 and um["within_bar"] is True
     assert um["tol_iteration_alone"]["within_bar"] is False and 1e-5 < um["tol_iteration_alone"]["max_rel"] < 2e-5
     assert cfgs["configs[2] 8192x8192 (the timed grid)"]["max_rel"] < 2e-6
+
+
+def test_round_4_legs_config5_config4_maps_and_the_callers_epsilon():
+    d = load(LINES[0])
+    # config5 (512^3) has a roofline object of its own, with traffic and the VALU figures measured in the run
+    c5 = d["config5"]
+    r5 = c5["roofline"]
+    assert r5["kernel"] == c5["kernel"] == "sweep3d_pair_kernel" and r5["bytes_per_launch"] == 8 * 512 ** 3
+    assert abs(r5["frac"] - c5["frac"]) < 1e-3 and 0.45 < r5["frac"] < 0.75
+    assert r5["traffic"] is not None and r5["traffic_source"].startswith("measured in this run") and r5["traffic"] > r5["bytes_per_launch"]
+    assert 0.5 < r5["valu_issue_frac"] <= 1.0
+    assert c5["precise"]["us_per_sweep"] > c5["us_per_sweep"]          # the bit-exact 3-D sweep is reported beside it
+    # config4: BASELINE configs[3]'s grid on one GPU
+    c4 = d["config4"]
+    assert "32768" in c4["workload"] and c4["iterations_per_launch"] == 2 and 0.6 < c4["frac"] < 0.95
+    assert abs(c4["frac"] - 8.0 * 32768 ** 2 * 2 / (c4["launch_us"] * 1e-6) / 1e9 / 8000.0) < 1e-3
+    # the reference's maps as the plugin relaxes them, with the reference's CPU time beside them
+    m = d["maps"]
+    for name in ("maze", "umass", "basic"):
+        for key in ("%s default eps 1e-06" % name, "%s default eps 0.001" % name):
+            e = m[key]
+            assert e["iterations"] == e["reference_iterations"] and e["reference_cpu_seconds"] > 100 * e["seconds"], key
+    assert m["maze default eps 1e-06"]["seconds"] < 0.10 and m["umass default eps 1e-06"]["seconds"] < 0.20
+    # parity at the epsilon the reference's callers use: the same stop as the reference, within the bar
+    cfgs = d["parity"]["configs"]
+    at_callers = {k: v for k, v in cfgs.items() if "callers' eps" in k}
+    assert len(at_callers) >= 4
+    for k, v in at_callers.items():
+        assert v["same_iterations"] is True and v["within_bar"] is True and v["max_rel"] < 1e-5, k

@@ -119,3 +119,42 @@ def test_8192_default_relaxation_pairs_against_half_sweeps(record_property):
     record_property("seconds_pairs", secs[None])
     record_property("seconds_half_sweeps", secs["0"])
     print("8192^2 default relaxation incl. upload: pairs %.3f s, half-sweeps %.3f s" % (secs[None], secs["0"]))
+
+
+@pytest.mark.parametrize("rows,switch", [(None, None), (4, "2"), (7, "0"), (33, "2")])
+@pytest.mark.parametrize("scheme", ["redblack", "jacobi"])
+@pytest.mark.parametrize("n", [512, 1024])
+def test_tol_relaxations_through_tracked_pairs_equal_the_half_sweep_path(n, scheme, rows, switch):
+    """The tol passes (Jacobi and red-black) with work lists and the check as their second iteration: the whole relaxation --
+    tol phase, finishing phase, Jacobi handover rule -- gives the bits of the same relaxation through list-driven single sweeps
+    (EPIC_HIP_TRACK_PAIRS=0), which tests/test_gpu_tol.py holds to oracle/tol_checker.c."""
+    u0, locked = synthetic_grid([n, n])
+    out = {}
+    for pairs in (None, "0"):
+        h = Harmonic()
+        h.set_grid([n, n], u0, locked)
+        h.epsilon, h.numIterationsToStaggerCheck = 1e-6, 100
+        base = dict(EPIC_HIP_MATH="tol", EPIC_HIP_TILE="0", EPIC_HIP_TRACK="1", EPIC_HIP_FUSE_MIN_CELLS="0", EPIC_HIP_TRACK_PAIRS=pairs,
+                    EPIC_HIP_TRACK_PAIR_ROWS=rows if pairs is None else None, EPIC_HIP_TRACK_SWITCH=switch if pairs is None else None)
+        with scheme_env(scheme), env(**base):
+            assert E.harmonic_complete_gpu(h, 1024) == 0
+        out[pairs] = (int(h.currentIteration), float(h.delta), hashlib.sha256(h.u_array().tobytes()).hexdigest())
+    assert out[None] == out["0"], out
+
+
+@pytest.mark.parametrize("scheme", ["redblack", "jacobi"])
+@pytest.mark.parametrize("name", ["g2d_64", "g2d_70x66_dense", "g2d_8x300", "g2d_23x37"])
+def test_tol_tracked_pairs_equal_the_checkers_loop(goldens, name, scheme):
+    import ctypes as ct
+
+    g, info = goldens["small"], goldens["manifest"]["small"][name]
+    m = [int(x) for x in g[name + "/m"]]
+    p = O.Problem(m, g[name + "/u0"], g[name + "/locked"], info["epsilon"], info["stagger"])
+    assert O.oracle().oracle_tol_complete(ct.byref(p.h), 0 if scheme == "jacobi" else 1) == 0
+    h = Harmonic()
+    h.set_grid(m, g[name + "/u0"], g[name + "/locked"])
+    h.epsilon, h.numIterationsToStaggerCheck = info["epsilon"], info["stagger"]
+    with scheme_env(scheme), env(EPIC_HIP_MATH="tol", EPIC_HIP_TILE="0", EPIC_HIP_TRACK="1", EPIC_HIP_FUSE_MIN_CELLS="0"):
+        assert E.harmonic_complete_gpu(h, 1024) == 0
+    assert h.currentIteration == p.h.currentIteration and np.float32(h.delta) == np.float32(p.h.delta)
+    assert np.array_equal(h.u_array().ravel(), p.u)
