@@ -383,29 +383,20 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB
 constexpr int kPairWaves = EPIC_PAIR_BLOCK_WAVES;  // waves per workgroup = pairs of consecutive planes
 constexpr int kPairMinBlocks = EPIC_PAIR_MIN_BLOCKS;
 constexpr int kPairRows = 64;  // x1-rows per task (512^3: 32 rows 273.5 us, 64: 269.7, 128: 268.5, 256: 323 -- too few tasks)
-#ifndef EPIC_PAIR_HAND_RING
-#define EPIC_PAIR_HAND_RING 3
-#endif
-constexpr int kHandRing = EPIC_PAIR_HAND_RING;  // rows per plane in the LDS ring of published splits
-constexpr int kHandSlotBytes = 2048;            // q and n of one row of 256 cells
 constexpr int kPairOuterAhead = EPIC_PAIR_OUTER_AHEAD;  // rows the outer planes' loads run ahead of their use (1 or 2)
 // X0M = false: the pair is two consecutive PLANES (x0, x0 + 1) and the wave marches along x1 (rows of a task's chunk);
 // X0M = true: the pair is two consecutive ROWS (x1, x1 + 1) of a strip and the wave marches along x0, plane by plane -- all
 // workgroups then move through memory together, plane after plane.  "c" below is the pair axis, "t" the march axis.
-template <bool CHECK, bool RB, bool X0M, bool HAND>
-__global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) __attribute__((amdgpu_waves_per_eu(2, 2))) void sweep3d_pair_kernel(Sweep3dArgs a)
+template <bool CHECK, bool RB, bool X0M>
+__global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pair_kernel(Sweep3dArgs a)
 {
-    typedef unsigned vu4 __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) char math_lds_bytes[TolLn<5>::kLdsBytes];
-    // HAND: the splits of a wave's two planes, published row by row for the waves of the planes on either side (see hand_publish below)
-    __shared__ __attribute__((aligned(16))) char hand_ring[HAND ? kPairWaves * 2 * kHandRing * kHandSlotBytes : 16];
-    __shared__ unsigned hand_flags[kPairWaves * 2 + 66];   // per wave {rows begun, rows published}; then 66 words nobody reads
-    if (HAND && threadIdx.x < kPairWaves * 2) hand_flags[threadIdx.x] = 0u;   // (the barrier is the table's)
     const TolLnEntry *const tl = reinterpret_cast<const TolLnEntry *>(math_lds_bytes);
     TolLn<5>::stage(reinterpret_cast<TolLnEntry *>(math_lds_bytes));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float dmax = 0.0f;
+    typedef unsigned vu4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(4))) uint64_t cu64;
     struct RowSide { lmask m0, m1, m2, m3; };
     const size_t pitch = (size_t)a.pitch;
@@ -415,60 +406,7 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) __attribute__((
     const int c_begin = X0M ? 0 : a.plane_begin, c_end = X0M ? a.m1 : a.plane_end, c_max = (X0M ? a.m1 : a.m0) - 1;
     const int t_begin = X0M ? a.plane_begin : 0, t_end = X0M ? a.plane_end : a.m1, t_max = (X0M ? a.m0 : a.m1) - 1;
 
-    // ---- handover of splits between the waves of a workgroup (HAND) -------------------------------------------------
-    // The rows of the planes next to a wave's pair are the OWNED rows of the waves on either side, which split them anyway one
-    // step earlier: every wave publishes the splits (q, n) of its two planes in LDS -- a ring of kHandRing rows per plane --
-    // and takes its outer rows' splits from its neighbours' rings instead of computing them a second time.  Nobody ever
-    // waits: a row is numbered (task, step), the producer writes {begun = row, data, published = row} in that order, the
-    // consumer reads {published, data, begun} in that order (the LDS serves a wave's operations in order) and uses the data
-    // only if its row was published and no row that shares the slot has been begun -- otherwise (a neighbour that lags or
-    // has run ahead, no neighbour in this workgroup, a neighbour without planes) it splits the row itself as before.  Same
-    // values either way: bit-identical results by construction, and no wave can hang on another.
-    const unsigned hand_lane = (unsigned)(uintptr_t)hand_ring + (unsigned)lane * 16u;
-    const unsigned hand_own = hand_lane + (unsigned)wave * (2u * kHandRing * kHandSlotBytes);
-    const unsigned hand_left = hand_lane + (unsigned)max(wave - 1, 0) * (2u * kHandRing * kHandSlotBytes) + kHandRing * kHandSlotBytes;  // its plane B
-    const unsigned hand_right = hand_lane + (unsigned)min(wave + 1, kPairWaves - 1) * (2u * kHandRing * kHandSlotBytes);                  // its plane A
-    const unsigned flag_base = (unsigned)(uintptr_t)hand_flags;
-    // lane 0 writes the flag, the others a word of their own behind the flags (no lane masking, no bank conflict)
-    const unsigned flag_own = flag_base + (lane == 0 ? (unsigned)wave * 8u : (unsigned)(kPairWaves * 2 + lane) * 4u);
-    const unsigned flag_left = flag_base + (unsigned)max(wave - 1, 0) * 8u, flag_right = flag_base + (unsigned)min(wave + 1, kPairWaves - 1) * 8u;
-    struct HandIn { vu4 q, n; unsigned begun, published; };
-    auto hand_publish = [&](const Split4 &sa, const Split4 &sb, unsigned slot_off, unsigned row) {
-        const vu4 qa = {f2u(sa.qx), f2u(sa.qy), f2u(sa.qz), f2u(sa.qw)}, na = {sa.nx, sa.ny, sa.nz, sa.nw};
-        const vu4 qb = {f2u(sb.qx), f2u(sb.qy), f2u(sb.qz), f2u(sb.qw)}, nb = {sb.nx, sb.ny, sb.nz, sb.nw};
-        asm volatile("ds_write_b32 %0, %2\n\t"
-                     "ds_write_b128 %1, %3\n\t"
-                     "ds_write_b128 %1, %4 offset:1024\n\t"
-                     "ds_write_b128 %1, %5 offset:%7\n\t"
-                     "ds_write_b128 %1, %6 offset:%8\n\t"
-                     "ds_write_b32 %0, %2 offset:4"
-                     : : "v"(flag_own), "v"(hand_own + slot_off), "v"(row), "v"(qa), "v"(na), "v"(qb), "v"(nb),
-                         "n"(kHandRing * kHandSlotBytes), "n"(kHandRing * kHandSlotBytes + 1024) : "memory");
-    };
-    auto hand_issue = [&](HandIn &in, unsigned flag, unsigned slot) {
-        asm volatile("ds_read_b32 %0, %4 offset:4\n\t"
-                     "ds_read_b128 %1, %5\n\t"
-                     "ds_read_b128 %2, %5 offset:1024\n\t"
-                     "ds_read_b32 %3, %4"
-                     : "=&v"(in.published), "=&v"(in.q), "=&v"(in.n), "=&v"(in.begun) : "v"(flag), "v"(slot) : "memory");
-    };
-    auto hand_wait = [&](HandIn &l, HandIn &r) {
-        __builtin_amdgcn_sched_barrier(0);   // the splits of the next owned rows stay in front of the wait: they cover the round trip
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(l.q), "+v"(l.n), "+v"(l.begun), "+v"(l.published), "+v"(r.q), "+v"(r.n), "+v"(r.begun), "+v"(r.published));
-    };
-    auto hand_good = [&](const HandIn &in, unsigned row) -> bool {   // wave-uniform
-        const unsigned pub = (unsigned)__builtin_amdgcn_readfirstlane((int)in.published), beg = (unsigned)__builtin_amdgcn_readfirstlane((int)in.begun);
-#ifdef EPIC_HAND_FORCE   // timing-only builds (wrong results when forced to 1)
-        return EPIC_HAND_FORCE != 0;
-#endif
-        return pub >= row && beg < row + kHandRing && pub < row + kHandRing;
-    };
-    auto hand_split = [&](const HandIn &in) -> Split4 {
-        return Split4{u2f(in.q.x), u2f(in.q.y), u2f(in.q.z), u2f(in.q.w), in.n.x, in.n.y, in.n.z, in.n.w};
-    };
-
-    unsigned task = 0;
-    for (int vb = blockIdx.x; vb < a.nblocks; vb += gridDim.x, ++task) {
+    for (int vb = blockIdx.x; vb < a.nblocks; vb += gridDim.x) {
         // XCD-aware order: workgroup vb runs on XCD vb % 8 (round-robin dispatch; the grid is a multiple of 8), and the strips of a
         // row go to ONE XCD's L2 (each fetches its neighbour's edge cell: with the strips on different XCDs that was a 128-byte
         // line from HBM per 4 bytes used, 12 % of the sweep's reads).  The (plane group, chunk) pairs are dealt over the XCDs in
@@ -549,11 +487,6 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) __attribute__((
         hA[0] = side(cA, t0); hB[0] = side(cB, t0);
         sA[3] = tol_split4(qA[3]); sB[3] = tol_split4(qB[3]);
         sA[0] = tol_split4(qA[0]); sB[0] = tol_split4(qB[0]);
-        // rows are numbered task * 8192 + step + 1 (a task has at most 4096 steps); the row of step s sits in slot s % kHandRing
-        const unsigned row0 = task * 8192u + 1u;
-        const bool from_left = HAND && wave > 0, from_right = HAND && wave + 1 < kPairWaves && has_b;
-        unsigned slot = 0;   // of the row of the step at hand, in bytes
-        if (HAND) hand_publish(sA[0], sB[0], 0u, row0);
 
         auto step = [&](int t, const int k) {  // k = (t - t0) & 3, a constant in every expansion
             const int km = (k + 3) & 3, kp = (k + 1) & 3, kn = (k + 2) & 3;
@@ -561,26 +494,8 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) __attribute__((
             qA[kn] = ld(ocA, t + 2); qB[kn] = ld(ocB, t + 2); pa[ko] = ld(oa, t + kPairOuterAhead); pb[ko] = ld(ob, t + kPairOuterAhead);
             eA[kn] = eld(ocA, t + 2); eB[kn] = eld(ocB, t + 2);
             hA[kp & 1] = side(cA, t + 1); hB[kp & 1] = side(cB, t + 1);
-            HandIn in_l, in_r;
-            const unsigned row = row0 + (unsigned)(t - t0);
-            if (HAND) {   // the neighbours' splits of this step's outer rows: on their way while the next owned rows are split
-                hand_issue(in_l, flag_left, hand_left + slot);
-                hand_issue(in_r, flag_right, hand_right + slot);
-            }
             sA[kp] = tol_split4(qA[kp]); sB[kp] = tol_split4(qB[kp]);
-            Split4 so_a, so_b;
-            if (HAND) {
-                hand_wait(in_l, in_r);
-                slot = slot + kHandSlotBytes == kHandRing * kHandSlotBytes ? 0u : slot + kHandSlotBytes;
-                hand_publish(sA[kp], sB[kp], slot, row + 1u);   // the owned rows of the next step
-                if (from_left && hand_good(in_l, row)) so_a = hand_split(in_l);
-                else so_a = tol_split4(pa[k]);
-                if (from_right && hand_good(in_r, row)) so_b = hand_split(in_r);
-                else so_b = tol_split4(pb[k]);
-            } else {
-                so_a = tol_split4(pa[k]);
-                so_b = tol_split4(pb[k]);
-            }
+            const Split4 so_a = tol_split4(pa[k]), so_b = tol_split4(pb[k]);
             // the strip-edge cells of both owned rows in ONE packed split (.x: plane A's -- lane 0 left, lane 63 right --, .y: plane B's)
             const Split2 es = tol_split2(v2f{eA[k], eB[k]});
             const Split2 esA = Split2{v2f{es.q.x, es.q.x}, v2f{es.zm.x, es.zm.x}}, esB = Split2{v2f{es.q.y, es.q.y}, v2f{es.zm.y, es.zm.y}};
@@ -675,16 +590,9 @@ void launch_sweep_3d_math(int math, dim3 grid, dim3 block, hipStream_t stream, c
     if (a.wake.list_out) launch_sweep_3d_track<CHECK, RB, true>(math, grid, block, stream, a, tiles);
     else launch_sweep_3d_track<CHECK, RB, false>(math, grid, block, stream, a, tiles);
 }
-// EPIC_HIP_3D_HANDOVER=0: every wave splits its outer rows itself (A/B, tests); read per launch
-bool sweep_3d_handover()
-{
-    const char *e = getenv("EPIC_HIP_3D_HANDOVER");
-    return !(e && e[0] == '0');
-}
 template <bool CHECK, bool RB, bool X0M> void launch_sweep_3d_pair_axis(dim3 block, hipStream_t stream, const Sweep3dArgs &a)
 {
-    // (Jacobi only: the red-black instantiation with the handover comes out of the compiler at 149 registers with 240 B of scratch)
-    void (*kernel)(Sweep3dArgs) = !RB && sweep_3d_handover() ? sweep3d_pair_kernel<CHECK, RB, X0M, !RB> : sweep3d_pair_kernel<CHECK, RB, X0M, false>;
+    auto kernel = sweep3d_pair_kernel<CHECK, RB, X0M>;
     // resident workgroups walk the logical blocks (each stages the 20 KiB table once)
     const int res = resident_blocks_of((const void *)kernel);
     const dim3 grid((unsigned)(res >= 8 && a.nblocks > res ? res / 8 * 8 : a.nblocks));   // a multiple of 8: vb % 8 is the XCD
