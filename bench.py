@@ -16,7 +16,7 @@ the reference's rounding stages kept.  It is a TOLERANCE mode, and the line says
 `parity` object holds, per BASELINE config, the measured distance of the converged field from the reference's (fields the
 reference itself converged, tests/golden/; at 8192^2 and 512^3 the library's reference-identical default mode, relaxed in this
 same run) next to the 1e-5 bar.  A tol relaxation finishes with the reference's own iteration (from the first check with
-delta < 100 eps on; harmonic_execute_gpu, "Finish"): with that every config is within the bar; what the tol iteration ALONE
+delta < 10 eps on; harmonic_execute_gpu, "Finish"): with that every config is within the bar; what the tol iteration ALONE
 does is recorded beside it (`tol_iteration_alone`: umass.png 1.6e-5, outside the bar) and timed (`relax_tol_alone`).  The bit-exact `precise` mode
 is timed beside it (`kernels.precise`), and `relax_default` is the whole relaxation as the unchanged ROS plugin gets it
 (no environment: precise + red-black, bit-identical to harmonic_complete_cpu).
@@ -198,7 +198,7 @@ def parity_object(args, E, MODES, relaxed, locked_8192):
         return h.u_array().ravel().copy(), int(h.currentIteration)
 
     out = {"mode": {"math": args.math, "scheme": args.scheme}, "bar": "|du| <= 1e-5 max(1, |u|) over reached free cells",
-           "finish": ("tol relaxations leave the tol arithmetic at the first check with delta < 100 eps and finish with the reference's own "
+           "finish": ("tol relaxations leave the tol arithmetic at the first check with delta < 10 eps (100 eps for eps <= 1e-5) and finish with the reference's own "
                       "iteration (precise red-black): the library's default for harmonic_execute_gpu / harmonic_complete_gpu; "
                       "`tol_iteration_alone` repeats a config with EPIC_HIP_TOL_FINISH=0") if args.math == "tol" else None,
            "configs": {}}
@@ -833,7 +833,7 @@ def main():
                             "epic_hip_work_done); effective = the same with every tile counted, i.e. the rate an untracked "
                             "solver would need for this time-to-solution -- tiles skipped by activity tracking hold exactly the "
                             "values the update would have produced.  finishing_iterations: tol math -- the last iterations of the call "
-                            "are the reference's own (precise red-black half-sweeps, from the first check with delta < 100 eps on), "
+                            "are the reference's own (precise red-black half-sweeps, from the first check with delta < 10 eps on), "
                             "which is what puts the converged field within the parity bar on every config; relax_tol_alone is the same "
                             "leg with EPIC_HIP_TOL_FINISH=0"}
                 if key in ("relax", "relax_jacobi", "relax_default"):

@@ -2088,7 +2088,7 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
     } handover{c};   // (the context outlives this function: it still holds the field and the mask)
     // Finish (tol math only; EPIC_HIP_TOL_FINISH=0 switches it off).  Where a converged f32 field ends inside the iteration's
     // dead band is decided by the last few per cent of the iterations, and the parity bar is on the reference's end point:
-    // so at the first check with delta < 100 epsilon (why 100: below) this loop leaves the tol arithmetic and continues with THE REFERENCE'S OWN
+    // so at the first check with delta < 10 epsilon (100 epsilon when epsilon <= 1e-5: below) this loop leaves the tol arithmetic and continues with THE REFERENCE'S OWN
     // ITERATION -- red-black half-sweeps with the bit-exact expf / logf, what the library runs by default from the start --
     // and only a check of that phase may end it.  Measured with the checker (oracle_tol_complete states the same rule) on the
     // reference's maps: umass.png 1.6e-5 -> 1.4e-6 from harmonic_complete_cpu's field, after 86 101 + 8 101 iterations against the
@@ -2117,13 +2117,12 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
             fprintf(stderr, "Warning[epic_hip]: EPIC_HIP_TOL_FINISH=0 ignored for epsilon > 1e-5 (the relaxation stops before stagnation; the finishing iterations decide where).\n");
     }
     const bool finish_wanted = c->math == 4 && !finish_off;
-    // 100 (round 3: 10).  If delta decays as a clean exponential with time constant tau, the finishing phase lasts tau ln(factor)
-    // iterations whatever the map, and on the maps where delta crosses epsilon slowly 2.3 tau was not enough for the stop to be the
-    // reference's (round 4, all thirteen maps of the reference, tools/finish_study_gpu.py): maps/trivial.png at 1e-6 stopped at
-    // 475 401 instead of 503 201 iterations, 4.2e-3 away (a MISS), maps/maze_3.png at 1e-3 one check early (413 301 for 413 401,
-    // 2.7e-6); with 30 (3.4 tau) or 100 (4.6 tau) both stop at the reference's iteration, 1.8e-6 / 8.7e-7 and 2.5e-6 / 1.1e-6 from
-    // its field.  Every other map, the 8192^2 grid and 512^3 end where they ended before, in the same time.
-    float finish_factor = 100.0f;
+    // 10 at the epsilons the callers use; 100 for relaxations to stagnation (epsilon <= 1e-5): where delta decays smoothly all
+    // the way down -- maps/trivial.png, an almost empty 1024^2 room, a decade per 150 000-270 000 iterations -- the finishing
+    // phase must span enough of that decay for the stop to be the reference's (round 4, tools/finish_study_gpu.py: with 10 it
+    // stopped at 475 401 instead of 503 201 iterations, 4.2e-3 away; with 30 or 100 at 503 201, 1.8e-6 / 8.7e-7; the other
+    // twelve maps and the 8192^2 grid do not care -- their delta collapses within a few checks)
+    float finish_factor = harmonic->epsilon <= kTolFinishOptionalBelow ? 100.0f : 10.0f;
     if (const char *e = getenv("EPIC_HIP_TOL_FINISH_FACTOR")) {   // study knob (tools/finish_study_gpu.py)
         const float v = (float)atof(e);
         if (v >= 1.0f && v <= 1e9f) finish_factor = v;

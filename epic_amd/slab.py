@@ -521,7 +521,7 @@ class SlabSolver:
         result = False
         last_check, handed_over = -1.0, False
         # tol math: the loop finishes with the reference's own iteration (precise red-black) from the first check with
-        # delta < 100 epsilon, and only a check of that phase may end it -- harmonic_execute_gpu's "Finish" rule, same float
+        # delta < 10 epsilon (100 epsilon for epsilon <= 1e-5), and only a check of that phase may end it -- harmonic_execute_gpu's "Finish" rule, same float
         # arithmetic for the limit; EPIC_HIP_TOL_FINISH=0 switches it off
         import numpy as np
 
@@ -529,7 +529,8 @@ class SlabSolver:
         # (the switch is honoured for relaxations to stagnation only, epsilon <= 1e-5, as in harmonic_execute_gpu)
         finish_off = os.environ.get("EPIC_HIP_TOL_FINISH", "1")[:1] == "0" and np.float32(self.epsilon) <= np.float32(1e-5)
         finish_wanted = getattr(be, "math", 0) == 4 and not finish_off
-        finish_below = float(np.float32(100.0) * np.float32(self.epsilon))
+        factor = np.float32(100.0) if np.float32(self.epsilon) <= np.float32(1e-5) else np.float32(10.0)   # as harmonic_execute_gpu
+        finish_below = float(factor * np.float32(self.epsilon))
         finishing, math0, redblack0 = False, getattr(be, "math", 0), self.redblack
         try:
             while not result or self.iteration < floor:

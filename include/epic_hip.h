@@ -62,7 +62,7 @@ int epic_hip_tile_iterations(EpicHarmonicT *harmonic);
 int epic_hip_fused_rows_per_task(EpicHarmonicT *harmonic);
 
 /* tol math, harmonic_execute_gpu / harmonic_complete_gpu: the loop leaves the tol arithmetic at the first check with
- * delta < 100 epsilon and FINISHES with the reference's own iteration (red-black half-sweeps, bit-exact expf / logf), and only
+ * delta < 10 epsilon (100 epsilon for epsilon <= 1e-5) and FINISHES with the reference's own iteration (red-black half-sweeps, bit-exact expf / logf), and only
  * a check of that phase may end it -- the converged field is then the end point of the reference's iteration from a state
  * within a few 1e-5 of it: maps/umass.png 1.4e-6 from harmonic_complete_cpu's field instead of 1.6e-5.
  * EPIC_HIP_TOL_FINISH=0 in the environment keeps the tol iteration to the end.  Returns the iteration number at which the

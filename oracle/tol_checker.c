@@ -207,7 +207,7 @@ int oracle_tol_run(TolHarmonic *h, unsigned int iterations, int scheme)
  * check's delta, as harmonic_execute_gpu does (why: oracle/harmonic_oracle.c, oracle_jacobi_complete).
  *
  * FINISH (the library's default for its "until converged" loops; oracle_tol_set_finish(0) / EPIC_HIP_TOL_FINISH=0 switch it
- * off): at the first check with delta < 100 epsilon the loop leaves the tol arithmetic and continues with THE REFERENCE'S OWN
+ * off): at the first check with delta < 10 epsilon (100 epsilon for epsilon <= 1e-5) the loop leaves the tol arithmetic and continues with THE REFERENCE'S OWN
  * ITERATION -- the red-black half-sweep of harmonic_cpu.cpp:38-133 (oracle_update: expf / logf) -- until the reference's
  * test fires in that phase.  Why: where a converged f32 field ends inside the iteration's dead band is decided by the
  * last few per cent of the iterations; on maps/umass.png the tol iteration alone ends 1.6e-5 from the reference's field,
@@ -233,7 +233,7 @@ int oracle_tol_complete(TolHarmonic *h, int scheme)
     if (!q || !zb || (scheme == 0 && !b)) { free(b); free(q); free(zb); return 2; }
     h->currentIteration = 0;
     h->delta = h->epsilon + 1.0f;
-    const float finish_below = 100.0f * h->epsilon;   /* as harmonic_execute_gpu (why 100: there) */
+    const float finish_below = (h->epsilon <= 1e-5f ? 100.0f : 10.0f) * h->epsilon;   /* as harmonic_execute_gpu (why 100: there) */
     /* the switch is honoured for relaxations to stagnation only (epsilon <= 1e-5), as in harmonic_execute_gpu: above that the
      * iteration at which the loop stops decides the field, and the finishing phase is what makes it the reference's */
     const int finish_on = g_tol_finish || h->epsilon > 1e-5f;

@@ -121,7 +121,7 @@ def test_parity_object_names_every_baseline_config_and_its_misses():
     assert p["misses"] == sorted(k for k, v in measured.items() if not v["within_bar"])
     # round 3: tol relaxations finish with the reference's own iteration (the line says so), and with that EVERY config is within
     # the bar -- umass.yaml too, which the tol iteration alone misses (recorded beside it)
-    assert p["misses"] == [] and "finish" in p and "100 eps" in p["finish"]
+    assert p["misses"] == [] and "finish" in p and "10 eps" in p["finish"]
     um = cfgs["configs[1] umass.yaml"]
     assert um["max_rel"] < 3e-6 and um["within_bar"] is True
     assert um["tol_iteration_alone"]["within_bar"] is False and 1e-5 < um["tol_iteration_alone"]["max_rel"] < 2e-5

@@ -90,7 +90,7 @@ def test_synthetic_family_vs_reference_converged(synth_goldens, n, mname, math, 
           % (n, mname, sname, its, info["iterations"], delta, rel, ab))
     assert delta < 1e-6
     assert rel <= BAR, "converged field further than 1e-5 max(1, |u|) from the reference's"
-    # (tol: the relaxation finishes with the reference's own iteration from delta < 100 eps on; where the tol phase freezes
+    # (tol: the relaxation finishes with the reference's own iteration from delta < 10 eps on; where the tol phase freezes
     #  between two checks -- the front arrives and everything stops -- that phase starts from a field that already looks
     #  converged and walks the dead band for a few hundred iterations of its own: 4 501 against 3 801 at 512^2)
     assert abs(its - info["iterations"]) <= (0.02 if mname == "precise" else 0.25) * info["iterations"]

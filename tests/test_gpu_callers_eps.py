@@ -108,7 +108,7 @@ def tol_distance(h, name, eps, ref_maps):
 @pytest.mark.parametrize("name,eps", [r for r in RUNS if float(r[1]) > 1e-5])
 def test_tol_with_its_finishing_iterations_at_the_callers_epsilons(name, eps, scheme, ref_maps, record_property):
     """At 1e-3 / 1e-2 the tol relaxation must stop at the reference's own iteration (the finishing phase is the reference's
-    iteration, entered at the first check with delta < 100 eps, and it is what decides the stop) and be within the bar there."""
+    iteration, entered at the first check with delta < 10 eps, and it is what decides the stop) and be within the bar there."""
     run = MANIFEST["maps"][name]["runs"][eps]
     h = relax(name, float(eps), math="tol", scheme=scheme)
     worst = tol_distance(h, name, eps, ref_maps)
@@ -122,8 +122,8 @@ def test_tol_with_its_finishing_iterations_at_the_callers_epsilons(name, eps, sc
 @pytest.mark.parametrize("name,eps", [r for r in RUNS if float(r[1]) <= 1e-5])
 def test_tol_with_its_finishing_iterations_at_stagnation(name, eps, ref_maps, record_property):
     """eps = 1e-6 is f32 stagnation: the finishing phase walks the dead band on its own, so the iteration
-    count may exceed the reference's (by up to 25 %), the field is within the bar.  (The hand-over is at delta < 100 eps:
-    with round 3's 10 eps maps/trivial.png -- delta decaying smoothly, a decade per 150 000+ iterations -- stopped 27 800 iterations early,
+    count may exceed the reference's (by up to 25 %), the field is within the bar.  (The hand-over is at delta < 100 eps here:
+    with 10 eps maps/trivial.png -- delta decaying smoothly, a decade per 150 000+ iterations -- stopped 27 800 iterations early,
     4.2e-3 from the reference; DESIGN.md section 2, tools/finish_study_gpu.py.)"""
     run = MANIFEST["maps"][name]["runs"][eps]
     h = relax(name, float(eps), math="tol", scheme="redblack")

@@ -181,7 +181,7 @@ def test_measured_task_height_of_the_fused_passes_changes_nothing_but_time(math,
 @pytest.mark.parametrize("finish", [1, 0])
 def test_slab_driver_solves_tol_like_the_library_and_the_checker(goldens, name, finish, monkeypatch):
     """SlabSolver.solve() (epic_amd/slab.py, one slab) with the tol math states the rules of harmonic_execute_gpu -- Jacobi
-    handover, and the finishing iterations (the reference's own, from the first check with delta < 100 eps on) -- so its field,
+    handover, and the finishing iterations (the reference's own, from the first check with delta < 10 eps on) -- so its field,
     iteration count and delta are oracle_tol_complete's and harmonic_complete_gpu's, bit for bit, with the rule on and off."""
     import torch
 
@@ -417,7 +417,7 @@ FINISHED_TOL = 2e-6   # tol relaxations that finish with the reference's iterati
 @pytest.mark.parametrize("name", ["basic", "maze", "umass"])
 def test_tol_maps_converge_within_the_bar_with_the_finishing_iterations(goldens, name, tol_env, record_property):
     """BASELINE configs 1-2 with the tol arithmetic as the library runs it by default (Jacobi here): the loop leaves the tol
-    arithmetic at the first check with delta < 100 eps and finishes with the reference's own iteration (harmonic_execute_gpu,
+    arithmetic at the first check with delta < 10 eps and finishes with the reference's own iteration (harmonic_execute_gpu,
     "Finish"; oracle_tol_complete states the same rule).  ALL THREE maps end within the 1e-5 bar -- umass.png, which the tol
     iteration alone misses (1.6e-5, next test), at 1.4e-6 -- after about the reference's number of iterations (maze: 52 001 +
     3 501 against 52 101, the tol phase freezes between two checks there)."""

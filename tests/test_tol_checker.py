@@ -4,7 +4,7 @@ goldens, and the split e^u = q 2^n on its own.  No GPU.
 What is claimed for the arithmetic (the device kernels are held to it bit for bit in tests/test_gpu_tol.py):
   * it is NOT the reference's arithmetic; converged at eps = 1e-6 it agrees with the reference's converged fields within
     1e-5 max(1, |u|) on the seeded grids and on basic.png (maze / umass need minutes on a CPU: GPU suite) -- and within 1e-6
-    when the loop finishes with the reference's own iteration from delta < 100 eps on (the default: oracle_tol_complete);
+    when the loop finishes with the reference's own iteration from delta < 10 eps on (the default: oracle_tol_complete);
   * Jacobi stops by the reference's own test (max |du| < eps), after about as many iterations as the reference's red-black;
   * the split is unbiased to a few 1e-3 ulp and within one ulp.
 """
@@ -29,7 +29,7 @@ def rel_err(got, want, locked):
 @pytest.fixture
 def finish_rule():
     """Switches the checker's finishing rule (oracle_tol_complete: the reference's own iteration from the first check with
-    delta < 100 eps) and puts it back on."""
+    delta < 10 eps) and puts it back on."""
     lib = O.oracle()
     lib.oracle_tol_set_finish.argtypes = (ct.c_int,)
     lib.oracle_tol_set_finish.restype = None
@@ -42,7 +42,7 @@ def finish_rule():
 @pytest.mark.parametrize("name", SMALL_2D + SMALL_3D)
 def test_tol_converges_on_the_seeded_grids_within_the_bar(goldens, name, scheme, finish, finish_rule):
     """finish = 1: the library's default for its "until converged" loops -- the tol iteration hands over to the reference's
-    own iteration at the first check with delta < 100 eps; the converged field is then within 1e-6 (measured: <= 2.7e-7) of
+    own iteration at the first check with delta < 10 eps; the converged field is then within 1e-6 (measured: <= 2.7e-7) of
     the reference's.  finish = 0: the tol iteration to the end (within the 1e-5 bar on these grids)."""
     finish_rule(finish)
     g, info = goldens["small"], goldens["manifest"]["small"][name]
