@@ -1,6 +1,6 @@
 """Small 2-D grids: several iterations per launch on LDS tiles (epic_amd/csrc/kernels_tile2d.hip).
 
-The path replaces, for grids of at most 1 Mcell, the launch-per-iteration loop of the reference
+The path replaces, for grids of at most 3 Mcell, the launch-per-iteration loop of the reference
 (/root/reference/libepic/src/harmonic/harmonic_gpu.cu:266-290) between two convergence checks.  Its arithmetic is the
 per-iteration kernels', so everything here is held at tolerance 0: against the per-iteration kernels (EPIC_HIP_TILE=0),
 against the checker (oracle/), and against the vectors the reference itself produced (tests/golden/).
