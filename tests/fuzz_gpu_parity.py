@@ -1,0 +1,160 @@
+"""Randomised differential campaign: the library on the GPU against the checker (oracle/), tolerance 0.
+
+Every case draws a grid (2-D up to ~0.8 Mcell or 3-D up to ~0.3 Mcell, ragged sizes, random obstacle density, a few goals, a
+non-uniform start), an arithmetic and scheme (the library's default, precise Jacobi, tol red-black, tol Jacobi), a number of
+iterations ending in a check, and a random setting of the knobs that select the code path (tiles on / off with random ring
+depth, tile height and width; fused passes from 0 cells on; work lists forced; tracked pairs; graphs on / off; task heights) --
+none of which may change a bit.  The field and delta after the iterations are compared with the checker's statement of the same
+iterations (oracle_update* for the default, oracle_jacobi_run, oracle_tol_run).
+
+    python tests/fuzz_gpu_parity.py [--cases 300] [--seed 1]         (test infrastructure: uses oracle/, like the tests)
+tests/test_gpu_fuzz.py runs a short campaign of it under pytest.
+"""
+import argparse
+import ctypes as ct
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+import _oracle as O  # noqa: E402
+from epic_amd import epic_harmonic as eh  # noqa: E402
+from epic_amd.harmonic import Harmonic  # noqa: E402
+from epic_amd.synthetic import synthetic_grid  # noqa: E402
+
+E = eh._epic
+KNOBS = ("EPIC_HIP_TILE", "EPIC_HIP_TILE_HALO", "EPIC_HIP_TILE_ROWS", "EPIC_HIP_TILE_WIDTH", "EPIC_HIP_TILE_PIPELINE", "EPIC_HIP_FUSE_MIN_CELLS",
+         "EPIC_HIP_NO_FUSE", "EPIC_HIP_NO_GRAPH", "EPIC_HIP_TRACK", "EPIC_HIP_TRACK_PAIRS", "EPIC_HIP_TRACK_PAIR_ROWS", "EPIC_HIP_FUSED_ROWS",
+         "EPIC_HIP_ROWS_PER_TASK", "EPIC_HIP_3D_PAIR", "EPIC_HIP_3D_MARCH", "EPIC_HIP_3D_PAIR_ROWS", "EPIC_HIP_TRACK_SWITCH", "EPIC_HIP_MATH",
+         "EPIC_HIP_SCHEME")
+MODES = [("default", eh.MATH_PRECISE, eh.SCHEME_REDBLACK), ("precise jacobi", eh.MATH_PRECISE, eh.SCHEME_JACOBI),
+         ("tol redblack", eh.MATH_TOL, eh.SCHEME_REDBLACK), ("tol jacobi", eh.MATH_TOL, eh.SCHEME_JACOBI)]
+
+
+def draw_case(rng):
+    if rng.random() < 0.3:
+        m = [int(rng.integers(3, 70)), int(rng.integers(3, 70)), int(rng.integers(3, 300))]
+        while np.prod(m) > 300000:
+            m[int(rng.integers(0, 3))] //= 2
+            m = [max(3, x) for x in m]
+    else:
+        m = [int(rng.integers(3, 900)), int(rng.integers(3, 1300))]
+        if rng.random() < 0.2:
+            m[int(rng.integers(0, 2))] = int(rng.integers(3, 12))     # thin grids
+    dens = float(rng.choice([0.0, 0.02, 0.05, 0.15, 0.35]))
+    seed = int(rng.integers(1, 1 << 30))
+    u0, locked = synthetic_grid(m, seed, dens)
+    free = np.flatnonzero(locked == 0)
+    for idx in rng.choice(free, size=min(free.size, int(rng.integers(0, 4))), replace=False) if free.size else []:
+        u0[idx] = 0.0
+        locked[idx] = 1
+    if rng.random() < 0.8 and free.size > 8:
+        O.scramble_free(m, u0, locked, seed=seed + 7, lo=float(rng.choice([-3.0, -40.0, -900.0])), hi=0.0)
+    mode = MODES[int(rng.integers(0, len(MODES)))]
+    k = int(rng.integers(1, 45))
+    env = {}
+    if len(m) == 2:
+        env["EPIC_HIP_TILE"] = rng.choice(["0", "1", None])
+        if env["EPIC_HIP_TILE"] != "0" and rng.random() < 0.6:
+            env["EPIC_HIP_TILE_HALO"] = str(int(rng.integers(1, 28)))
+            if rng.random() < 0.5:
+                env["EPIC_HIP_TILE_ROWS"] = str(2 * int(rng.integers(2, 30)))
+            env["EPIC_HIP_TILE_WIDTH"] = rng.choice(["64", "128", None])
+        env["EPIC_HIP_TILE_PIPELINE"] = rng.choice(["0", None])
+        if rng.random() < 0.4:
+            env["EPIC_HIP_FUSE_MIN_CELLS"] = "0"
+            env["EPIC_HIP_TILE"] = "0"
+            if rng.random() < 0.5:
+                env["EPIC_HIP_FUSED_ROWS"] = str(int(rng.integers(4, 60)))
+        env["EPIC_HIP_TRACK_PAIRS"] = rng.choice(["0", None])
+        if rng.random() < 0.3:
+            env["EPIC_HIP_TRACK_PAIR_ROWS"] = str(int(rng.integers(2, 40)))
+        if rng.random() < 0.3:
+            env["EPIC_HIP_ROWS_PER_TASK"] = str(int(rng.integers(1, 40)))
+    else:
+        env["EPIC_HIP_3D_PAIR"] = rng.choice(["0", None])
+        env["EPIC_HIP_3D_MARCH"] = rng.choice(["x0", None])
+        if rng.random() < 0.4:
+            env["EPIC_HIP_3D_PAIR_ROWS"] = str(int(rng.integers(4, 50)))
+    env["EPIC_HIP_NO_GRAPH"] = rng.choice(["1", None])
+    env["EPIC_HIP_TRACK"] = rng.choice(["0", "1", None])
+    env["EPIC_HIP_TRACK_SWITCH"] = rng.choice(["0", "2", None])
+    return m, u0, locked, mode, k, {a: (None if b is None else str(b)) for a, b in env.items()}
+
+
+def checker(m, u0, locked, mode, k):
+    p = O.Problem(m, u0, locked)
+    name, math, scheme = mode
+    if math == eh.MATH_TOL:
+        assert O.oracle().oracle_tol_run(ct.byref(p.h), k, 1 if scheme == eh.SCHEME_REDBLACK else 0) == 0
+    elif scheme == eh.SCHEME_JACOBI:
+        assert O.oracle().oracle_jacobi_run(ct.byref(p.h), k) == 0
+    else:
+        for i in range(k):
+            (O.oracle().oracle_update_and_check if i == k - 1 else O.oracle().oracle_update)(ct.byref(p.h))
+    return p.u.copy(), float(p.h.delta)
+
+
+def library(m, u0, locked, mode, k, env):
+    prev = {a: os.environ.get(a) for a in KNOBS}
+    for a in KNOBS:
+        os.environ.pop(a, None)
+    for a, b in env.items():
+        if b is not None:
+            os.environ[a] = b
+    try:
+        h = Harmonic()
+        h.set_grid(m, u0, locked)
+        h.epsilon = 1e-6
+        for fn in (E.harmonic_initialize_dimension_size_gpu, E.harmonic_initialize_potential_values_gpu, E.harmonic_initialize_locked_gpu):
+            assert fn(h) == 0
+        assert E.harmonic_initialize_gpu(h, 1024) == 0
+        assert E.epic_hip_set_math_mode(h, mode[1]) == 0 and E.epic_hip_set_scheme(h, mode[2]) == 0
+        # in two calls at a random split, so that batches, graphs and lists are entered and left mid-way
+        first = k // 2 if k > 3 else 0
+        if first:
+            assert E.epic_hip_update_n_gpu(h, first, 0) == 0
+        assert E.epic_hip_update_n_gpu(h, k - first, 1) in (0, 1)
+        assert h.currentIteration == k
+        assert E.harmonic_get_potential_values_gpu(h) == 0
+        delta = float(h.delta)
+        for fn in (E.harmonic_uninitialize_gpu, E.harmonic_uninitialize_dimension_size_gpu, E.harmonic_uninitialize_potential_values_gpu,
+                   E.harmonic_uninitialize_locked_gpu):
+            assert fn(h) == 0
+        return h.u_array().ravel().copy(), delta
+    finally:
+        for a, b in prev.items():
+            os.environ.pop(a, None) if b is None else os.environ.__setitem__(a, b)
+
+
+def campaign(cases, seed, verbose=True):
+    rng = np.random.default_rng(seed)
+    bad = []
+    for i in range(cases):
+        m, u0, locked, mode, k, env = draw_case(rng)
+        want, wdelta = checker(m, u0, locked, mode, k)
+        got, gdelta = library(m, u0, locked, mode, k, env)
+        ok = np.array_equal(got, want) and gdelta == wdelta
+        if verbose or not ok:
+            print(f"case {i:4d} {'ok  ' if ok else 'FAIL'} {str(m):18s} {mode[0]:15s} k={k:2d} " + " ".join(f"{a[9:]}={b}" for a, b in env.items() if b is not None), flush=True)
+        if not ok:
+            diff = np.flatnonzero(got != want)
+            bad.append(dict(case=i, seed=seed, m=m, mode=mode[0], k=k, env=env, cells=int(diff.size), first=int(diff[0]) if diff.size else -1,
+                            delta=(gdelta, wdelta)))
+    return bad
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--quiet", action="store_true")
+    a = ap.parse_args()
+    bad = campaign(a.cases, a.seed, verbose=not a.quiet)
+    print(f"{a.cases} cases, seed {a.seed}: {len(bad)} mismatches")
+    for b in bad:
+        print(b)
+    sys.exit(1 if bad else 0)
