@@ -148,13 +148,94 @@ def campaign(cases, seed, verbose=True):
     return bad
 
 
+def draw_complete(rng):
+    """A whole relaxation: a small grid (the checker must finish it), a random epsilon and check interval."""
+    if rng.random() < 0.25:
+        m = [int(rng.integers(3, 22)), int(rng.integers(3, 22)), int(rng.integers(3, 40))]
+    else:
+        m = [int(rng.integers(3, 110)), int(rng.integers(3, 140))]
+    dens = float(rng.choice([0.0, 0.05, 0.15, 0.3]))
+    seed = int(rng.integers(1, 1 << 30))
+    u0, locked = synthetic_grid(m, seed, dens)
+    free = np.flatnonzero(locked == 0)
+    for idx in rng.choice(free, size=min(free.size, int(rng.integers(0, 3))), replace=False) if free.size else []:
+        u0[idx] = 0.0
+        locked[idx] = 1
+    mode = MODES[int(rng.integers(0, len(MODES)))]
+    eps = float(rng.choice([1e-2, 1e-3, 1e-4, 1e-6]))
+    stagger = int(rng.choice([1, 7, 50, 100, 128]))
+    env = {}
+    if len(m) == 2:
+        env["EPIC_HIP_TILE"] = rng.choice(["0", "1", None])
+        if env["EPIC_HIP_TILE"] != "0" and rng.random() < 0.5:
+            env["EPIC_HIP_TILE_HALO"] = str(int(rng.integers(1, 20)))
+            env["EPIC_HIP_TILE_WIDTH"] = rng.choice(["64", "128", None])
+        env["EPIC_HIP_TILE_PIPELINE"] = rng.choice(["0", None])
+        if rng.random() < 0.3:
+            env["EPIC_HIP_FUSE_MIN_CELLS"] = "0"
+            env["EPIC_HIP_TILE"] = "0"
+        env["EPIC_HIP_TRACK_PAIRS"] = rng.choice(["0", None])
+    else:
+        env["EPIC_HIP_3D_PAIR"] = rng.choice(["0", None])
+    env["EPIC_HIP_NO_GRAPH"] = rng.choice(["1", None])
+    env["EPIC_HIP_TRACK"] = rng.choice(["0", "1", None])
+    env["EPIC_HIP_TRACK_SWITCH"] = rng.choice(["0", "2", None])
+    return m, u0, locked, mode, eps, stagger, {a: (None if b is None else str(b)) for a, b in env.items()}
+
+
+def campaign_complete(cases, seed, verbose=True):
+    """harmonic_complete_gpu against the checker's loops: field, iteration count and delta, tolerance 0 -- the library's default
+    against oracle_complete (= harmonic_complete_cpu), precise Jacobi against oracle_jacobi_complete (with its hand-over to
+    red-black), tol against oracle_tol_complete (with its finishing iterations)."""
+    rng = np.random.default_rng(seed)
+    bad = []
+    names = {eh.MATH_PRECISE: "precise", eh.MATH_TOL: "tol"}
+    for i in range(cases):
+        m, u0, locked, mode, eps, stagger, env = draw_complete(rng)
+        p = O.Problem(m, u0, locked, epsilon=eps, stagger=stagger)
+        if mode[1] == eh.MATH_TOL:
+            rc = O.oracle().oracle_tol_complete(ct.byref(p.h), 1 if mode[2] == eh.SCHEME_REDBLACK else 0)
+        elif mode[2] == eh.SCHEME_JACOBI:
+            rc = O.oracle().oracle_jacobi_complete(ct.byref(p.h))
+        else:
+            rc = O.oracle().oracle_complete(ct.byref(p.h))
+        assert rc == 0, rc
+        prev = {a: os.environ.get(a) for a in KNOBS}
+        for a in KNOBS:
+            os.environ.pop(a, None)
+        for a, b in env.items():
+            if b is not None:
+                os.environ[a] = b
+        os.environ["EPIC_HIP_MATH"] = names[mode[1]]
+        os.environ["EPIC_HIP_SCHEME"] = "redblack" if mode[2] == eh.SCHEME_REDBLACK else "jacobi"
+        try:
+            h = Harmonic()
+            h.set_grid(m, u0, locked)
+            h.epsilon = eps
+            h.numIterationsToStaggerCheck = stagger
+            assert E.harmonic_complete_gpu(h, 1024) == 0
+            got, its, delta = h.u_array().ravel().copy(), int(h.currentIteration), float(h.delta)
+        finally:
+            for a, b in prev.items():
+                os.environ.pop(a, None) if b is None else os.environ.__setitem__(a, b)
+        ok = np.array_equal(got, p.u) and its == int(p.h.currentIteration) and delta == float(p.h.delta)
+        if verbose or not ok:
+            print(f"complete {i:4d} {'ok  ' if ok else 'FAIL'} {str(m):14s} {mode[0]:15s} eps {eps:g} stagger {stagger:3d} iterations {its} (checker {int(p.h.currentIteration)}) "
+                  + " ".join(f"{a[9:]}={b}" for a, b in env.items() if b is not None), flush=True)
+        if not ok:
+            bad.append(dict(case=i, seed=seed, m=m, mode=mode[0], eps=eps, stagger=stagger, env=env, iterations=(its, int(p.h.currentIteration)),
+                            cells=int((got != p.u).sum()), delta=(delta, float(p.h.delta))))
+    return bad
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--complete", action="store_true", help="whole relaxations (harmonic_complete_gpu) instead of fixed iteration counts")
     a = ap.parse_args()
-    bad = campaign(a.cases, a.seed, verbose=not a.quiet)
+    bad = (campaign_complete if a.complete else campaign)(a.cases, a.seed, verbose=not a.quiet)
     print(f"{a.cases} cases, seed {a.seed}: {len(bad)} mismatches")
     for b in bad:
         print(b)

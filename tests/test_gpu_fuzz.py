@@ -10,3 +10,8 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
 @pytest.mark.parametrize("seed", [11, 12])
 def test_random_cases_against_the_checker(seed):
     assert F.campaign(40, seed, verbose=False) == []
+
+
+@pytest.mark.parametrize("seed", [21])
+def test_random_whole_relaxations_against_the_checker(seed):
+    assert F.campaign_complete(40, seed, verbose=False) == []
