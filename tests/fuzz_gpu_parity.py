@@ -27,7 +27,7 @@ from epic_amd.harmonic import Harmonic  # noqa: E402
 from epic_amd.synthetic import synthetic_grid  # noqa: E402
 
 E = eh._epic
-KNOBS = ("EPIC_HIP_TILE", "EPIC_HIP_TILE_HALO", "EPIC_HIP_TILE_ROWS", "EPIC_HIP_TILE_WIDTH", "EPIC_HIP_TILE_PIPELINE", "EPIC_HIP_FUSE_MIN_CELLS",
+KNOBS = ("EPIC_HIP_DEVICES", "EPIC_HIP_HALO", "EPIC_HIP_NO_PEER", "EPIC_HIP_THREADS", "EPIC_HIP_TILE", "EPIC_HIP_TILE_HALO", "EPIC_HIP_TILE_ROWS", "EPIC_HIP_TILE_WIDTH", "EPIC_HIP_TILE_PIPELINE", "EPIC_HIP_FUSE_MIN_CELLS",
          "EPIC_HIP_NO_FUSE", "EPIC_HIP_NO_GRAPH", "EPIC_HIP_TRACK", "EPIC_HIP_TRACK_PAIRS", "EPIC_HIP_TRACK_PAIR_ROWS", "EPIC_HIP_FUSED_ROWS",
          "EPIC_HIP_ROWS_PER_TASK", "EPIC_HIP_3D_PAIR", "EPIC_HIP_3D_MARCH", "EPIC_HIP_3D_PAIR_ROWS", "EPIC_HIP_TRACK_SWITCH", "EPIC_HIP_MATH",
          "EPIC_HIP_SCHEME")
@@ -83,6 +83,11 @@ def draw_case(rng):
     env["EPIC_HIP_NO_GRAPH"] = rng.choice(["1", None])
     env["EPIC_HIP_TRACK"] = rng.choice(["0", "1", None])
     env["EPIC_HIP_TRACK_SWITCH"] = rng.choice(["0", "2", None])
+    if m[0] >= 48 and rng.random() < 0.25:   # the in-library slabs (the device repeated: one GPU suffices), 2-4 of them
+        env["EPIC_HIP_DEVICES"] = ",".join(["0"] * int(rng.integers(2, 5)))
+        env["EPIC_HIP_HALO"] = rng.choice([None, "1", "2", "3", "5"])
+        env["EPIC_HIP_NO_PEER"] = rng.choice(["1", None])
+        env["EPIC_HIP_THREADS"] = rng.choice(["0", None])
     return m, u0, locked, mode, k, {a: (None if b is None else str(b)) for a, b in env.items()}
 
 
