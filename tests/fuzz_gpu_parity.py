@@ -36,7 +36,12 @@ MODES = [("default", eh.MATH_PRECISE, eh.SCHEME_REDBLACK), ("precise jacobi", eh
 
 
 def draw_case(rng):
-    if rng.random() < 0.3:
+    big = rng.random() < 0.08    # now and then a grid of the size where the library changes gear (4 Mcell: fused passes, work lists)
+    if big and rng.random() < 0.4:
+        m = [int(rng.integers(60, 150)), int(rng.integers(60, 150)), int(rng.integers(250, 700))]
+    elif big:
+        m = [int(rng.integers(1500, 2600)), int(rng.integers(1800, 3000))]
+    elif rng.random() < 0.3:
         m = [int(rng.integers(3, 70)), int(rng.integers(3, 70)), int(rng.integers(3, 300))]
         while np.prod(m) > 300000:
             m[int(rng.integers(0, 3))] //= 2
@@ -55,7 +60,7 @@ def draw_case(rng):
     if rng.random() < 0.8 and free.size > 8:
         O.scramble_free(m, u0, locked, seed=seed + 7, lo=float(rng.choice([-3.0, -40.0, -900.0])), hi=0.0)
     mode = MODES[int(rng.integers(0, len(MODES)))]
-    k = int(rng.integers(1, 45))
+    k = int(rng.integers(1, 14 if big else 45))
     env = {}
     if len(m) == 2:
         env["EPIC_HIP_TILE"] = rng.choice(["0", "1", None])
@@ -88,23 +93,47 @@ def draw_case(rng):
         env["EPIC_HIP_HALO"] = rng.choice([None, "1", "2", "3", "5"])
         env["EPIC_HIP_NO_PEER"] = rng.choice(["1", None])
         env["EPIC_HIP_THREADS"] = rng.choice(["0", None])
-    return m, u0, locked, mode, k, {a: (None if b is None else str(b)) for a, b in env.items()}
+    env = {a: (None if b is None else str(b)) for a, b in env.items()}
+    # live edits of the resident state between the two calls (the navigation node's set_cells: 0 = goal, 1 = obstacle, 2 = free; cells
+    # out of range and unknown types are skipped by the reference): 2-D, one device
+    edits = None
+    if len(m) == 2 and k > 3 and env.get("EPIC_HIP_DEVICES") is None and rng.random() < 0.3:
+        n = int(rng.integers(1, 12))
+        v = np.stack([rng.integers(0, m[1] + 2, n), rng.integers(0, m[0] + 2, n)], axis=1).astype(np.uint32)   # (x = column, y = row)
+        edits = (np.ascontiguousarray(v), rng.integers(0, 4, n).astype(np.uint32))
+    return m, u0, locked, mode, k, env, edits
 
 
-def checker(m, u0, locked, mode, k):
+def first_part(k):
+    return k // 2 if k > 3 else 0
+
+
+def checker(m, u0, locked, mode, k, edits=None):
     p = O.Problem(m, u0, locked)
     name, math, scheme = mode
-    if math == eh.MATH_TOL:
-        assert O.oracle().oracle_tol_run(ct.byref(p.h), k, 1 if scheme == eh.SCHEME_REDBLACK else 0) == 0
-    elif scheme == eh.SCHEME_JACOBI:
-        assert O.oracle().oracle_jacobi_run(ct.byref(p.h), k) == 0
-    else:
-        for i in range(k):
-            (O.oracle().oracle_update_and_check if i == k - 1 else O.oracle().oracle_update)(ct.byref(p.h))
+    lib = O.oracle()
+
+    def run(n, check):
+        if n == 0:
+            return
+        if math == eh.MATH_TOL:
+            assert lib.oracle_tol_run(ct.byref(p.h), n, 1 if scheme == eh.SCHEME_REDBLACK else 0) == 0
+        elif scheme == eh.SCHEME_JACOBI:
+            assert lib.oracle_jacobi_run(ct.byref(p.h), n) == 0
+        else:
+            for i in range(n):
+                (lib.oracle_update_and_check if check and i == n - 1 else lib.oracle_update)(ct.byref(p.h))
+
+    first = first_part(k)
+    run(first, False)
+    if edits is not None and first:
+        v, t = edits
+        assert lib.oracle_set_cells_2d(ct.byref(p.h), len(t), v.ctypes.data_as(eh._UP), t.ctypes.data_as(eh._UP)) == 0
+    run(k - first, True)
     return p.u.copy(), float(p.h.delta)
 
 
-def library(m, u0, locked, mode, k, env):
+def library(m, u0, locked, mode, k, env, edits=None):
     prev = {a: os.environ.get(a) for a in KNOBS}
     for a in KNOBS:
         os.environ.pop(a, None)
@@ -120,9 +149,12 @@ def library(m, u0, locked, mode, k, env):
         assert E.harmonic_initialize_gpu(h, 1024) == 0
         assert E.epic_hip_set_math_mode(h, mode[1]) == 0 and E.epic_hip_set_scheme(h, mode[2]) == 0
         # in two calls at a random split, so that batches, graphs and lists are entered and left mid-way
-        first = k // 2 if k > 3 else 0
+        first = first_part(k)
         if first:
             assert E.epic_hip_update_n_gpu(h, first, 0) == 0
+            if edits is not None:
+                v, t = edits
+                assert E.harmonic_utilities_set_cells_2d_gpu(h, 1024, len(t), v.ctypes.data_as(eh._UP), t.ctypes.data_as(eh._UP)) == 0
         assert E.epic_hip_update_n_gpu(h, k - first, 1) in (0, 1)
         assert h.currentIteration == k
         assert E.harmonic_get_potential_values_gpu(h) == 0
@@ -140,12 +172,13 @@ def campaign(cases, seed, verbose=True):
     rng = np.random.default_rng(seed)
     bad = []
     for i in range(cases):
-        m, u0, locked, mode, k, env = draw_case(rng)
-        want, wdelta = checker(m, u0, locked, mode, k)
-        got, gdelta = library(m, u0, locked, mode, k, env)
+        m, u0, locked, mode, k, env, edits = draw_case(rng)
+        want, wdelta = checker(m, u0, locked, mode, k, edits)
+        got, gdelta = library(m, u0, locked, mode, k, env, edits)
         ok = np.array_equal(got, want) and gdelta == wdelta
         if verbose or not ok:
-            print(f"case {i:4d} {'ok  ' if ok else 'FAIL'} {str(m):18s} {mode[0]:15s} k={k:2d} " + " ".join(f"{a[9:]}={b}" for a, b in env.items() if b is not None), flush=True)
+            print(f"case {i:4d} {'ok  ' if ok else 'FAIL'} {str(m):18s} {mode[0]:15s} k={k:2d} " + " ".join(f"{a[9:]}={b}" for a, b in env.items() if b is not None)
+                  + (f" edits={len(edits[1])}" if edits is not None else ""), flush=True)
         if not ok:
             diff = np.flatnonzero(got != want)
             bad.append(dict(case=i, seed=seed, m=m, mode=mode[0], k=k, env=env, cells=int(diff.size), first=int(diff[0]) if diff.size else -1,
