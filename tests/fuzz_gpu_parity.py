@@ -95,9 +95,9 @@ def draw_case(rng):
         env["EPIC_HIP_THREADS"] = rng.choice(["0", None])
     env = {a: (None if b is None else str(b)) for a, b in env.items()}
     # live edits of the resident state between the two calls (the navigation node's set_cells: 0 = goal, 1 = obstacle, 2 = free; cells
-    # out of range and unknown types are skipped by the reference): 2-D, one device
+    # out of range and unknown types are skipped by the reference): 2-D, one device or slabs
     edits = None
-    if len(m) == 2 and k > 3 and env.get("EPIC_HIP_DEVICES") is None and rng.random() < 0.3:
+    if len(m) == 2 and k > 3 and rng.random() < 0.3:
         n = int(rng.integers(1, 12))
         v = np.stack([rng.integers(0, m[1] + 2, n), rng.integers(0, m[0] + 2, n)], axis=1).astype(np.uint32)   # (x = column, y = row)
         edits = (np.ascontiguousarray(v), rng.integers(0, 4, n).astype(np.uint32))
