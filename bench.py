@@ -397,8 +397,82 @@ def live_traffic(args):
     return out, counts
 
 
+def summarise_into_config(out):
+    """BASELINE's metric is "relax to eps = 1e-6"; the timed steps are a steady-state rate.  The driver's record keeps `config`,
+    `roofline` and `cpu_baseline` whole and only NAMES the other objects, so the time-to-solution, the parity verdict and the
+    other configs' headline numbers are repeated inside `config`: relax_to_eps for the fastest parity-clean mode and for the
+    library default (what an unchanged caller gets), parity_misses, config5_frac, maps_seconds."""
+    cfg = out["config"]
+
+    def leg(key):
+        x = out.get(key)
+        if not x:
+            return None
+        return {"mode": "%s %s%s" % (x["math"], x["scheme"], " + finishing iterations" if x.get("finishing_iterations") else ""),
+                "seconds": x["seconds"], "iterations": x["iterations"], "finishing_iterations": x.get("finishing_iterations", 0),
+                "recomputed_Mcell_updates_per_s": x["recomputed_Mcell_updates_per_s"],
+                "effective_Mcell_updates_per_s": x["effective_Mcell_updates_per_s"]}
+
+    legs = {k: leg(k) for k in ("relax", "relax_jacobi", "relax_default")}
+    if any(legs.values()):
+        # with a parity miss in the line only the bit-exact default counts as clean
+        misses = (out.get("parity") or {}).get("misses")
+        have = [(legs[k]["seconds"], k) for k in (("relax_default",) if misses else tuple(legs)) if legs.get(k)]
+        best = min(have)[1] if have else None
+        cfg["relax_to_eps"] = {
+            "epsilon": 1e-6,
+            "fastest_parity_clean": dict(legs[best], leg=best) if best else None,
+            "library_default": legs["relax_default"],
+            "timed_scheme": legs["relax_jacobi"],
+            "note": "harmonic_execute_gpu from the initial field to the reference's stop, final D2H included; library_default = no "
+                    "environment (bit-identical to harmonic_complete_cpu); full objects: the line's relax* keys"}
+    if "parity" in out:
+        cfg["parity_misses"] = out["parity"].get("misses")
+    if "config5" in out:
+        cfg["config5_frac"] = out["config5"]["frac"]
+        if "precise" in out["config5"]:
+            cfg["config5_frac_default_math"] = out["config5"]["precise"]["frac"]
+    if "kernels" in out and "precise" in out["kernels"]:
+        cfg["default_math_frac"] = out["kernels"]["precise"]["frac"]   # the bit-exact sweep an unchanged caller's kernels run at
+    if "maps" in out:
+        cfg["maps_seconds"] = {name: out["maps"]["%s default eps 1e-06" % name]["seconds"] for name in ("maze", "umass")
+                               if "%s default eps 1e-06" % name in out["maps"]}
+
+
+def self_launch(args):
+    """`python3 bench.py --gpus N` with N > 1 typed as is (no launcher): start the N ranks ourselves, as a CHILD process --
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same
+    arguments>` -- relay the child's output (rank 0's one JSON line on stdout) and return its exit code.  This process has
+    made no GPU call and has not imported torch at this point, and it never replaces itself (a child, not an exec)."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:   # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL's P2P transport needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)   # stderr goes straight through
+    lines = []
+    for line in child.stdout:
+        (lines.append(line) if line.startswith("{") else sys.stderr.write(line))
+    rc = child.wait()
+    for line in lines[-1:]:    # ONE line: rank 0's
+        sys.stdout.write(line)
+    sys.stdout.flush()
+    if rc == 0 and not lines:
+        sys.stderr.write("bench.py: the %d ranks ended without a result line\n" % args.gpus)
+        rc = 1
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.in_library_child:
+        sys.exit(self_launch(args))
     import numpy as np
 
     live, live_note = {}, "not measured in this run"
@@ -575,7 +649,7 @@ def main():
             # moves through HBM is `traffic`; that rate against the same peak is this:
             "hbm_frac_measured": None if hbm_measured is None else round(hbm_measured / HBM_PEAK_GBPS, 4),
             "hbm_GBps_measured": None if hbm_measured is None else round(hbm_measured, 1),
-            "limiter": "valu" if valu_bound else "valu+hbm",
+            "limiter": "valu" if valu_bound else "hbm",   # the same decision as `bound` (kept for readers of earlier rounds' lines)
             "iterations_per_launch": per_pass,
             "bytes_per_launch": int(BYTES_PER_CELL_SWEEP * cells_per_launch * per_pass),
             "note": "frac = 8 B x grid cells x iterations per launch / mean launch-to-launch device time (HIP events on the kernel's "
@@ -878,6 +952,7 @@ def main():
             out["parity"] = parity_object(args, E, MODES, relaxed, locked)
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(grid, u0, locked, args.cpu_half_sweeps, free_by_colour)
+        summarise_into_config(out)
         print(json.dumps(out), flush=True)
         return
 

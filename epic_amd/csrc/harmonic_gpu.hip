@@ -121,8 +121,8 @@ struct Track {
 
 struct Ctx {
     int n = 0;
-    int m[3] = {0, 0, 0};   // as given by the caller
-    int rows = 0;           // 2-D: m[0];            3-D: m[0] * m[1] (rows of length m[2])
+    int m[4] = {0, 0, 0, 0};   // as given by the caller
+    int rows = 0;           // 2-D: m[0];            3-D: m[0] * m[1] (rows of length m[2]);   4-D: m[0] * m[1] * m[2] (held, never swept)
     int cols = 0;           // last dimension
     int pitch = 0;          // floats per row on the device
     float *buf[2] = {nullptr, nullptr};
@@ -134,6 +134,7 @@ struct Ctx {
     // small grids (kernels_tile2d.hip): max |du| per tile of a check iteration, written by the kernel straight into pinned host
     // memory -- no zeroing, no atomics on one word, no copy: the check costs the wait for the stream and nothing else
     float *h_tile_delta = nullptr;   // 2 x kTileDeltaCap floats: two blocks of iterations may be in flight (tiles_pipelined)
+    int tile_delta_n = 0;            // words the latest check launch of enqueue_plain_run wrote there (that launch's tiles_r x tiles_c)
     // small grids, harmonic_execute_gpu: a THIRD buffer of u and two events, so that the block of iterations after a check can be
     // enqueued before the check's result is known without destroying the state that check refers to (tiles_pipelined)
     float *spare = nullptr;
@@ -148,7 +149,7 @@ struct Ctx {
     // Launch-bound grids replay the plain sweeps between two checks from a captured hipGraph; key = (count, starting
     // buffer, starting parity, math, scheme, rows_per_task, fused-pass configuration) -- everything a captured launch
     // sequence depends on.
-    struct Replay { hipGraphExec_t exec; int cur_flip; double work; };  // cur_flip: whether the sequence ends in the other buffer; work: what it adds to work_full
+    struct Replay { hipGraphExec_t exec; int cur_flip; double work; int tile_delta_n; };  // cur_flip: whether the sequence ends in the other buffer; work: what it adds to work_full; tile_delta_n: per-tile maxima its check writes
     std::map<std::tuple<unsigned, int, int, int, int, int, int>, Replay> graphs;
     bool graphs_broken = false;    // a capture / instantiate / launch failed once: batches run eagerly from then on
     // Activity tracking (struct Track above): one set of work lists for the grid, or one per slab in multi-device mode.
@@ -208,6 +209,7 @@ struct Ctx {
     static size_t mask_words_both_2d(int rows, int pitch) { return epic_hip::mask_words_2d(rows, pitch) + epic_hip::mask_words_fused_2d(rows, pitch); }
     size_t mask_bytes() const
     {
+        if (n == 4) return 64;   // (nothing is ever swept: d_locked only has to be a live allocation)
         return sizeof(uint32_t) * (n == 2 ? mask_words_both_2d(rows, pitch) : epic_hip::mask_words_3d(m[0], m[1], pitch));
     }
     uint32_t *maskf() const { return n == 2 && maskw ? maskw + epic_hip::mask_words_2d(rows, pitch) : nullptr; }
@@ -248,14 +250,19 @@ Ctx *find_ctx(Harmonic *h)
 
 bool dims_from(const Harmonic *h, Ctx *c)
 {
-    if (h->n != 2 && h->n != 3) return false;
+    // n = 4: the reference holds the state on the device and sweeps NOTHING (harmonic_gpu.cu:156-162, :327-336 -- the n == 4
+    // branches are empty, currentIteration still counts); the same here: state resident, every update a counting no-op.
+    if (h->n != 2 && h->n != 3 && h->n != 4) return false;
     for (unsigned i = 0; i < h->n; i++)
-        if (h->m[i] < 3 || h->m[i] > (1u << 30)) return false;
+        if (h->m[i] < (h->n == 4 ? 1u : 3u) || h->m[i] > (1u << 30)) return false;
     c->n = (int)h->n;
-    for (unsigned i = 0; i < 3; i++) c->m[i] = i < h->n ? (int)h->m[i] : 0;
+    for (unsigned i = 0; i < 4; i++) c->m[i] = i < h->n ? (int)h->m[i] : 0;
     c->cols = c->m[c->n - 1];
-    const long long rows = c->n == 2 ? (long long)c->m[0] : (long long)c->m[0] * c->m[1];
-    if (rows > 0x7fffffffLL) return false;
+    long long rows = 1;
+    for (int i = 0; i + 1 < c->n; i++) {
+        rows *= c->m[i];
+        if (rows > 0x7fffffffLL) return false;
+    }
     c->rows = (int)rows;
     c->pitch = epic_hip::pitch_for_cols(c->cols);
     resolve_tracking(c);
@@ -379,7 +386,7 @@ void drop_ctx_if_empty(Harmonic *h)
 // are launch-bound either way (3.2-4 us per sweep without, 5-6.7 us with lists, measured), so "automatic" leaves them alone.
 void resolve_tracking(Ctx *c)
 {
-    c->track = c->track_mode == 1 || (c->track_mode == 2 && (long long)c->rows * c->pitch > (1ll << 22));
+    c->track = c->n != 4 && (c->track_mode == 1 || (c->track_mode == 2 && (long long)c->rows * c->pitch > (1ll << 22)));
 }
 
 int auto_rows_per_task(const Ctx *c)
@@ -423,6 +430,7 @@ hipError_t multi_sweep(Ctx *c, bool check, unsigned iteration);
 
 hipError_t enqueue_sweep(Ctx *c, bool check, unsigned iteration)
 {
+    if (c->n == 4) return hipSuccess;   // the reference's empty n == 4 branch: nothing is swept, the caller counts
     if (c->multi()) return multi_sweep(c, check, iteration);
     hipError_t e;
     if (check) {
@@ -679,6 +687,7 @@ bool tile_checks(const Ctx *c, const epic_hip::TilePlan &tp)
 // check_last (tile path only, tile_checks()): one more iteration after the `count` plain ones, a check, in the same launches.
 hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first, bool check_last = false)
 {
+    if (c->n == 4) return check_last ? hipErrorInvalidValue : hipSuccess;
     if (c->multi()) return check_last ? hipErrorInvalidValue : multi_run(c, count, first, false);
     const epic_hip::TilePlan tp = tile_plan(c);
     if (check_last && !tile_checks(c, tp)) return hipErrorInvalidValue;
@@ -694,6 +703,7 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first, bool check_
             c->work_full += (double)k;
             i += k;
         }
+        if (check_last) c->tile_delta_n = tp.tiles_r * tp.tiles_c;   // read_tile_delta reads exactly what this launch wrote
         return hipSuccess;
     }
     const bool no_fuse = getenv("EPIC_HIP_NO_FUSE") != nullptr;   // (read per call: the tests switch it)
@@ -823,6 +833,7 @@ hipError_t enqueue_rb_pairs_tracked(Ctx *c, unsigned npairs, unsigned first, boo
 
 hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first, bool check_last = false)
 {
+    if (c->n == 4) return enqueue_plain_run(c, count, first, check_last);
     const bool small = (long long)c->rows * c->pitch <= (1ll << 22);
     const bool no_graph = getenv("EPIC_HIP_NO_GRAPH") != nullptr;  // (read per batch: the tests switch it)
     // a captured sequence bakes in the work-list buffers and list mode: run eagerly until the forced iterations are over
@@ -831,7 +842,7 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first, bool chec
     // (the fused-pass switches are read per batch -- EPIC_HIP_NO_FUSE, EPIC_HIP_FUSE_MIN_CELLS, EPIC_HIP_FUSED_ROWS --, so they
     // belong to the key: 0 = single sweeps, otherwise the task height of the pass)
     const epic_hip::TilePlan tp = tile_plan(c);
-    const int fuse_cfg = tp.halo > 0 ? -(tp.halo * 1024 + tp.tile_rows) : fuses_tol(c) ? jacobi_fused_rows_per_task(c) : 0;
+    const int fuse_cfg = tp.halo > 0 ? -((tp.halo * 1024 + tp.tile_rows) * 4 + tp.tile_cols / 64) : fuses_tol(c) ? jacobi_fused_rows_per_task(c) : 0;
     const auto key = std::make_tuple(2u * count + (check_last ? 1u : 0u), c->cur + 2 * (c->track ? 1 + c->trk.phase : 0), (int)(first & 1u), c->math,
                                      (int)c->redblack, auto_rows_per_task(c), fuse_cfg);
     if (c->graphs_broken) return enqueue_plain_run(c, count, first, check_last);
@@ -863,7 +874,7 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first, bool chec
             return enqueue_plain_run(c, count, first, check_last);
         }
         if (c->graphs.size() >= 16) drop_graphs(c);
-        it = c->graphs.emplace(key, Ctx::Replay{exec, cur_flip, work}).first;
+        it = c->graphs.emplace(key, Ctx::Replay{exec, cur_flip, work, check_last ? c->tile_delta_n : 0}).first;
     }
     hipError_t e = hipGraphLaunch(it->second.exec, c->stream);
     if (e != hipSuccess) {  // nothing was enqueued: run the batch eagerly instead, and stop replaying
@@ -873,6 +884,7 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first, bool chec
     }
     c->cur ^= it->second.cur_flip;
     c->work_full += it->second.work;
+    if (check_last) c->tile_delta_n = it->second.tile_delta_n;
     if (c->track) c->trk.phase = (int)((c->trk.phase + count) % 6);
     return hipSuccess;
 }
@@ -912,9 +924,8 @@ int read_tile_delta(Harmonic *h, Ctx *c, const char *fn)
         report(fn, "Failed to synchronize the device after the 'update and check' kernel.");
         return EPIC_ERROR_DEVICE_SYNCHRONIZE;
     }
-    const epic_hip::TilePlan tp = tile_plan(c);
     float d = 0.0f;
-    for (int t = 0, n = tp.tiles_r * tp.tiles_c; t < n; ++t) d = std::max(d, c->h_tile_delta[t]);
+    for (int t = 0; t < c->tile_delta_n; ++t) d = std::max(d, c->h_tile_delta[t]);   // the plan of the launch that wrote them
     h->delta = d;
     return EPIC_SUCCESS;
 }
@@ -923,6 +934,7 @@ int multi_read_delta(Harmonic *h, Ctx *c, const char *fn);
 
 int read_delta(Harmonic *h, Ctx *c, const char *fn)
 {
+    if (c->n == 4) return EPIC_SUCCESS;   // nothing was swept: delta stays what it was (as harmonic_update_and_check_cpu leaves it)
     if (c->multi()) return multi_read_delta(h, c, fn);
     if (hipMemcpyAsync(c->h_delta, c->d_delta, sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
         report(fn, "Failed to copy memory from device to host for the max delta.");
@@ -966,6 +978,7 @@ int upload_locked(Harmonic *h, Ctx *c, const char *fn)
 {
     if (c->multi()) return multi_upload_locked(h, c, fn);
     force_all(c);
+    if (c->n == 4) return EPIC_SUCCESS;   // never read: no lane masks to derive
     const size_t cells = (size_t)c->rows * c->cols;
     uint32_t *tmp = nullptr;
     if (hipMalloc((void **)&tmp, cells * sizeof(uint32_t)) != hipSuccess) {
@@ -1711,7 +1724,7 @@ int harmonic_initialize_potential_values_gpu(Harmonic *harmonic)  // harmonic_mo
     }
     Ctx probe;
     if (!dims_from(harmonic, &probe)) {
-        report(fn, "Invalid input (only n = 2 and n = 3 with every m[i] >= 3 are supported).");
+        report(fn, "Invalid input (n = 2 and n = 3 need every m[i] >= 3; n = 4 is held but never swept; other n are not supported).");
         return EPIC_ERROR_INVALID_DATA;
     }
     Ctx *c = get_ctx(harmonic, true);
@@ -1794,7 +1807,7 @@ int harmonic_initialize_locked_gpu(Harmonic *harmonic)  // harmonic_model_gpu.cu
     }
     Ctx probe;
     if (!dims_from(harmonic, &probe)) {
-        report(fn, "Invalid input (only n = 2 and n = 3 with every m[i] >= 3 are supported).");
+        report(fn, "Invalid input (n = 2 and n = 3 need every m[i] >= 3; n = 4 is held but never swept; other n are not supported).");
         return EPIC_ERROR_INVALID_DATA;
     }
     Ctx *c = get_ctx(harmonic, true);
@@ -2052,6 +2065,10 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
         report(fn, "Invalid data.");
         return EPIC_ERROR_INVALID_DATA;
     }
+    if (c->n == 4) {   // no sweep ever changes delta: the reference's loop (harmonic_gpu.cu:266-290) would never return
+        report(fn, "Invalid data (n = 4 is a counting no-op: there is nothing to relax).");
+        return EPIC_ERROR_INVALID_DATA;
+    }
 
     harmonic->currentIteration = 0;
     fold_listed_work(c);
@@ -2135,6 +2152,14 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
     // what follows every check iteration (result and harmonic->delta are the check's)
     auto after_check = [&] {
         if (finish_wanted && !finish.on && harmonic->delta < finish_below) {
+            // A delta that has fallen by less than 0.3 % over the last check interval is a plateau on which the stop is decided by
+            // single ulps of single cells (maps/trivial.png: 0.15 % per 100 iterations): there an arithmetic that is not the
+            // reference's bit for bit cannot promise the reference's stop, whatever the hand-over factor.
+            if (handover.last_check > 0.0f && harmonic->delta > 0.997f * handover.last_check) {
+                fprintf(stderr, "Warning[epic_hip]: tol math on a slowly converging map (delta %.3e after %.3e one check earlier): the stop is decided by "
+                                "single ulps here and the tol arithmetic cannot promise the 1e-5 parity bar; the default (precise) math reproduces the reference.\n",
+                        (double)harmonic->delta, (double)handover.last_check);
+            }
             finish.on = true;
             c->finish_from = harmonic->currentIteration;
             c->math = 0;          // precise
@@ -2194,11 +2219,11 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
             // (Jacobi handover, the tol mode's finishing phase) -- the block enqueued ahead is let run and ignored: the state the
             // check refers to is intact.  The GPU never waits for the host between blocks (that wait was 12 % of a map's
             // relaxation: profiles/r04_experiments.txt); iterations, checks and results are those of the plain loop.
-            struct Blk { float *final_buf; unsigned it_end, steps; int slot; };
+            struct Blk { float *final_buf; unsigned it_end, steps; int slot, ntiles; };
             float *bufs[3] = {c->buf[0], c->buf[1], c->spare};
             int slot = 0;
+            const epic_hip::TilePlan tp = tile_plan(c);   // ONE plan for every block of this stretch (the mode cannot change inside it)
             auto enqueue_block = [&](float *in, unsigned first, Blk *out) -> hipError_t {
-                const epic_hip::TilePlan tp = tile_plan(c);
                 const unsigned total = (stagger - first % stagger) + 1;   // the plain iterations and the check
                 float *o1 = nullptr, *o2 = nullptr;
                 for (float *b : bufs)
@@ -2215,7 +2240,7 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
                     i += k;
                 }
                 hipError_t e = hipEventRecord(c->ev_blk[slot], c->stream);
-                *out = Blk{src, first + total, total, slot};
+                *out = Blk{src, first + total, total, slot, tp.tiles_r * tp.tiles_c};
                 slot ^= 1;
                 return e;
             };
@@ -2224,7 +2249,15 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
                 else c->cur = b.final_buf == c->buf[0] ? 0 : 1;
                 harmonic->d_u = current_u(c);
             };
-            Blk prev, next;
+            Blk prev, next, verified;      // verified: the latest block whose check has been read -- what currentIteration describes
+            bool have_verified = false;
+            // every error return below leaves the context in the state the iteration count describes: the blocks in flight are
+            // waited for (best effort) and the last verified block is adopted
+            auto bail = [&](int code) {
+                (void)hipStreamSynchronize(c->stream);
+                if (have_verified) adopt(verified);
+                return code;
+            };
             hipError_t pe = enqueue_block(c->buf[c->cur], harmonic->currentIteration, &prev);
             bool leave = false;
             while (pe == hipSuccess && !leave) {
@@ -2232,15 +2265,16 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
                 if (pe != hipSuccess) break;
                 if (hipEventSynchronize(c->ev_blk[prev.slot]) != hipSuccess) {
                     report(fn, "Failed to synchronize the device after the 'update and check' kernel.");
-                    return EPIC_ERROR_DEVICE_SYNCHRONIZE;
+                    return bail(EPIC_ERROR_DEVICE_SYNCHRONIZE);
                 }
-                const epic_hip::TilePlan tp = tile_plan(c);
                 float d = 0.0f;
                 const float *tile_max = c->h_tile_delta + (size_t)prev.slot * kTileDeltaCap;
-                for (int t = 0, n = tp.tiles_r * tp.tiles_c; t < n; ++t) d = std::max(d, tile_max[t]);
+                for (int t = 0; t < prev.ntiles; ++t) d = std::max(d, tile_max[t]);   // exactly the words that block's check wrote
                 harmonic->delta = d;
                 harmonic->currentIteration = prev.it_end;
                 c->work_full += (double)prev.steps;
+                verified = prev;
+                have_verified = true;
                 result = d < harmonic->epsilon ? EPIC_SUCCESS_AND_CONVERGED : EPIC_SUCCESS;
                 const int math0 = c->math;
                 const bool rb0 = c->redblack;
@@ -2249,7 +2283,7 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
                 const bool changed = c->math != math0 || c->redblack != rb0;
                 if (stop || changed) {
                     // the block enqueued ahead ran (or runs) in a mode, or past an end, that the check has just ruled out
-                    if (hipStreamSynchronize(c->stream) != hipSuccess) return EPIC_ERROR_DEVICE_SYNCHRONIZE;
+                    if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(EPIC_ERROR_DEVICE_SYNCHRONIZE);
                     adopt(prev);
                     leave = true;   // the outer loop ends (stop) or goes on from here in the new mode
                 } else {
@@ -2258,7 +2292,7 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
             }
             if (pe != hipSuccess) {
                 report(fn, "Failed to perform the Jacobi update step.");
-                return EPIC_ERROR_KERNEL_EXECUTION;
+                return bail(EPIC_ERROR_KERNEL_EXECUTION);
             }
         } else if (tile_checks(c, tile_plan(c))) {
             // Small grids (kernels_tile2d.hip): the plain iterations up to the next check AND that check are one sequence of tile

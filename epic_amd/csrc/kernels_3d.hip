@@ -380,6 +380,26 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB
 #ifndef EPIC_PAIR_BLOCK_WAVES
 #define EPIC_PAIR_BLOCK_WAVES 4
 #endif
+#ifndef EPIC_PAIR_SEQ
+#define EPIC_PAIR_SEQ 0
+#endif
+// EPIC_PAIR_LDS_OUTER = 1 (build knob, A/B): the rows of the two OUTER planes (x0 - 1 of plane A, x0 + 1 of plane B) do not wait
+// in registers while they are in flight: they are loaded two steps ahead by LDS-DMA (buffer_load_dwordx4 ... lds: 1 KiB per
+// wave-instruction, no destination registers) into a ring of four 2 KiB slots per wave and read back with two ds_read_b128 in
+// the step that splits them -- 16 VGPRs less for the rings.  One __shared__ array PER SLOT: the compiler orders a read behind
+// a pending LDS-DMA by a counted vmcnt only where its alias analysis can tell the slots apart (one array for all slots: vmcnt(0)
+// before every read, i.e. no prefetch at all); a wave's own reads need nothing but that wait (MI355X_MICROARCH.md item 7).
+#ifndef EPIC_PAIR_LDS_OUTER
+#define EPIC_PAIR_LDS_OUTER 0
+#endif
+// One row of a wave (64 lanes x 16 bytes) from memory straight into LDS at `lds_row` (wave-uniform; lane i lands at + 16 i).
+// A __device__ function, not a lambda of the kernel: the host pass of hipcc drops a kernel template whose (host-and-device)
+// lambdas name this device-only builtin -- silently, the kernel's handle is then an undefined symbol of the object file.
+template <class T>
+__device__ __forceinline__ void lds_dma_row(const __amdgpu_buffer_rsrc_t &rsrc, T *lds_row, unsigned lane_off, unsigned row_off)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_row, 16, lane_off, row_off, 0, 0);
+}
 constexpr int kPairWaves = EPIC_PAIR_BLOCK_WAVES;  // waves per workgroup = pairs of consecutive planes
 constexpr int kPairMinBlocks = EPIC_PAIR_MIN_BLOCKS;
 constexpr int kPairRows = 64;  // x1-rows per task (512^3: 32 rows 273.5 us, 64: 269.7, 128: 268.5, 256: 323 -- too few tasks)
@@ -396,6 +416,12 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pa
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float dmax = 0.0f;
+#if EPIC_PAIR_LDS_OUTER
+    // slot j of the ring: [wave][outer row a / b][lane]
+    typedef unsigned vu4s __attribute__((ext_vector_type(4)));
+    __shared__ vu4s outer_slot0[kPairWaves][2][kWave], outer_slot1[kPairWaves][2][kWave], outer_slot2[kPairWaves][2][kWave],
+        outer_slot3[kPairWaves][2][kWave];
+#endif
     typedef unsigned vu4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(4))) uint64_t cu64;
     struct RowSide { lmask m0, m1, m2, m3; };
@@ -470,6 +496,18 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pa
             dmax = max2(dmax, fabsf(c.w - o.w));
         };
 
+#if EPIC_PAIR_LDS_OUTER
+        auto slot = [&](const int j) -> vu4s(*)[kWave] {   // j: a constant in every expansion
+            return j == 0 ? outer_slot0[wave] : j == 1 ? outer_slot1[wave] : j == 2 ? outer_slot2[wave] : outer_slot3[wave];
+        };
+        // the outer rows of step t into slot j (the same addresses as ld(): t clamped like there)
+        auto ld_outer = [&](const int j, int t) {
+            t = min(max(t, 0), t_max);
+            vu4s(*s)[kWave] = slot(j);
+            lds_dma_row(rin, &s[0][0], lane16, oa + t_off(t));
+            lds_dma_row(rin, &s[1][0], lane16, ob + t_off(t));
+        };
+#endif
         // rings, rotated through constant indices of fully unrolled steps (no moves): the pair's rows 2 ahead over four sets
         // (steps j - 1, j, j + 1 in use, j + 2 in flight), their splits likewise, the outer rows 2 ahead
         float4 qA[4], qB[4], pa[4], pb[4];
@@ -482,8 +520,13 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pa
         eA[0] = eld(ocA, t0); eB[0] = eld(ocB, t0);
         qA[1] = ld(ocA, t0 + 1); qB[1] = ld(ocB, t0 + 1);
         eA[1] = eld(ocA, t0 + 1); eB[1] = eld(ocB, t0 + 1);
+#if EPIC_PAIR_LDS_OUTER
+        ld_outer(0, t0);
+        if (kPairOuterAhead > 1) ld_outer(1, t0 + 1);
+#else
         pa[0] = ld(oa, t0); pb[0] = ld(ob, t0);
         if (kPairOuterAhead > 1) { pa[1] = ld(oa, t0 + 1); pb[1] = ld(ob, t0 + 1); }
+#endif
         hA[0] = side(cA, t0); hB[0] = side(cB, t0);
         sA[3] = tol_split4(qA[3]); sB[3] = tol_split4(qB[3]);
         sA[0] = tol_split4(qA[0]); sB[0] = tol_split4(qB[0]);
@@ -491,7 +534,16 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pa
         auto step = [&](int t, const int k) {  // k = (t - t0) & 3, a constant in every expansion
             const int km = (k + 3) & 3, kp = (k + 1) & 3, kn = (k + 2) & 3;
             const int ko = (k + kPairOuterAhead) & 3;
+#if EPIC_PAIR_LDS_OUTER
+            qA[kn] = ld(ocA, t + 2); qB[kn] = ld(ocB, t + 2); ld_outer(ko, t + kPairOuterAhead);
+            {   // (the compiler waits for exactly this slot's two transfers: counted vmcnt)
+                const vu4s ra = slot(k)[0][lane], rb = slot(k)[1][lane];
+                pa[k] = make_float4(u2f(ra.x), u2f(ra.y), u2f(ra.z), u2f(ra.w));
+                pb[k] = make_float4(u2f(rb.x), u2f(rb.y), u2f(rb.z), u2f(rb.w));
+            }
+#else
             qA[kn] = ld(ocA, t + 2); qB[kn] = ld(ocB, t + 2); pa[ko] = ld(oa, t + kPairOuterAhead); pb[ko] = ld(ob, t + kPairOuterAhead);
+#endif
             eA[kn] = eld(ocA, t + 2); eB[kn] = eld(ocB, t + 2);
             hA[kp & 1] = side(cA, t + 1); hB[kp & 1] = side(cB, t + 1);
             sA[kp] = tol_split4(qA[kp]); sB[kp] = tol_split4(qB[kp]);
@@ -504,16 +556,25 @@ __global__ __launch_bounds__(kWave * kPairWaves, kPairMinBlocks) void sweep3d_pa
             // the reference's order of the six neighbours: x0 - 1, x0 + 1, x1 - 1, x1 + 1, (x2 - 1, x2 + 1 inside tol_row_3d)
             // both rows' table reads are issued before either is waited for (Jacobi: 8 reads in flight; red-black: 4): the row
             // B's front end covers row A's round trip to LDS and the other way round
-            TolRowFront fA, fB;
-            if (!X0M) {  // pair axis = x0, ring = x1
-                fA = tol_row_3d_front<RB>(pa[k], qB[k], qA[km], qA[k], qA[kp], so_a, sB[k], sA[km], sA[k], sA[kp], eA[k], eA[k], esA, evenA, tl);
-                fB = tol_row_3d_front<RB>(qA[k], pb[k], qB[km], qB[k], qB[kp], sA[k], so_b, sB[km], sB[k], sB[kp], eB[k], eB[k], esB, !evenA, tl);
-            } else {     // ring = x0, pair axis = x1
-                fA = tol_row_3d_front<RB>(qA[km], qA[kp], pa[k], qA[k], qB[k], sA[km], sA[kp], so_a, sA[k], sB[k], eA[k], eA[k], esA, evenA, tl);
-                fB = tol_row_3d_front<RB>(qB[km], qB[kp], qA[k], qB[k], pb[k], sB[km], sB[kp], sA[k], sB[k], so_b, eB[k], eB[k], esB, !evenA, tl);
-            }
+            // (X0M = false: pair axis = x0, ring = x1; X0M = true: ring = x0, pair axis = x1)
+            auto frontA = [&] {
+                return !X0M ? tol_row_3d_front<RB>(pa[k], qB[k], qA[km], qA[k], qA[kp], so_a, sB[k], sA[km], sA[k], sA[kp], eA[k], eA[k], esA, evenA, tl)
+                            : tol_row_3d_front<RB>(qA[km], qA[kp], pa[k], qA[k], qB[k], sA[km], sA[kp], so_a, sA[k], sB[k], eA[k], eA[k], esA, evenA, tl);
+            };
+            auto frontB = [&] {
+                return !X0M ? tol_row_3d_front<RB>(qA[k], pb[k], qB[km], qB[k], qB[kp], sA[k], so_b, sB[km], sB[k], sB[kp], eB[k], eB[k], esB, !evenA, tl)
+                            : tol_row_3d_front<RB>(qB[km], qB[kp], qA[k], qB[k], pb[k], sB[km], sB[kp], sA[k], sB[k], so_b, eB[k], eB[k], esB, !evenA, tl);
+            };
+#if EPIC_PAIR_SEQ   // build knob (A/B): row A is finished before row B is begun -- lower register pressure inside the step, the two rows' table reads do not overlap
+            TolRowFront fA = frontA();
+            const float4 oA = tol_row_3d_back<RB, 2, 0>(fA, qA[k], ha.m0, ha.m1, ha.m2, ha.m3, evenA);
+            TolRowFront fB = frontB();
+            const float4 oB = tol_row_3d_back<RB, 2, 0>(fB, qB[k], hb.m0, hb.m1, hb.m2, hb.m3, !evenA);
+#else
+            TolRowFront fA = frontA(), fB = frontB();
             const float4 oA = tol_row_3d_back<RB, 6, (RB ? 2 : 4)>(fA, qA[k], ha.m0, ha.m1, ha.m2, ha.m3, evenA);
             const float4 oB = tol_row_3d_back<RB, 2, 0>(fB, qB[k], hb.m0, hb.m1, hb.m2, hb.m3, !evenA);
+#endif
             const bool chk_t = !X0M || (t >= a.check_lo && t < a.check_hi);  // scalar
             if (chkA && chk_t) fold(qA[k], oA);
             if (chkB && chk_t) fold(qB[k], oB);

@@ -52,7 +52,8 @@ int epic_hip_iterations_per_pass(EpicHarmonicT *harmonic);
 /* Small 2-D grids (at most 3 Mcell, one device, activity tracking off -- the maps the reference's callers relax): the plain
  * iterations between two checks run SEVERAL PER LAUNCH on tiles that stay in LDS with that many ghost rings
  * (epic_amd/csrc/kernels_tile2d.hip); bit-identical to single iterations.  Returns the iterations one such launch advances
- * (8 to 14, chosen per grid), 0 where the path is not used.  EPIC_HIP_TILE=0 switches it off; EPIC_HIP_TILE_HALO / _ROWS / _MAX_CELLS tune it. */
+ * (8, 10, 12, 14 or 16, chosen per grid by a cost model of the launch; 1 to 27 when EPIC_HIP_TILE_HALO fixes it), 0 where the path
+ * is not used.  EPIC_HIP_TILE=0 switches it off; EPIC_HIP_TILE_HALO / _ROWS / _WIDTH / _MAX_CELLS tune it. */
 int epic_hip_tile_iterations(EpicHarmonicT *harmonic);
 
 /* Rows per task of that fused pass in the current configuration (0: no fused pass).  On grids of at least 4 Mcell on one
@@ -65,8 +66,15 @@ int epic_hip_fused_rows_per_task(EpicHarmonicT *harmonic);
  * delta < 10 epsilon (100 epsilon for epsilon <= 1e-5) and FINISHES with the reference's own iteration (red-black half-sweeps, bit-exact expf / logf), and only
  * a check of that phase may end it -- the converged field is then the end point of the reference's iteration from a state
  * within a few 1e-5 of it: maps/umass.png 1.4e-6 from harmonic_complete_cpu's field instead of 1.6e-5.
- * EPIC_HIP_TOL_FINISH=0 in the environment keeps the tol iteration to the end.  Returns the iteration number at which the
- * finishing phase of the latest call began (0: it had none). */
+ * EPIC_HIP_TOL_FINISH=0 in the environment keeps the tol iteration to the end (honoured for epsilon <= 1e-5 only: above, the
+ * finishing phase is what makes the stop the reference's).  EPIC_HIP_TOL_FINISH_FACTOR=f replaces the 10 / 100 (a study knob:
+ * tools/finish_study_gpu.py swept it over every map of the reference).
+ * WHAT tol CANNOT PROMISE: on maps whose delta crosses epsilon in steps of single ulps (the reference's maps/trivial.png, an
+ * almost empty 1024^2 room: delta falls 0.15 % per 100 iterations) the iteration at which the loop stops is decided by single
+ * ulps of single cells; no hand-over factor is safe there (4e-3 from the reference for factors 10, 50, 300; inside the bar for
+ * 20 and 100 -- by chance), and only the default precise math reproduces the reference.  The library says so once on stderr
+ * when a tol relaxation reaches its hand-over on such a plateau (delta down by < 0.3 % over the last check interval).
+ * Returns the iteration number at which the finishing phase of the latest call began (0: it had none). */
 unsigned int epic_hip_finish_iteration(EpicHarmonicT *harmonic);
 
 /* Tuning knob: rows marched by one wave in the 2-D kernel (0 = automatic).  Also EPIC_HIP_ROWS_PER_TASK. */

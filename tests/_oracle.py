@@ -159,3 +159,21 @@ def load_png_reference_rule(path):
     u = np.where(px == 255, np.float32(0.0), np.float32(-1e6)).astype(np.float32)
     locked = ((px == 0) | (px == 255)).astype(np.uint32)
     return [px.shape[0], px.shape[1]], u, locked
+
+
+def session_scheme():
+    """The iteration scheme a library context created NOW runs: EPIC_HIP_SCHEME as the library reads it (absent: its default,
+    the reference's red-black half-sweeps).  tests/conftest.py sets the variable for the session (EPIC_TEST_SCHEME)."""
+    return "jacobi" if os.environ.get("EPIC_HIP_SCHEME") == "jacobi" else "redblack"
+
+
+def run_session(p, k):
+    """k iterations of the session's scheme on Problem p with the reference's arithmetic, from p.h.currentIteration on; the last
+    one is a check (p.h.delta = its max |du|) -- what k - 1 harmonic_update_gpu + one harmonic_update_and_check_gpu of a
+    context without an explicit epic_hip_set_scheme must reproduce."""
+    lib = oracle()
+    if session_scheme() == "jacobi":
+        return lib.oracle_jacobi_run(ct.byref(p.h), k)
+    for i in range(k):
+        (lib.oracle_update_and_check if i == k - 1 else lib.oracle_update)(ct.byref(p.h))
+    return 0

@@ -9,12 +9,17 @@ import pytest
 os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
 
 # The library's default iteration is the reference's red-black half-sweep (bit-identical to harmonic_complete_cpu with the
-# default precise math).  Most of this suite was written against the Jacobi scheme -- the one BASELINE.json's metric names and
-# bench.py times -- and compares with the checker's Jacobi, so the session selects it the way a user would; the tests of the
-# DEFAULT remove the variable again (scheme_env(None) below): tests/test_gpu_bench_parity.py::test_empty_environment_...,
-# tests/test_gpu_tile.py::test_maps_relax_through_tiles_..., tests/test_gpu_callers_eps.py (every reference map at the
-# callers' epsilons) and the C++ plugin replay (tests/test_gpu_plugin_replay.py), which runs without any variable.
-os.environ.setdefault("EPIC_HIP_SCHEME", "jacobi")
+# default precise math); BASELINE.json's metric names the Jacobi scheme, which is what bench.py times.  The suite runs under
+# EITHER for the session, selected the way a user would select it -- the environment the library reads:
+#   EPIC_TEST_SCHEME=jacobi  (default)  EPIC_HIP_SCHEME=jacobi for every context that does not set a scheme itself
+#   EPIC_TEST_SCHEME=default            the variable is left unset: every such context runs the LIBRARY DEFAULT (red-black)
+# Tests that need one scheme set it themselves (epic_hip_set_scheme, scheme_env below); the others compare with the checker's
+# statement of the session's scheme (_oracle.run_session).  Both modes are run on the GPU box every round.
+if os.environ.get("EPIC_TEST_SCHEME", "jacobi") == "jacobi":
+    os.environ.setdefault("EPIC_HIP_SCHEME", "jacobi")
+else:
+    assert os.environ["EPIC_TEST_SCHEME"] == "default", "EPIC_TEST_SCHEME is jacobi or default"
+    os.environ.pop("EPIC_HIP_SCHEME", None)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,7 +28,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "multi_gpu: needs at least two GPUs and EPIC_TEST_MULTI_GPU=1 (always combined with gpu; skips itself otherwise)")
+    config.addinivalue_line("markers", "multi_gpu: needs at least two GPUs (always combined with gpu; skips itself on one; EPIC_TEST_MULTI_GPU=0 opts out)")
 
 
 @pytest.fixture(scope="session", autouse=True)

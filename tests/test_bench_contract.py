@@ -161,3 +161,25 @@ def test_round_4_legs_config5_config4_maps_and_the_callers_epsilon():
     rule, old = ic["rule (hand-over at 100 eps)"], ic["hand-over at 10 eps (round 3's rule)"]
     assert rule["within_bar"] is True and rule["iterations"] == ic["reference_iterations"]
     assert old["within_bar"] is False and ic["reference_iterations"] - old["iterations"] > 10000
+
+
+def test_plain_multi_gpu_command_starts_its_own_ranks_as_a_child():
+    """`python3 bench.py --gpus 2` with no launcher in front: the parent starts torch.distributed.run as a CHILD before it
+    imports torch or touches a device, relays the ranks' output and returns their exit code.  Without a GPU (this container)
+    the ranks themselves must be what reports the missing device -- on a GPU box tests/test_gpu_bench_launch.py reads the line."""
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: tests/test_gpu_bench_launch.py runs the command to the end")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["EPIC_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "must be launched with" not in r.stderr          # round 4's refusal is gone
+    assert "no GPU visible" in r.stderr                      # said by a rank, i.e. the ranks were started
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index("sys.exit(self_launch(args))") < src.index("import torch  # first")   # before torch is imported

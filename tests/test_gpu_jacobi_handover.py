@@ -35,6 +35,12 @@ def gpu_complete(u, locked, env, monkeypatch):
     return h.u_array().reshape(GRID).copy(), int(h.currentIteration), float(h.delta)
 
 
+@pytest.fixture(autouse=True)
+def jacobi_session(monkeypatch):
+    """These tests are about the Jacobi scheme whatever the session runs (tests/conftest.py: EPIC_TEST_SCHEME)."""
+    monkeypatch.setenv("EPIC_HIP_SCHEME", "jacobi")
+
+
 @pytest.mark.parametrize("math", ["precise", "tol"])
 @pytest.mark.parametrize("devices", [None, "0,0,0"])
 def test_second_goal_terminates_and_equals_the_checker(math, devices, monkeypatch):

@@ -31,8 +31,8 @@ ALL_LISTS = [("0,0", "8"), ("0,0,0,0", "3"), ("0,0,0", "1"), ("0,0,0,0,0,0,0,0",
 ALL_IDS = ["2slabs_halo8", "4slabs_halo3", "3slabs_halo1", "8slabs_halo8"]
 # On a node with several GPUs the same tests also run with one slab per REAL device (hipMemcpyPeerAsync between devices,
 # per-device streams and events): every device once, and every device twice interleaved ("0,1,0,1"...).
-# (opt-in with EPIC_TEST_MULTI_GPU=1: copies between two real devices have never run in this project's 1-GPU sessions)
-_NDEV = E.epic_hip_device_count() if os.environ.get("EPIC_TEST_MULTI_GPU") == "1" else 0
+# (automatic wherever the library sees two or more devices; EPIC_TEST_MULTI_GPU=0 switches it off)
+_NDEV = E.epic_hip_device_count() if os.environ.get("EPIC_TEST_MULTI_GPU", "1") != "0" else 0
 if _NDEV >= 2:
     _real = ",".join(str(d) for d in range(min(_NDEV, 8)))
     ALL_LISTS += [(_real, "8"), (_real + "," + _real, "3")]
@@ -110,7 +110,7 @@ def test_navigation_node_flow_with_live_edits(devices):
     p = O.Problem(m, u0, locked)
     lib = O.oracle()
     assert E.epic_hip_update_n_gpu(h, 11, 0) == 0
-    lib.oracle_jacobi_run(ct.byref(p.h), 11)
+    O.run_session(p, 11)
     edits, types = [], []
     for (_, lo, hi, _g) in slabs[1:]:        # a goal on the last row of the slab above, an obstacle on the first row of this one
         edits += [(37, lo - 1), (150, lo), (151, lo + 1)]
@@ -121,7 +121,7 @@ def test_navigation_node_flow_with_live_edits(devices):
     assert E.harmonic_utilities_set_cells_2d_gpu(h, NT, *args) == 0
     assert lib.oracle_set_cells_2d(ct.byref(p.h), *args) == 0
     assert E.epic_hip_update_n_gpu(h, 23, 1) in (0, 1)
-    lib.oracle_jacobi_run(ct.byref(p.h), 23)
+    O.run_session(p, 23)
     assert E.harmonic_get_potential_values_gpu(h) == 0
     P.gpu_fini(h)
     assert np.array_equal(h.u_array().ravel(), p.u) and h.delta == p.h.delta
@@ -219,7 +219,7 @@ def test_config4_32768_squared_on_slabs(devlist):
     assert moved == int((ref != u0.reshape(n, n)).sum()) and 0 < moved <= 2 * (2 * K + 1) ** 2
     win = (slice(c - W, c + W), slice(c - W, c + W))
     p = O.Problem([2 * W, 2 * W], u0.reshape(n, n)[win].copy(), locked.reshape(n, n)[win].copy())
-    O.oracle().oracle_jacobi_run(ct.byref(p.h), K)
+    O.run_session(p, K)
     assert np.array_equal(ref[win].ravel(), p.u)
 
 

@@ -80,8 +80,10 @@ def gpu_sweeps(m, u0, locked, k, rows_per_task=0):
 
 
 def oracle_jacobi(m, u0, locked, k):
+    """k iterations of the SESSION's scheme by the checker (tests/conftest.py: Jacobi unless EPIC_TEST_SCHEME=default, then the
+    library default, the reference's red-black) -- what gpu_sweeps(), which sets no scheme, must reproduce."""
     p = O.Problem(m, u0, locked)
-    assert O.oracle().oracle_jacobi_run(ct.byref(p.h), k) == 0
+    assert O.run_session(p, k) == 0
     return p.u, float(p.h.delta)
 
 
@@ -254,6 +256,32 @@ def test_execute_gpu_validation_and_lifecycle(capfd):
     assert "Error[harmonic_execute_gpu]" in capfd.readouterr().err
 
 
+def test_n4_is_held_on_the_device_and_counted_but_never_swept(capfd):
+    """harmonic_gpu.cu:156-162, :327-336: the reference's n == 4 branches are empty -- the state goes to the device, every
+    update advances currentIteration and sweeps nothing.  The same here (the CPU half: tests/test_cpu_abi.py::test_n4_...);
+    harmonic_execute_gpu refuses n = 4, where the reference's loop would never return (no sweep ever lowers delta)."""
+    h = Harmonic()
+    u0 = np.linspace(-5.0, 0.0, 3 * 4 * 5 * 6, dtype=np.float32)
+    h.set_grid([3, 4, 5, 6], u0, np.zeros(u0.size, np.uint32))
+    for fn in (E.harmonic_initialize_dimension_size_gpu, E.harmonic_initialize_potential_values_gpu, E.harmonic_initialize_locked_gpu):
+        assert fn(h) == 0, fn.__name__
+    assert h.d_m and h.d_u and h.d_locked
+    assert E.harmonic_initialize_gpu(h, NT) == 0 and h.d_delta
+    h.delta = 7.0
+    for k in range(1, 4):
+        assert E.harmonic_update_gpu(h, NT) == 0 and h.currentIteration == k
+    assert E.harmonic_update_and_check_gpu(h, NT) == 0 and h.currentIteration == 4 and h.delta == 7.0   # (delta untouched, as on the CPU)
+    assert E.epic_hip_update_n_gpu(h, 10, 0) == 0 and h.currentIteration == 14
+    h.u_array().ravel()[:] = 1.0
+    assert E.harmonic_get_potential_values_gpu(h) == 0 and np.array_equal(h.u_array().ravel(), u0)       # what was uploaded
+    assert E.harmonic_execute_gpu(h, NT) == eh.EPIC_ERROR_INVALID_DATA
+    assert "n = 4 is a counting no-op" in capfd.readouterr().err
+    for fn in (E.harmonic_uninitialize_gpu, E.harmonic_uninitialize_dimension_size_gpu, E.harmonic_uninitialize_potential_values_gpu,
+               E.harmonic_uninitialize_locked_gpu):
+        assert fn(h) == 0, fn.__name__
+    assert not h.d_m and not h.d_u and not h.d_locked and not h.d_delta
+
+
 def test_navigation_node_flow_set_cells_and_mid_solve_readback():
     """src/epic_navigation_node_harmonic.cpp:165-189, :357-380, :522-542: update(k) batches, live cell edits on the
     resident state, full-field readback between batches; then update_model re-upload."""
@@ -268,7 +296,7 @@ def test_navigation_node_flow_set_cells_and_mid_solve_readback():
         rc = E.harmonic_update_and_check_gpu(h, NT)
         assert rc in (0, 1)
         assert E.epic_hip_update_n_gpu(h, k - 1, 0) == 0
-        lib.oracle_jacobi_run(ct.byref(p.h), k)
+        O.run_session(p, k)
 
     batch(10)
     assert E.harmonic_get_potential_values_gpu(h) == 0
@@ -296,8 +324,9 @@ def test_navigation_node_flow_set_cells_and_mid_solve_readback():
     h.locked_array().ravel()[:] = locked
     assert E.harmonic_update_model_gpu(h) == 0
     p2 = O.Problem(m, u0, locked)
+    p2.h.currentIteration = h.currentIteration     # (red-black: the iteration number selects the colour)
     assert E.epic_hip_update_n_gpu(h, 6, 1) in (0, 1)
-    lib.oracle_jacobi_run(ct.byref(p2.h), 6)
+    O.run_session(p2, 6)
     assert E.harmonic_get_potential_values_gpu(h) == 0
     assert_close(h.u_array(), p2.u, p2.locked, FIXED_TOL, "after update_model")
     gpu_fini(h)
@@ -321,7 +350,7 @@ def test_full_size_8192_window_property():
     lw = locked.reshape(n, n)[win].copy()
     uw = u0.reshape(n, n)[win].copy()
     p = O.Problem([2 * W, 2 * W], uw, lw)
-    O.oracle().oracle_jacobi_run(ct.byref(p.h), K)
+    O.run_session(p, K)
     assert_close(got[win], p.u, lw, FIXED_TOL, "window around the goal")
     outside = np.ones((n, n), dtype=bool)
     outside[win] = False
@@ -405,7 +434,9 @@ def test_raw_operator_row_ranges_match_whole_sweep():
                                    eh.MATH_PRECISE, d2.data_ptr(), s) == 0
     torch.cuda.synchronize()
     assert torch.equal(b1, b2) and int(d1.item()) == int(d2.item()) and int(d1.item()) != 0
-    want, wdelta = oracle_jacobi([rows, cols], u0, locked, 1)
+    p = O.Problem([rows, cols], u0, locked)     # (epic_hip_sweep_2d IS the Jacobi sweep, whatever the session's scheme)
+    assert O.oracle().oracle_jacobi_run(ct.byref(p.h), 1) == 0
+    want, wdelta = p.u, float(p.h.delta)
     assert_close(b1[:, :cols].cpu().numpy(), want, locked, FIXED_TOL, "raw operator")
     assert abs(np.int32(d1.item()).view(np.float32) - wdelta) <= 1e-5 * max(1.0, wdelta)
 
@@ -486,7 +517,9 @@ def test_slab_solver_hip_backend_single_rank():
         s.sweep(check=(i == 22))
     delta = s.reduce_delta()
     u0, locked = synthetic_grid(grid, 4, 0.05)
-    want, wdelta = oracle_jacobi(grid, u0, locked, 23)
+    p = O.Problem(grid, u0, locked)     # (SlabSolver's own default scheme is Jacobi, whatever the session's)
+    assert O.oracle().oracle_jacobi_run(ct.byref(p.h), 23) == 0
+    want, wdelta = p.u, float(p.h.delta)
     assert np.array_equal(s.owned().ravel(), want)
     assert delta == wdelta
 
@@ -684,7 +717,7 @@ def test_activity_tracking_survives_model_reupload_and_graph_replay():
             assert E.epic_hip_update_n_gpu(h, n, 1) in (0, 1)
         assert E.harmonic_get_potential_values_gpu(h) == 0
         p = O.Problem(m, u0, locked)
-        assert lib.oracle_jacobi_run(ct.byref(p.h), 341) == 0
+        assert O.run_session(p, 341) == 0
         assert np.array_equal(h.u_array().ravel(), p.u) and float(h.delta) == float(p.h.delta)
         h.u_array().ravel()[:] = u0   # start over from the host copy
         h.currentIteration = 0
@@ -695,7 +728,7 @@ def test_activity_tracking_survives_model_reupload_and_graph_replay():
         assert E.epic_hip_update_n_gpu(h, n, 1) in (0, 1)
     assert E.harmonic_get_potential_values_gpu(h) == 0
     p = O.Problem(m, u0, locked)
-    assert lib.oracle_jacobi_run(ct.byref(p.h), 256) == 0
+    assert O.run_session(p, 256) == 0
     assert np.array_equal(h.u_array().ravel(), p.u) and float(h.delta) == float(p.h.delta)
     gpu_fini(h)
 

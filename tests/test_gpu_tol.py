@@ -275,7 +275,7 @@ def test_tol_fused_pairs_with_live_edits_and_model_updates(monkeypatch):
     def batch(k):
         assert E.harmonic_update_and_check_gpu(h, NT) in (0, 1)
         assert E.epic_hip_update_n_gpu(h, k - 1, 0) == 0
-        assert lib.oracle_tol_run(ct.byref(p.h), k, 0) == 0
+        assert lib.oracle_tol_run(ct.byref(p.h), k, 0 if O.session_scheme() == "jacobi" else 1) == 0   # the session's scheme (conftest.py)
 
     for k, edits in ((10, [(250, 40, 0), (10, 5, 1)]), (25, [(251, 40, 1), (10, 5, 2), (200, 20, 0)]), (8, [(30, 30, 1)]), (13, [])):
         batch(k)
@@ -292,7 +292,7 @@ def test_tol_fused_pairs_with_live_edits_and_model_updates(monkeypatch):
     h.locked_array().ravel()[:] = locked
     assert E.harmonic_update_model_gpu(h) == 0
     assert E.epic_hip_set_math_mode(h, eh.MATH_TOL) == 0
-    want, wdelta = checker_iterations(m, u0, locked, 7, eh.SCHEME_JACOBI)
+    want, wdelta = checker_iterations(m, u0, locked, 7, eh.SCHEME_JACOBI if O.session_scheme() == "jacobi" else eh.SCHEME_REDBLACK)
     assert E.epic_hip_update_n_gpu(h, 7, 1) in (0, 1)
     assert E.harmonic_get_potential_values_gpu(h) == 0
     assert np.array_equal(h.u_array().ravel(), want) and float(h.delta) == wdelta
