@@ -848,6 +848,7 @@ def main():
         # the dominant kernel on its own: a batch of plain iterations (no check) is launches of that kernel only -- the
         # fused pass where the library fuses (two iterations per launch), the single sweep otherwise
         per_pass = max(1, int(E.epic_hip_iterations_per_pass(h)))
+        library_dump = eh.config_dump(h)   # what the timed context was configured with and which path it is on, in the library's own words
         batch = 2 * (args.stagger // 2)
         kms, ms1 = 0.0, ct.c_float(0.0)
         for _ in range(max(2, args.steps)):
@@ -857,10 +858,13 @@ def main():
         cells_per_launch = n * n if args.scheme == "jacobi" else n * n // 2   # cells one ITERATION recomputes
         single_us = None
         if per_pass == 2:   # the single sweep of the same arithmetic, same run: what the fusion buys
+            # (the library reads its environment once per context: a knob changed on a live one is announced -- include/epic_hip.h)
             os.environ["EPIC_HIP_NO_FUSE"] = "1"
+            assert E.epic_hip_config_reload(h) == 0
             assert E.epic_hip_timed_sweeps_gpu(h, batch, 0, ct.byref(ms1)) == 0
             assert E.epic_hip_timed_sweeps_gpu(h, batch, 0, ct.byref(ms1)) == 0
             del os.environ["EPIC_HIP_NO_FUSE"]
+            assert E.epic_hip_config_reload(h) == 0
             single_us = ms1.value * 1e3 / batch
         out.update({
             "value": round(updates_in(args.scheme, sweeps, develop + args.warmup * args.stagger) / wall / 1e6, 1),
@@ -875,7 +879,10 @@ def main():
             },
             "roofline": roofline(cells_per_launch, launch_us, args.math, args.scheme, True, per_pass),
             "step_us_per_iteration": round(step_us_per_sweep, 3),
+            "library": library_dump,   # epic_hip_config_dump of the timed context: every EPIC_HIP_* knob as read, state, kernel path
         })
+        if library_dump:
+            out["config"]["kernel_path"] = library_dump["path"]["plain_batch"]
         if single_us is not None:
             out.setdefault("kernels", {})["single_sweep"] = {
                 "launch_us": round(single_us, 3),
@@ -899,6 +906,7 @@ def main():
             for key, math, scheme, track in legs:
                 if key == "relax_tol_alone":
                     os.environ["EPIC_HIP_TOL_FINISH"] = "0"
+                    assert E.epic_hip_config_reload(h) == 0
                 h.u_array().ravel()[:] = u0
                 assert E.harmonic_update_model_gpu(h) == 0
                 assert E.epic_hip_set_math_mode(h, MODES[math]) == 0
@@ -908,7 +916,9 @@ def main():
                 t0 = time.perf_counter()
                 rc = E.harmonic_execute_gpu(h, 1024)
                 dt = time.perf_counter() - t0
-                os.environ.pop("EPIC_HIP_TOL_FINISH", None) if key == "relax_tol_alone" else None
+                if key == "relax_tol_alone":
+                    os.environ.pop("EPIC_HIP_TOL_FINISH", None)
+                    assert E.epic_hip_config_reload(h) == 0
                 assert rc == 0, rc
                 its = int(h.currentIteration)
                 assert E.epic_hip_work_done(h, ct.byref(work), 0) == 0    # whole-grid iterations' worth of tiles actually run

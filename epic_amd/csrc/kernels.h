@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "driver_config.h"   // LaunchKnobs: what the launchers take from the environment (read in driver_config.cpp only)
+
 namespace epic_hip {
 
 // ---- 2-D (kernels_2d.hip) -------------------------------------------------------------------
@@ -37,11 +39,7 @@ inline size_t sweep_2d_list_cap(size_t tiles) { return (tiles + kWakeListCount -
 // (8192^2 tol relaxation: 2.74 s with 8192 waves, 2.66 with 4096, 2.97 with 2048).  EPIC_HIP_LIST_WAVES overrides.
 inline int sweep_2d_list_blocks(size_t tiles, int resident_blocks)
 {
-    static const size_t forced = [] {
-        const char *e = getenv("EPIC_HIP_LIST_WAVES");
-        const long v = e ? atol(e) : 0;
-        return (size_t)(v >= 4 ? v : 0);
-    }();
+    const size_t forced = process_launch_knobs().list_waves;
     const size_t waves = forced ? forced : (size_t)(resident_blocks > 0 ? resident_blocks : 2048) * 4;
     return (int)(((tiles < waves ? tiles : waves) + 31) / 32) * 8;
 }
@@ -152,7 +150,7 @@ hipError_t launch_follow_paths_2d(const float *u, const uint32_t *maskw, int row
 
 // tol math, 2-D: rows are loaded kTolRowsAhead steps ahead of their use through a ring of kTolRowsAhead + 3 register sets; the
 // pipelined loop runs in trips of kTolTripRows rows (the rings close after lcm(ring, 2) steps), and the host picks rows per
-// task in multiples of it (harmonic_gpu.hip: auto_rows_per_task).
+// task in multiples of it (driver_plan.hip: auto_rows_per_task).
 #ifndef EPIC_TOL_AHEAD  // build knob (A/B)
 #define EPIC_TOL_AHEAD 2
 #endif
@@ -205,7 +203,8 @@ __host__ __device__ inline unsigned mask_bit_2d(unsigned c) { return (c >> 2) & 
 // ---- 3-D (kernels_3d.hip) -------------------------------------------------------------------
 hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, int m0, int m1, int pitch,
                            int plane_begin, int plane_end, int math, int parity, unsigned *delta_bits,
-                           hipStream_t stream, const Activity *act = nullptr, int check_begin = -1, int check_end = -1);
+                           hipStream_t stream, const Activity *act = nullptr, int check_begin = -1, int check_end = -1,
+                           const LaunchKnobs *knobs = nullptr);   // knobs: the caller's context's (null: the process-wide ones)
 // tiles of the 3-D sweep: one per (x0-plane, 32-row x1-chunk, 256-column x2-strip)
 inline size_t sweep_3d_tiles(int m0, int m1, int pitch)
 {

@@ -451,7 +451,7 @@ constexpr int kFusedOut = 248;  // owned columns per wave
 // iterations reach two cells far: its own cells, the two nearest rows of the tiles above and below, the two nearest columns
 // of the tiles left and right, and the one corner cell of each diagonal neighbour.  A tile that is skipped holds, in BOTH
 // buffers, the values the pass would have written (it did not change in the previous pass, and nothing it reads did).  The
-// lists of this tiling are separate from the plain sweep's (different tiles): harmonic_gpu.hip runs every tile in the first
+// lists of this tiling are separate from the plain sweep's (different tiles): driver_enqueue.hip runs every tile in the first
 // pass after anything else has touched the field.
 // CHECK: max |du| of the SECOND iteration of the pass (the one a check iteration is when the host makes it the last of a
 // batch): |level B - level A| over the cells level B recomputes, owned lanes only.
@@ -1046,14 +1046,7 @@ namespace {
 // EPIC_HIP_FLAGS: bit 0 = alternate march direction (default 1).  Stores are always non-temporal (bit 1 used to switch
 // that; measured on 8192^2 when both were switchable: traffic-only build 115.6 -> 96.6 us, red-black 104.2 -> 100.5 us,
 // precise Jacobi 161.3 -> 155.8 us).
-int sweep_flags()
-{
-    static const int flags = [] {
-        const char *e = getenv("EPIC_HIP_FLAGS");
-        return e ? atoi(e) : 3;
-    }();
-    return flags;
-}
+int sweep_flags() { return process_launch_knobs().flags; }   // (the environment is read in driver_config.cpp only)
 
 // Workgroups of a launch whose workgroups walk `nblocks` logical blocks: what the chip keeps resident of `kernel`, in whole
 // groups of the 8 XCDs (blocks are dealt round-robin over them; a stride that is a multiple of 8 keeps a workgroup's blocks

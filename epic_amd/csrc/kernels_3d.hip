@@ -664,23 +664,12 @@ template <bool CHECK, bool RB> void launch_sweep_3d_pair(dim3 block, hipStream_t
     if (x0m) launch_sweep_3d_pair_axis<CHECK, RB, true>(block, stream, a);
     else launch_sweep_3d_pair_axis<CHECK, RB, false>(block, stream, a);
 }
-// EPIC_HIP_3D_MARCH=x0|x1: the axis the pair kernel marches along (x1: pairs of planes; x0: pairs of rows)
-bool sweep_3d_pair_x0_march()
+// (LaunchKnobs, driver_config.h: EPIC_HIP_3D_MARCH=x0|x1 -- the axis the pair kernel marches along, x1: pairs of planes, x0: pairs of
+//  rows; EPIC_HIP_3D_PAIR=0 -- the one-plane-per-wave kernel for every launch (A/B, tests); EPIC_HIP_3D_PAIR_ROWS overrides the rule below)
+// x1-rows per task of the pair kernel
+int sweep_3d_pair_rows(int m1, const LaunchKnobs &knobs)
 {
-    const char *e = getenv("EPIC_HIP_3D_MARCH");
-    return e && e[0] == 'x' && e[1] == '0';
-}
-// EPIC_HIP_3D_PAIR=0: the one-plane-per-wave kernel for every launch (A/B, tests); read per launch, the tests switch it
-bool sweep_3d_pair_enabled()
-{
-    const char *e = getenv("EPIC_HIP_3D_PAIR");
-    return !(e && e[0] == '0');
-}
-// x1-rows per task of the pair kernel (EPIC_HIP_3D_PAIR_ROWS overrides)
-int sweep_3d_pair_rows(int m1)
-{
-    const char *e = getenv("EPIC_HIP_3D_PAIR_ROWS");
-    const int v = e ? atoi(e) : 0;
+    const int v = knobs.pair3d_rows;
     if (v > 0) return v < 4 ? 4 : v > 4096 ? 4096 : v;
     // a multiple of 8 chunks of about kPairRows rows where the grid allows it: the chunk alone then selects the XCD (see the kernel)
     const int rounds = (m1 + 8 * kPairRows / 2) / (8 * kPairRows) > 0 ? (m1 + 8 * kPairRows / 2) / (8 * kPairRows) : 1;
@@ -692,8 +681,9 @@ int sweep_3d_pair_rows(int m1)
 // parity < 0: Jacobi (in != out); parity 0 / 1: red-black half-sweep in place (in == out).
 hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, int m0, int m1, int pitch,
                            int plane_begin, int plane_end, int math, int parity, unsigned *delta_bits,
-                           hipStream_t stream, const Activity *act, int check_begin, int check_end)
+                           hipStream_t stream, const Activity *act, int check_begin, int check_end, const LaunchKnobs *knobs_in)
 {
+    const LaunchKnobs &knobs = knobs_in ? *knobs_in : process_launch_knobs();
     if (plane_end <= plane_begin) return hipSuccess;
     if (pitch <= 0 || (pitch % 256) != 0 || m0 <= 0 || m1 <= 0 || plane_begin < 0 || plane_end > m0)
         return hipErrorInvalidValue;
@@ -724,12 +714,12 @@ hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *maskw, i
     const size_t tiles = sweep_3d_tiles(m0, m1, pitch);
     a.wake = wake_args(whole ? act : nullptr, tiles);
     a.rows = kRowsPerTask;
-    if (math == kMathTol && !a.wake.list_out && !a.wake.list_in && sweep_3d_pair_enabled()) {  // two planes per wave (no work lists)
-        bool x0m = sweep_3d_pair_x0_march();
+    if (math == kMathTol && !a.wake.list_out && !a.wake.list_in && knobs.pair3d) {  // two planes per wave (no work lists)
+        bool x0m = knobs.march_x0;
         const long long plane_b = (long long)m1 * pitch * 4, row_b = (long long)pitch * 4;
-        a.rows = sweep_3d_pair_rows(x0m ? plane_end - plane_begin : m1);
+        a.rows = sweep_3d_pair_rows(x0m ? plane_end - plane_begin : m1, knobs);
         // 32-bit byte offsets from one descriptor: the task's steps along the march axis and four steps of the pair axis
-        if (x0m && plane_b * (a.rows + 12) + 3 * row_b > 0x7fffffffLL) x0m = false, a.rows = sweep_3d_pair_rows(m1);
+        if (x0m && plane_b * (a.rows + 12) + 3 * row_b > 0x7fffffffLL) x0m = false, a.rows = sweep_3d_pair_rows(m1, knobs);
         if (!x0m && row_b * (a.rows + 12) + 3 * plane_b > 0x7fffffffLL) return hipErrorInvalidValue;
         const int march = x0m ? plane_end - plane_begin : m1, pairs = x0m ? m1 : plane_end - plane_begin;
         a.nchunks = (march + a.rows - 1) / a.rows;

@@ -141,6 +141,8 @@ _SIGNATURES = {
     "epic_hip_get_layout": (_H, _UP, ct.POINTER(ct.c_size_t), ct.POINTER(ct.c_size_t)),
     "epic_hip_device_layout": (_H, ct.c_int, ct.POINTER(ct.c_int), _UP, _UP, _UP),
     "epic_hip_multi_report": (_H, ct.c_char_p, ct.c_size_t),
+    "epic_hip_config_dump": (_H, ct.c_char_p, ct.c_size_t),
+    "epic_hip_config_reload": (_H,),
     "epic_hip_pack_mask_2d": (ct.c_void_p, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_int, ct.c_int, ct.c_void_p,
                               ct.c_void_p),
     "epic_hip_sweep_2d": (ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_uint, ct.c_uint, ct.c_uint,
@@ -183,3 +185,13 @@ SCHEME_REDBLACK = 1
 EPIC_CELL_TYPE_GOAL = 0
 EPIC_CELL_TYPE_OBSTACLE = 1
 EPIC_CELL_TYPE_FREE = 2
+
+
+def config_dump(h):
+    """epic_hip_config_dump as a dict: the context's Config (every EPIC_HIP_* knob as read when it was created), its state and the
+    path a batch of plain iterations takes now; None without device state."""
+    import json
+
+    buf = ct.create_string_buffer(1 << 14)
+    n = _epic.epic_hip_config_dump(h, buf, len(buf))
+    return json.loads(buf.value.decode()) if n > 0 else None

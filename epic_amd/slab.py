@@ -408,7 +408,7 @@ class SlabSolver:
 
     def tune_pairs(self):
         """Measure the task height of the fused double sweep on this slab, as the library does for its own grids
-        (epic_amd/csrc/harmonic_gpu.hip: tune_fused_rows -- the time of a pass depends on the height in a way no rule predicts):
+        (epic_amd/csrc/driver_plan.hip: tune_fused_rows -- the time of a pass depends on the height in a way no rule predicts):
         every candidate runs three times from the current buffer into the other one, which the next real pass overwrites.
         Slabs of at least 4 Mcell on a GPU; results do not depend on the height.  Returns the height in use (0: the rule)."""
         be = self.backend
@@ -513,7 +513,7 @@ class SlabSolver:
     def solve(self, max_sweeps=None):
         """Relax until a check sweep finds delta < epsilon with iteration >= max(grid) (the reference's exit rule).
         Jacobi hands over to the reference's red-black half-sweeps at the first check with delta < 1 that is not below the
-        previous check's delta, exactly as harmonic_execute_gpu does (epic_amd/csrc/harmonic_gpu.hip, "Jacobi handover":
+        previous check's delta, exactly as harmonic_execute_gpu does (epic_amd/csrc/driver_loop.hip, "Jacobi handover":
         Jacobi's two colour chains can stagnate one ulp apart and never meet the absolute test).  delta is the all-reduced
         value, so every rank takes the decision at the same iteration."""
         self.iteration = 0

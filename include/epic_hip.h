@@ -73,7 +73,7 @@ int epic_hip_fused_rows_per_task(EpicHarmonicT *harmonic);
  * almost empty 1024^2 room: delta falls 0.15 % per 100 iterations) the iteration at which the loop stops is decided by single
  * ulps of single cells; no hand-over factor is safe there (4e-3 from the reference for factors 10, 50, 300; inside the bar for
  * 20 and 100 -- by chance), and only the default precise math reproduces the reference.  The library says so once on stderr
- * when a tol relaxation reaches its hand-over on such a plateau (delta down by < 0.3 % over the last check interval).
+ * when a tol relaxation reaches its hand-over on such a plateau (delta down by less than 0.3 % per check over the last 32 checks).
  * Returns the iteration number at which the finishing phase of the latest call began (0: it had none). */
 unsigned int epic_hip_finish_iteration(EpicHarmonicT *harmonic);
 
@@ -154,7 +154,8 @@ int epic_hip_eval_math(const float *d_in, float *d_out, size_t n, int which, voi
  * 2048, 32 below): ghost units per interior side, traded every G
  * iterations with hipMemcpyPeerAsync -- or, where peer access between two listed devices cannot be enabled (reported once on
  * stderr; EPIC_HIP_NO_PEER=1 forces it), through pinned host memory; results are bit-identical to the single-device path for
- * every list and every G.  One host thread per slab issues its launches (EPIC_HIP_THREADS=0: the calling thread does);
+ * every list and every G.  One host thread per slab issues its launches (EPIC_HIP_THREADS=0: the calling thread does; between hand-overs a
+ * thread spins for at most EPIC_HIP_SPIN_US microseconds, default 20, then sleeps: an idle Harmonic costs its host process nothing);
  * activity tracking works per slab.  Grids with fewer than 4 units per listed device and an unusable list fall back to one
  * device; path requests walk on the host in this mode.
  * epic_hip_device_layout: which device holds which units (rows of a 2-D grid, planes of a 3-D one) -- returns the number of slabs (1 in single-device mode) and
@@ -169,6 +170,20 @@ int epic_hip_device_layout(EpicHarmonicT *harmonic, int cap, int *devices, unsig
  * the time both were running (overlap_us) and whether the copies ended before the interior did (copies_hidden).  Runs the iterations up to and including the next exchange (currentIteration advances).  Returns the
  * number of bytes written, 0 when the Harmonic is not in multi-device mode or buf is too small. */
 int epic_hip_multi_report(EpicHarmonicT *harmonic, char *buf, size_t cap);
+
+/* ---- configuration ---------------------------------------------------------------------------------------------------
+ * The library reads its environment (the EPIC_HIP_* knobs of INTEGRATION.md section 6) ONCE per Harmonic, when the library-side
+ * context of that Harmonic is created (the first harmonic_initialize_*_gpu), into one struct (epic_amd/csrc/driver_config.h);
+ * nothing is read again behind the caller's back.
+ * epic_hip_config_dump: one JSON object in buf -- "config": every knob as read then; "state": dimensions and the modes in force now
+ * (epic_hip_set_* change them); "path": the kernel family a batch of plain iterations takes (LDS tiles / fused pairs / tracked
+ * pairs / list-driven sweeps / single sweeps, replayed from a hipGraph or not), the tile plan, task heights, and in multi-device
+ * mode the halo depth and the transport of every seam.  Returns the bytes written; 0 without a context or when buf is too small.
+ * epic_hip_config_reload: re-reads the environment for this Harmonic's context (a knob that changed is applied; modes set through
+ * epic_hip_set_* stay unless their variable changed; the device list only takes effect at the next initialisation) -- for a caller
+ * that changes a variable on a live context (tests, bench.py).  NULL: the process-wide knobs the raw operators below go by. */
+int epic_hip_config_dump(EpicHarmonicT *harmonic, char *buf, size_t cap);
+int epic_hip_config_reload(EpicHarmonicT *harmonic);
 
 /* Geometry of the device-resident state: pitch in floats, bytes of one u buffer, bytes of the packed mask. */
 int epic_hip_get_layout(EpicHarmonicT *harmonic, unsigned int *pitch, size_t *u_bytes, size_t *mask_bytes);

@@ -1,4 +1,4 @@
-// Fault-injection driver for the library's HOST driver (epic_amd/csrc/harmonic_gpu.hip compiled against the fake HIP runtime
+// Fault-injection driver for the library's HOST driver (epic_amd/csrc/driver_*.hip compiled against the fake HIP runtime
 // of this directory; tests/test_host_driver_faults.py builds and runs it under ASan + UBSan and under TSan).
 //
 // For every scenario -- the plugin's one call, the navigation node's fine-grained flow, 3-D, the tile path and the plain

@@ -1,6 +1,6 @@
 // fake_hip.cpp -- a malloc-backed stand-in for the HIP runtime and for the kernel launchers, TEST INFRASTRUCTURE ONLY.
 //
-// tests/test_host_driver_faults.py compiles epic_amd/csrc/harmonic_gpu.hip (the library's HOST driver, unchanged) against
+// tests/test_host_driver_faults.py compiles epic_amd/csrc/driver_*.hip (the library's HOST driver, unchanged) against
 // tests/fake_hip/hip/hip_runtime.h and links it with this file under -fsanitize=address,undefined (and, for the issuing
 // threads of the multi-device mode, -fsanitize=thread).  What the fake provides:
 //   * memory: hipMalloc / hipHostMalloc are malloc + a registry; copies are memcpy with the device side checked against the
@@ -286,7 +286,7 @@ hipError_t launch_follow_paths_2d(const float *, const uint32_t *, int, int, int
     return hipSuccess;
 }
 hipError_t launch_sweep_3d(const float *in, float *out, const uint32_t *, int m0, int m1, int pitch, int, int, int, int, unsigned *, hipStream_t, const Activity *, int,
-                           int)
+                           int, const LaunchKnobs *)
 {
     FAKE_LAUNCH("launch_sweep_3d");
     check_device(in, (size_t)m0 * m1 * pitch * 4);

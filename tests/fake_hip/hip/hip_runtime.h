@@ -1,6 +1,6 @@
 // A FAKE HIP runtime header -- TEST INFRASTRUCTURE ONLY (tests/test_host_driver_faults.py).
 //
-// The 2.4 kLoC host driver of the library (epic_amd/csrc/harmonic_gpu.hip: registry, lifecycle, unwind paths, the issuing
+// The 2.4 kLoC host driver of the library (epic_amd/csrc/driver_*.hip: registry, lifecycle, unwind paths, the issuing
 // threads of the multi-device mode) is compiled against THIS header with g++ and the sanitizers, in the CPU container, so that
 // every allocation / copy / launch site can be made to fail in turn (fake_hip.cpp: "fail the n-th call") and the unwind checked
 // for leaks, double frees and stale pointers.  Memory is malloc-backed, streams execute at once, kernels are no-ops.  Nothing

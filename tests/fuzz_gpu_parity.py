@@ -12,6 +12,7 @@ tests/test_gpu_fuzz.py runs a short campaign of it under pytest.
 """
 import argparse
 import ctypes as ct
+import json
 import os
 import sys
 
@@ -133,6 +134,9 @@ def checker(m, u0, locked, mode, k, edits=None):
     return p.u.copy(), float(p.h.delta)
 
 
+LAST = {"dump": None}   # epic_hip_config_dump of the latest library() context (which knobs it read, which kernel path it took)
+
+
 def library(m, u0, locked, mode, k, env, edits=None):
     prev = {a: os.environ.get(a) for a in KNOBS}
     for a in KNOBS:
@@ -158,6 +162,7 @@ def library(m, u0, locked, mode, k, env, edits=None):
         assert E.epic_hip_update_n_gpu(h, k - first, 1) in (0, 1)
         assert h.currentIteration == k
         assert E.harmonic_get_potential_values_gpu(h) == 0
+        LAST["dump"] = eh.config_dump(h)   # the library's own account of this context: printed with a mismatch
         delta = float(h.delta)
         for fn in (E.harmonic_uninitialize_gpu, E.harmonic_uninitialize_dimension_size_gpu, E.harmonic_uninitialize_potential_values_gpu,
                    E.harmonic_uninitialize_locked_gpu):
@@ -182,7 +187,8 @@ def campaign(cases, seed, verbose=True):
         if not ok:
             diff = np.flatnonzero(got != want)
             bad.append(dict(case=i, seed=seed, m=m, mode=mode[0], k=k, env=env, cells=int(diff.size), first=int(diff[0]) if diff.size else -1,
-                            delta=(gdelta, wdelta)))
+                            delta=(gdelta, wdelta), library=LAST["dump"]))
+            print("    the library's account of that context:", json.dumps(LAST["dump"]), flush=True)
     return bad
 
 

@@ -5,7 +5,7 @@ cell then flips between the two for ever and max |du| stays at one ulp of |u| --
 case that showed it is the nav_core plugin's SECOND makePlan (src/epic_nav_core_plugin.cpp:234-338: the goal moves, the
 field of the first goal is the start): plain Jacobi sits at delta = 7.6e-6 for 400 000 iterations and counting, the
 reference's red-black iteration stops after 1 901.  harmonic_execute_gpu therefore hands over to the reference's in-place
-half-sweeps at the first check with delta < 1 that is not below the previous check's delta (harmonic_gpu.hip, "Jacobi
+half-sweeps at the first check with delta < 1 that is not below the previous check's delta (driver_loop.hip, "Jacobi
 handover"); the checkers state the same rule (oracle_jacobi_complete, oracle_tol_complete), so iteration counts, delta and
 fields are compared bit for bit, one device and row slabs alike.
 """

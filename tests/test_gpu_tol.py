@@ -144,7 +144,7 @@ def test_3d_two_planes_per_wave_equals_the_checker_and_the_one_plane_kernel(m, s
                                          (eh.MATH_PRECISE, eh.SCHEME_REDBLACK)])
 def test_measured_task_height_of_the_fused_passes_changes_nothing_but_time(math, scheme, monkeypatch):
     """On grids of at least 4 Mcell the library measures the task height of a fused pass on the grid itself, the first time a
-    pair of plain iterations is enqueued past the first min(rows, cols) / 2 iterations (harmonic_gpu.hip: tune_fused_rows):
+    pair of plain iterations is enqueued past the first min(rows, cols) / 2 iterations (driver_plan.hip: tune_fused_rows):
     every candidate runs from the current buffer into the other one.  The field, the delta and the iteration count must be
     what the rule's height (EPIC_HIP_TUNE=0) gives, and the height in use afterwards is the rule's or one of the candidates."""
     m = [2048, 2100]

@@ -1,5 +1,5 @@
 """Tracked red-black relaxations as PAIRS of iterations (round 4): list-driven fused passes, the check as the second iteration
-of the last pair (epic_amd/csrc/kernels_2d.hip: rb_fused2d_kernel with TRACK / CHECK; harmonic_gpu.hip: enqueue_rb_pairs_tracked).
+of the last pair (epic_amd/csrc/kernels_2d.hip: rb_fused2d_kernel with TRACK / CHECK; driver_enqueue.hip: enqueue_rb_pairs_tracked).
 
 It is the path the library's DEFAULTS take on a large grid (precise math, red-black, activity tracking from 4 Mcell up), i.e. what
 the unchanged plugin gets at the benchmark's size, so the bar is the reference's bits: iteration count, final delta and the whole

@@ -1,7 +1,8 @@
 """The library's HOST driver under the sanitizers with fault injection (CPU container; nothing here needs or touches a GPU).
 
-epic_amd/csrc/harmonic_gpu.hip -- the registry of contexts, the device-state lifecycle with its ~20 allocation sites, the
-driver loops, the multi-device mode with its issuing threads -- is compiled UNCHANGED with g++ against a fake HIP runtime
+epic_amd/csrc/driver_*.hip + driver_config.cpp (one file, harmonic_gpu.hip, until round 5) -- the registry of contexts, the
+device-state lifecycle with its ~20 allocation sites, the driver loops, the multi-device mode with its issuing threads -- are
+compiled UNCHANGED with g++ against a fake HIP runtime
 (tests/fake_hip/: malloc-backed memory, streams that execute at once, no-op kernels, "fail the n-th call") and driven by
 tests/fake_hip/driver.cpp:
 
@@ -25,6 +26,7 @@ CSRC = os.path.join(ROOT, "epic_amd", "csrc")
 FAKE = os.path.join(ROOT, "tests", "fake_hip")
 
 pytestmark = pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+DRIVER_UNITS = ["driver_registry.hip", "driver_plan.hip", "driver_enqueue.hip", "driver_multi.hip", "driver_loop.hip", "driver_ext.hip"]
 
 
 def build(tmp_path, sanitize):
@@ -33,11 +35,27 @@ def build(tmp_path, sanitize):
     if "undefined" in sanitize:
         flags.append("-fno-sanitize-recover=undefined")
     exe = str(tmp_path / ("fault_driver_" + sanitize.split(",")[0]))
-    srcs = [os.path.join(CSRC, f) for f in ("harmonic_cpu.cpp", "harmonic_path_cpu.cpp", "harmonic_legacy_cpu.cpp", "abi_checks.cpp")]
-    # the .hip file holds host code only (the kernels live in kernels_*.hip, whose launchers the fake replaces)
-    subprocess.run(["g++", *flags, "-x", "c++", os.path.join(CSRC, "harmonic_gpu.hip"), os.path.join(FAKE, "fake_hip.cpp"),
+    srcs = [os.path.join(CSRC, f) for f in ("harmonic_cpu.cpp", "harmonic_path_cpu.cpp", "harmonic_legacy_cpu.cpp", "abi_checks.cpp", "driver_config.cpp")]
+    # the driver's .hip files hold host code only (the kernels live in kernels_*.hip, whose launchers the fake replaces)
+    driver = [os.path.join(CSRC, f) for f in DRIVER_UNITS]
+    subprocess.run(["g++", *flags, "-x", "c++", *driver, os.path.join(FAKE, "fake_hip.cpp"),
                     os.path.join(FAKE, "driver.cpp"), *srcs, "-lpthread", "-o", exe], check=True)
     return exe
+
+
+def test_the_environment_is_read_in_one_place_only():
+    """Round 5: every EPIC_HIP_* knob is parsed once per context into struct Config (epic_amd/csrc/driver_config.cpp); no other
+    translation unit of the library calls getenv."""
+    offenders = []
+    for name in sorted(os.listdir(CSRC)):
+        if not name.endswith((".hip", ".cpp", ".h")) or name == "driver_config.cpp":
+            continue
+        for i, line in enumerate(open(os.path.join(CSRC, name)), 1):
+            code = line.split("//")[0]
+            if "getenv" in code:
+                offenders.append("%s:%d" % (name, i))
+    assert not offenders, offenders
+    assert sorted(f for f in os.listdir(CSRC) if f.startswith("driver_") and f.endswith(".hip")) == sorted(DRIVER_UNITS)
 
 
 def test_every_failing_runtime_call_unwinds_cleanly_under_asan_ubsan(tmp_path):

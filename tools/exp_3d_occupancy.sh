@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5: the 3-D tol sweep (sweep3d_pair_kernel, 512^3) -- where its cycles go, and what a third wave per SIMD is worth.
 #   1. the counters this pool offers (rocprofv3 -L) -> gpurun_out/r05_counters_avail.txt
-#   2. same-call timing of the build variants in gpurun_alt/ (tools/build_3d_variants.sh) against the shipped library
+#   2. same-call timing of the build variants in gpurun_alt/ (tools/build_variant.sh kernels_3d) against the shipped library
 #   3. the 3-D tol parity tests through the candidate variant (EPIC_LIB)
 #   4. per-class stall counters of the shipped kernel and of the candidate: one rocprofv3 --pmc pass per group
 #   bash tools/exp_3d_occupancy.sh <candidate variant name> <other variants ...>

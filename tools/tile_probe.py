@@ -39,6 +39,7 @@ def main():
     assert E.epic_hip_set_math_mode(h, math) == 0 and E.epic_hip_set_scheme(h, scheme) == 0
     ms = ct.c_float(0)
     os.environ["EPIC_HIP_TILE"] = "0"
+    assert E.epic_hip_config_reload(h) == 0   # (the library reads its environment once per context)
     assert E.epic_hip_timed_sweeps_gpu(h, args.develop, 0, ct.byref(ms)) == 0   # a developed field (values vary: clocks)
     assert E.epic_hip_timed_sweeps_gpu(h, args.iters, 0, ct.byref(ms)) == 0
     print(f"{args.map} {list(h.shape)} {args.mode}: per-iteration kernels (eager) {ms.value / args.iters * 1e3:.3f} us/iteration", flush=True)
@@ -52,6 +53,7 @@ def main():
                 os.environ["EPIC_HIP_TILE_ROWS"] = str(rows)
             else:
                 os.environ.pop("EPIC_HIP_TILE_ROWS", None)
+            assert E.epic_hip_config_reload(h) == 0
             if E.epic_hip_tile_iterations(h) != halo:
                 print(f"halo {halo} rows {rows}: no plan")
                 continue
