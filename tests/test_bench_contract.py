@@ -7,7 +7,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = ["profiles/r04_bench_line_n1.json", "profiles/r04_bench_line_n2_gloo_one_gpu.json"]
+LINES = ["profiles/r05_bench_line_n1.json", "profiles/r05_bench_line_n2_gloo_one_gpu.json"]
 
 
 def load(rel):
@@ -58,7 +58,7 @@ def test_single_gpu_line_roofline_is_the_fused_pass_and_has_a_cpu_baseline():
     # the algorithmic figure never travels without the measured one: HBM bytes per launch (PMC) / launch duration / peak
     assert abs(r["hbm_GBps_measured"] - r["traffic"] / (r["launch_us"] * 1e-6) / 1e9) < 0.01 * r["hbm_GBps_measured"]
     assert abs(r["hbm_frac_measured"] - r["hbm_GBps_measured"] / r["peak"]) < 1e-3 and r["hbm_frac_measured"] < r["frac"]
-    assert r["limiter"] == "valu" and r["bound"] == "valu"
+    assert r["limiter"] == r["bound"] == "valu"          # ONE decision (round 4's line could say bound "hbm" beside limiter "valu+hbm")
     # ... and evidenced in the line itself: VALU instructions issued against the cycles the shader engines were busy, a child pass
     # of this command under rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES
     assert 0.80 < r["valu_issue_frac"] <= 1.0 and r["valu_issue_frac"] > r["hbm_frac_measured"] / 0.7875   # busier than HBM against its achievable 6.3 TB/s
@@ -161,6 +161,37 @@ def test_round_4_legs_config5_config4_maps_and_the_callers_epsilon():
     rule, old = ic["rule (hand-over at 100 eps)"], ic["hand-over at 10 eps (round 3's rule)"]
     assert rule["within_bar"] is True and rule["iterations"] == ic["reference_iterations"]
     assert old["within_bar"] is False and ic["reference_iterations"] - old["iterations"] > 10000
+
+
+def test_round_5_the_keys_the_driver_keeps_carry_relax_to_eps_parity_and_the_other_configs():
+    """The driver's record keeps `config`, `roofline` and `cpu_baseline` whole and only names the other objects: BASELINE's metric
+    is "relax to eps = 1e-6", so the time-to-solution, the parity verdict and the other configs' headline figures are inside `config`."""
+    d = load(LINES[0])
+    c = d["config"]
+    rt = c["relax_to_eps"]
+    assert rt["epsilon"] == 1e-6
+    for key in ("fastest_parity_clean", "library_default", "timed_scheme"):
+        x = rt[key]
+        for k in ("mode", "seconds", "iterations", "finishing_iterations", "recomputed_Mcell_updates_per_s", "effective_Mcell_updates_per_s"):
+            assert k in x, (key, k)
+    # the same numbers as the full legs of the line
+    assert rt["library_default"]["seconds"] == d["relax_default"]["seconds"] and rt["library_default"]["mode"] == "precise redblack"
+    assert rt["library_default"]["finishing_iterations"] == 0 and rt["timed_scheme"]["seconds"] == d["relax_jacobi"]["seconds"]
+    best = rt["fastest_parity_clean"]
+    assert best["leg"] in ("relax", "relax_jacobi", "relax_default") and best["seconds"] == d[best["leg"]]["seconds"]
+    assert best["seconds"] <= min(rt["library_default"]["seconds"], rt["timed_scheme"]["seconds"])
+    assert c["parity_misses"] == d["parity"]["misses"] == []
+    assert c["config5_frac"] == d["config5"]["frac"] and c["config5_frac_default_math"] == d["config5"]["precise"]["frac"]
+    assert c["default_math_frac"] == d["kernels"]["precise"]["frac"]
+    assert c["maps_seconds"] == {n: d["maps"]["%s default eps 1e-06" % n]["seconds"] for n in ("maze", "umass")}
+    # the library's own account of the timed context (epic_hip_config_dump): what it read, and which kernel path it is on
+    lib = d["library"]
+    assert lib["config"]["scheme"] == "redblack" and lib["state"]["scheme"] == "jacobi" and lib["state"]["math"] == 4   # no environment: set through the API
+    assert lib["path"]["plain_batch"] == c["kernel_path"] == "fused tol Jacobi pairs (jacobi_fused2d_kernel)"
+    assert lib["path"]["fused_rows_per_task"] == c["fused_rows_per_task"]
+    # the N > 1 line came out of the PLAIN command (no launcher in front): the parent started its own ranks
+    d2 = load(LINES[1])
+    assert d2["n_gpus"] == 2 and d2["ranks"]["ranks_seen"] == 2 and "in_library" in d2 and "error" not in d2["in_library"]
 
 
 def test_plain_multi_gpu_command_starts_its_own_ranks_as_a_child():

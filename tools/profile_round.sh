@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiles kept under profiles/ for a round (run on the GPU box through gpurun; TAG = r01, r02, ...):
-#   bash tools/profile_round.sh r04
+#   bash tools/profile_round.sh r05
 # rocprofv3 passes, each with the program itself after `--` (python3 <script>), counters in their own runs:
 #   1. --kernel-trace --stats of the bench.py command (default math = tol, untracked Jacobi, developed field: pairs of
 #      iterations as jacobi_fused2d_kernel, the check and the odd iteration as sweep2d_kernel) and of
@@ -10,7 +10,7 @@
 #   4. --kernel-trace --stats of whole relaxations with activity tracking (tools/time_relax.py): tol Jacobi, and the library
 #      default (precise, red-black) -- the list-driven kernels and the bypassed batches
 #   bash tools/profile_round.sh r03 3d      only the passes whose name contains "3d" (after a change to the 3-D kernel)
-TAG=${1:-r04}
+TAG=${1:-r05}
 ONLY=${2:-}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
