@@ -640,46 +640,6 @@ __device__ __forceinline__ float cell_update_2d(float up, float down, float left
     return (float)((double)t - kLn4);
 }
 
-// TWO independent cells at once, statement by statement: the same operations on the same values as two calls of
-// cell_update_2d -- the same bits -- but written interleaved, because the masked adds / subs of the precise form are `asm volatile`
-// statements, which the compiler keeps in source order: behind two CALLS the second cell's exps could not start before the
-// first cell's sum was finished, and a wave that updates two cells per lane (kernels_tile2d.hip: two row pairs per step) ran
-// two ~900-cycle dependent chains one after the other instead of side by side.
-template <int MATH>
-__device__ __forceinline__ void cell_update_2d_pair(float up0, float dn0, float lf0, float rt0, float up1, float dn1, float lf1, float rt1,
-                                                    const MathTab &lds, float &o0, float &o1)
-{
-    if (MATH != kMathPrecise) {   // (no volatile statements in these: the compiler interleaves the two calls itself)
-        o0 = cell_update_2d<MATH>(up0, dn0, lf0, rt0, lds);
-        o1 = cell_update_2d<MATH>(up1, dn1, lf1, rt1, lds);
-        return;
-    }
-    const float hv0 = max2(up0, dn0), lv0 = __builtin_fminf(up0, dn0), hv1 = max2(up1, dn1), lv1 = __builtin_fminf(up1, dn1);
-    const float mx0 = max2(max2(hv0, lf0), rt0), mx1 = max2(max2(hv1, lf1), rt1);
-    const lmask P0 = lanes_eq(hv0, mx0), Q0 = lanes_eq(lf0, mx0), PQ0 = P0 | Q0;
-    const lmask P1 = lanes_eq(hv1, mx1), Q1 = lanes_eq(lf1, mx1), PQ1 = P1 | Q1;
-    float db0 = hv0 - mx0, dc0 = lf0 - mx0, db1 = hv1 - mx1, dc1 = lf1 - mx1;
-    sub_where(db0, P0, lf0, mx0);
-    sub_where(db1, P1, lf1, mx1);
-    sub_where(dc0, PQ0, rt0, mx0);
-    sub_where(dc1, PQ1, rt1, mx1);
-    const float ea0 = precise_exp(lv0 - mx0, lds), ea1 = precise_exp(lv1 - mx1, lds);
-    const float eb0 = precise_exp(db0, lds), eb1 = precise_exp(db1, lds);
-    const float ec0 = precise_exp(dc0, lds), ec1 = precise_exp(dc1, lds);
-    const float t10 = ea0 + eb0, t11 = ea1 + eb1;
-    float t20 = t10 + ec0, t21 = t11 + ec1;
-    add_one_where(t20, Q0, t10);
-    add_one_where(t21, Q1, t11);
-    add_one_add_where(t20, P0, ea0, eb0);
-    add_one_add_where(t21, P1, ea1, eb1);
-    float s0 = t20 + 1.0f, s1 = t21 + 1.0f;
-    add_where(s0, PQ0, t20, ec0);
-    add_where(s1, PQ1, t21, ec1);
-    const float tt0 = mx0 + precise_ln(s0, lds), tt1 = mx1 + precise_ln(s1, lds);
-    o0 = (float)((double)tt0 - kLn4);
-    o1 = (float)((double)tt1 - kLn4);
-}
-
 template <int MATH>
 __device__ __forceinline__ float cell_update_3d(float a0, float a1, float b0, float b1, float c0, float c1,
                                                 const MathTab &lds)

@@ -53,10 +53,6 @@ constexpr int kTileThreads = 64 * kTileWaves;
 #define EPIC_TILE_WAVE_SYNC 0
 #endif
 constexpr bool kTileWaveSync = EPIC_TILE_WAVE_SYNC != 0;
-#ifndef EPIC_TILE_PAIRS  // build knob (A/B): a wave's passes of a step two at a time (1) or one after the other (0: shipped -- see the step loop)
-#define EPIC_TILE_PAIRS 0
-#endif
-constexpr bool kTilePairs = EPIC_TILE_PAIRS != 0;
 constexpr lmask kOddLanes = 0xaaaaaaaaaaaaaaaaull;
 
 struct Tile2dArgs {
@@ -172,72 +168,45 @@ __global__ __launch_bounds__(kTileThreads) void tile2d_kernel(Tile2dArgs a)
         // block starts at an even column)
         const int b = (R0 + C0 + a.parity + j) & 1;
         const lmask first_row = b ? ~kOddLanes : kOddLanes;
-        // A wave's passes of a step are independent of one another (red-black: a pass writes cells of the step's colour and reads
-        // the other colour's and its own cell; Jacobi: src != dst), so they run TWO AT A TIME: both passes' cells are read before
-        // either is written, and the two ~900-cycle dependent chains of a cell update (three exps, a log, three LDS round trips)
-        // run side by side instead of one after the other (round 5; EPIC_TILE_PAIRS=0 builds the one-at-a-time form).  A pass is
-        // a wave-uniform decision (stale or missing rows are skipped), so the pairing is decided on the scalar unit.
-        struct Pass { bool valid; lmask upd, own; int p; };
-        auto plan_pass = [&](const int i) -> Pass {
-            Pass ps = {false, 0ull, 0ull, 0};
+#pragma unroll
+        for (int i = 0; i < kPasses; ++i) {
+            lmask upd, own;
+            int p;
             const int blk = unit_blk(i);
             const lmask cols_ok = cols_from(blk, lo), own_cols = cols_from(blk, H);
             if (RB) {
                 const int r2 = 2 * unit_row(i);
                 const bool v0 = r2 >= lo && r2 <= hi_r, v1 = r2 + 1 >= lo && r2 + 1 <= hi_r;
-                if (!(v0 || v1)) return ps;   // wave-uniform: the pair has gone stale (or lies beyond the tile)
+                if (!(v0 || v1)) continue;   // wave-uniform: the pair has gone stale (or lies beyond the tile)
                 const lmask lock = (lockm[2 * i] & first_row) | (lockm[2 * i + 1] & ~first_row);
-                ps.upd = ((v0 ? first_row : 0ull) | (v1 ? ~first_row : 0ull)) & cols_ok & ~lock;
-                ps.own = ((r2 >= own_r0 && r2 < own_r1 ? first_row : 0ull) | (r2 + 1 >= own_r0 && r2 + 1 < own_r1 ? ~first_row : 0ull)) & own_cols;
-                ps.p = at(r2, 64 * blk + lane) + ((odd_lane ^ b) ? 0 : kTileCols);
+                upd = ((v0 ? first_row : 0ull) | (v1 ? ~first_row : 0ull)) & cols_ok & ~lock;
+                own = ((r2 >= own_r0 && r2 < own_r1 ? first_row : 0ull) | (r2 + 1 >= own_r0 && r2 + 1 < own_r1 ? ~first_row : 0ull)) & own_cols;
+                p = at(r2, 64 * blk + lane) + ((odd_lane ^ b) ? 0 : kTileCols);
             } else {
                 const int lr = unit_row(i);
-                if (lr < lo || lr > hi_r) return ps;   // wave-uniform
-                ps.upd = cols_ok & ~lockm[i];
-                ps.own = lr >= own_r0 && lr < own_r1 ? own_cols : 0ull;
-                ps.p = at(lr, 64 * blk + lane);
+                if (lr < lo || lr > hi_r) continue;   // wave-uniform
+                upd = cols_ok & ~lockm[i];
+                own = lr >= own_r0 && lr < own_r1 ? own_cols : 0ull;
+                p = at(lr, 64 * blk + lane);
             }
-            ps.valid = true;
-            return ps;
-        };
-        struct Cell { float c, uu, ud, ul, ur; };
-        auto read_cell = [&](const int p) { return Cell{u_lds[src + p], u_lds[src + p - kTileCols], u_lds[src + p + kTileCols], u_lds[src + p - 1], u_lds[src + p + 1]}; };
-        auto tol_value = [&](const Cell &x, const int p) {
-            return tol_update_2d(x.uu, x.ud, x.ul, x.ur, q_lds[src + p - kTileCols], n_lds[src + p - kTileCols], q_lds[src + p + kTileCols],
-                                 n_lds[src + p + kTileCols], q_lds[src + p - 1], n_lds[src + p - 1], q_lds[src + p + 1], n_lds[src + p + 1], tl);
-        };
-        auto write_cell = [&](const Pass &ps, const Cell &x, const float nv) {
-            const float o = sel(ps.upd, nv, x.c);
-            u_lds[dst + ps.p] = o;
+            const float c = u_lds[src + p];
+            const float uu = u_lds[src + p - kTileCols], ud = u_lds[src + p + kTileCols], ul = u_lds[src + p - 1], ur = u_lds[src + p + 1];
+            float nv;
+            if (TOL) {
+                nv = tol_update_2d(uu, ud, ul, ur, q_lds[src + p - kTileCols], n_lds[src + p - kTileCols], q_lds[src + p + kTileCols],
+                                   n_lds[src + p + kTileCols], q_lds[src + p - 1], n_lds[src + p - 1], q_lds[src + p + 1],
+                                   n_lds[src + p + 1], tl);
+            } else {
+                nv = cell_update_2d<MATH>(uu, ud, ul, ur, tab);
+            }
+            const float o = sel(upd, nv, c);
+            u_lds[dst + p] = o;
             if (TOL) {
                 const Split1 sp = tol_split1(o);
-                q_lds[dst + ps.p] = sp.q;
-                n_lds[dst + ps.p] = f2u(sp.zm);
+                q_lds[dst + p] = sp.q;
+                n_lds[dst + p] = f2u(sp.zm);
             }
-            if (check) dmax = max2(dmax, sel(ps.own, fabsf(x.c - o), 0.0f));   // (wave-uniform branch)
-        };
-        auto one_pass = [&](const Pass &ps) {
-            const Cell x = read_cell(ps.p);
-            write_cell(ps, x, TOL ? tol_value(x, ps.p) : cell_update_2d<MATH>(x.uu, x.ud, x.ul, x.ur, tab));
-        };
-#pragma unroll
-        for (int i = 0; i < kPasses; i += 2) {
-            const Pass pa = plan_pass(i), pb = i + 1 < kPasses ? plan_pass(i + 1) : Pass{false, 0ull, 0ull, 0};
-            if (kTilePairs && pa.valid && pb.valid) {
-                const Cell xa = read_cell(pa.p), xb = read_cell(pb.p);
-                float va, vb;
-                if (TOL) {
-                    va = tol_value(xa, pa.p);
-                    vb = tol_value(xb, pb.p);
-                } else {
-                    cell_update_2d_pair<MATH>(xa.uu, xa.ud, xa.ul, xa.ur, xb.uu, xb.ud, xb.ul, xb.ur, tab, va, vb);
-                }
-                write_cell(pa, xa, va);
-                write_cell(pb, xb, vb);
-            } else {
-                if (pa.valid) one_pass(pa);
-                if (pb.valid) one_pass(pb);
-            }
+            if (check) dmax = max2(dmax, sel(own, fabsf(c - o), 0.0f));   // (wave-uniform branch)
         }
         if (kTileWaveSync) {
             if (lane == 0) __hip_atomic_store(&step_done[wave], j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);

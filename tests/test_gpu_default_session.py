@@ -1,0 +1,37 @@
+"""The second session mode inside ONE `pytest -m gpu` run.
+
+tests/conftest.py runs the suite under EPIC_HIP_SCHEME=jacobi (what bench.py times) unless EPIC_TEST_SCHEME=default leaves the
+variable unset, so that every context which sets no scheme itself runs the LIBRARY DEFAULT (the reference's red-black).  Both modes
+are green on the whole suite (profiles/r05_experiments.txt item 4: 1149 passed each); so that a single `-m gpu` run -- the one the
+driver records -- also exercises the default, the files whose tests depend on the session's scheme (they compare with the checker
+through _oracle.run_session, or take their scheme from the environment) are run once more here, in a child process, under
+EPIC_TEST_SCHEME=default: the fine-grained ABI flows and full-size window properties of test_gpu_parity.py, the same on 2-8
+in-library slabs (test_gpu_multi_device.py), and the tol mode's live-edit flow (test_gpu_tol.py)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+
+FILES = ["tests/test_gpu_parity.py", "tests/test_gpu_multi_device.py", "tests/test_gpu_tol.py", "tests/test_gpu_config.py"]
+
+
+def test_the_scheme_dependent_files_pass_with_the_library_default_as_session_scheme():
+    if os.environ.get("EPIC_TEST_SCHEME", "jacobi") == "default":
+        pytest.skip("this session IS the default-scheme session")
+    env = {k: v for k, v in os.environ.items() if k not in ("EPIC_HIP_SCHEME", "PYTEST_CURRENT_TEST")}
+    env["EPIC_TEST_SCHEME"] = "default"
+    r = subprocess.run([sys.executable, "-m", "pytest", *FILES, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "not 8192_tracking and not relax_8192 and not 32768"],   # (the three longest: run in the outer session, scheme set explicitly)
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=840)
+    tail = r.stdout[-3000:] + r.stderr[-1500:]
+    assert r.returncode == 0, tail
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) > 300, tail
+    assert "failed" not in r.stdout.splitlines()[-1], tail
+    print(r.stdout.splitlines()[-1])
