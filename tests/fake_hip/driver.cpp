@@ -135,7 +135,7 @@ struct Scenario {
 static void set_env(const std::map<std::string, std::string> &env, bool on)
 {
     static const char *all[] = {"EPIC_HIP_DEVICES", "EPIC_HIP_THREADS", "EPIC_HIP_NO_PEER", "EPIC_HIP_TRACK", "EPIC_HIP_TILE", "EPIC_HIP_MATH",
-                                "EPIC_HIP_SCHEME", "EPIC_HIP_HALO", "EPIC_HIP_FUSE_MIN_CELLS", "EPIC_HIP_TUNE"};
+                                "EPIC_HIP_SCHEME", "EPIC_HIP_HALO", "EPIC_HIP_FUSE_MIN_CELLS", "EPIC_HIP_TUNE", "FAKE_NO_PEER_CAPABLE", "FAKE_CURRENT_DEVICE"};
     for (const char *k : all) unsetenv(k);
     if (on)
         for (auto &kv : env) setenv(kv.first.c_str(), kv.second.c_str(), 1);
@@ -148,6 +148,8 @@ static bool clean(const char *what, const Scenario &sc, long n, const Harmonic &
         EXPECT(fake_hip_live(kind) == 0, "%s, call %ld failing (%s): %ld live objects of kind %d after %s", sc.name, n, fake_hip_failed_call(),
                fake_hip_live(kind), kind, what);
     EXPECT(fake_hip_misuse() == 0, "%s, call %ld failing (%s): %ld misuses of the runtime", sc.name, n, fake_hip_failed_call(), fake_hip_misuse());
+    EXPECT(fake_hip_affinity() == 0, "%s, call %ld failing (%s): %ld violations of the device rules, the first: %s", sc.name, n, fake_hip_failed_call(),
+           fake_hip_affinity(), fake_hip_first_affinity());
     EXPECT(!h.d_m && !h.d_u && !h.d_locked && !h.d_delta, "%s, call %ld failing (%s): d_* not null after %s", sc.name, n, fake_hip_failed_call(), what);
     return failures == before;
 }
@@ -155,7 +157,25 @@ static bool clean(const char *what, const Scenario &sc, long n, const Harmonic &
 int main(int argc, char **argv)
 {
     const bool threads_only = argc > 1 && strcmp(argv[1], "threads") == 0;   // the TSan build: the scenarios with issuing threads, no walk
-    fake_hip_set_devices(1);
+    // "devices": FOUR fake devices with the real runtime's device rules enforced (fake_hip.cpp: device affinity) -- every slab on a
+    // device of its own, lists out of order and with repeats, with and without peer access, the caller's current device not 0.
+    // No session of this project has had two GPUs: this is the multi-device mode's device bookkeeping under test.
+    const bool devices_mode = argc > 1 && strcmp(argv[1], "devices") == 0;
+    fake_hip_set_devices(devices_mode ? 4 : 1);
+    std::vector<Scenario> device_scenarios = {
+        {"plugin, 2-D, four devices, issuing threads", {64, 40}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_DEVICES", "0,1,2,3"}, {"EPIC_HIP_HALO", "4"}}},
+        {"plugin, 2-D, four devices, caller's thread", {64, 40}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_DEVICES", "0,1,2,3"}, {"EPIC_HIP_THREADS", "0"}, {"EPIC_HIP_HALO", "3"}}},
+        {"node, 2-D, devices 2,0,3 (out of order), work lists, issuing threads", {48, 300}, 1e-3f, 4, seq_node, {{"EPIC_HIP_DEVICES", "2,0,3"}, {"EPIC_HIP_TRACK", "1"}}},
+        {"node, 2-D, devices 1,1,3 (one device twice), caller's thread", {48, 40}, 1e-3f, 4, seq_node, {{"EPIC_HIP_DEVICES", "1,1,3"}, {"EPIC_HIP_THREADS", "0"}}},
+        {"plugin, 3-D, planes on devices 3,1", {12, 6, 7}, 1e-3f, 5, seq_plugin, {{"EPIC_HIP_DEVICES", "3,1"}, {"EPIC_HIP_THREADS", "0"}}},
+        {"plugin, 2-D, tol fused pairs on devices 0,1,2", {72, 300}, 1e-3f, 10, seq_plugin,
+         {{"EPIC_HIP_DEVICES", "0,1,2"}, {"EPIC_HIP_MATH", "tol"}, {"EPIC_HIP_SCHEME", "jacobi"}, {"EPIC_HIP_FUSE_MIN_CELLS", "0"}, {"EPIC_HIP_HALO", "6"}}},
+        {"plugin, 2-D, four devices that CANNOT reach each other (staged halos)", {64, 40}, 1e-3f, 10, seq_plugin,
+         {{"EPIC_HIP_DEVICES", "0,1,2,3"}, {"EPIC_HIP_THREADS", "0"}, {"EPIC_HIP_HALO", "2"}, {"FAKE_NO_PEER_CAPABLE", "1"}}},
+        {"plugin, 2-D, devices 0,2 with staging forced, issuing threads", {64, 40}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_DEVICES", "0,2"}, {"EPIC_HIP_NO_PEER", "1"}}},
+        {"plugin, 2-D, ONE device, the caller's current device is 2", {20, 30}, 1e-3f, 10, seq_plugin, {{"FAKE_CURRENT_DEVICE", "2"}}},
+        {"node, 2-D, slabs on 0,1 while the caller's current device is 3", {32, 20}, 1e-3f, 4, seq_node, {{"EPIC_HIP_DEVICES", "0,1"}, {"FAKE_CURRENT_DEVICE", "3"}}},
+    };
     std::vector<Scenario> scenarios = {
         {"plugin, 2-D, tiles", {20, 30}, 1e-3f, 10, seq_plugin, {}},
         {"plugin, 2-D, plain sweeps", {20, 30}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_TILE", "0"}}},
@@ -197,10 +217,14 @@ int main(int argc, char **argv)
     }
     long walked = 0, tolerated = 0;
     std::map<std::string, std::set<int>> codes;   // failing call -> return codes seen
+    if (devices_mode) scenarios = device_scenarios;
     for (const Scenario &sc : scenarios) {
         const bool threaded = sc.env.count("EPIC_HIP_DEVICES") && !sc.env.count("EPIC_HIP_THREADS");
         if (threads_only && !threaded) continue;
         set_env(sc.env, true);
+        fake_hip_set_peer_capable(sc.env.count("FAKE_NO_PEER_CAPABLE") ? 0 : 1);
+        const int caller_device = sc.env.count("FAKE_CURRENT_DEVICE") ? atoi(sc.env.at("FAKE_CURRENT_DEVICE").c_str()) : 0;
+        (void)hipSetDevice(caller_device);
         long total;
         {
             Grid g(sc.dims, sc.eps, sc.stagger);
@@ -210,10 +234,13 @@ int main(int argc, char **argv)
             EXPECT(rc == 0, "%s: clean run returned %d", sc.name, rc);
             cleanup(&g.h);
             clean("the clean run", sc, 0, g.h);
+            int now = -1;
+            (void)hipGetDevice(&now);
+            EXPECT(now == caller_device, "%s: the caller's current device was %d and is %d after the calls", sc.name, caller_device, now);
         }
         printf("%-60s %5ld fallible runtime calls\n", sc.name, total);
         // with issuing threads the order of the calls is not deterministic: walk a sample there (every call is still some n)
-        const long stride = threads_only ? (total > 40 ? total / 40 : 1) : (threaded ? 3 : 1);
+        const long stride = threads_only || devices_mode ? (total > 40 ? total / 40 : 1) : (threaded ? 3 : 1);
         for (long n = 1; n <= total; n += stride) {
             Grid g(sc.dims, sc.eps, sc.stagger);
             fake_hip_fail_at(n);
@@ -238,8 +265,12 @@ int main(int argc, char **argv)
             EXPECT(rc2 == 0, "%s, after call %ld (%s) had failed: the next run returned %d", sc.name, n, what.c_str(), rc2);
             cleanup(&g.h);
             if (!clean("the run after the unwind", sc, n, g.h)) break;
+            int now = -1;
+            (void)hipGetDevice(&now);
+            EXPECT(now == caller_device, "%s, call %ld (%s): the caller's current device was %d and is %d", sc.name, n, what.c_str(), caller_device, now);
         }
         set_env(sc.env, false);
+        (void)hipSetDevice(0);
     }
     printf("walked %ld failing calls (%ld tolerated by a fallback)\n", walked, tolerated);
     for (auto &kv : codes) {

@@ -86,7 +86,11 @@ int fake_hip_failed(void);                // whether the armed failure has fired
 const char *fake_hip_failed_call(void);   // its name
 long fake_hip_live(int kind);             // live objects: 0 device allocations, 1 pinned host allocations, 2 streams, 3 events, 4 graphs
 long fake_hip_misuse(void);               // frees / destroys of things that were not live, copies into unknown device memory
-void fake_hip_set_devices(int n);
+void fake_hip_set_devices(int n);          // devices the runtime shows (also forgets every enabled peer access)
+void fake_hip_set_peer_capable(int on);    // what hipDeviceCanAccessPeer says about two different devices (default 1)
+long fake_hip_affinity(void);              // violations of the device rules: kernels / events / copies on the wrong device, memory of another
+                                           // device touched without peer access, hipMemcpyPeerAsync naming the wrong devices
+const char *fake_hip_first_affinity(void); // the first one, in words
 #ifdef __cplusplus
 }
 #endif

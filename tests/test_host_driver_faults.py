@@ -72,6 +72,43 @@ def test_every_failing_runtime_call_unwinds_cleanly_under_asan_ubsan(tmp_path):
     assert walked and int(walked[0].split()[1]) > 3000, walked
 
 
+def test_distinct_devices_keep_the_runtimes_device_rules(tmp_path):
+    """FOUR fake devices with the device rules of the real runtime enforced (tests/fake_hip/fake_hip.cpp, "device affinity"): a kernel
+    goes into a stream of the CURRENT device and touches only that device's memory or an enabled peer's, an event is recorded into a
+    stream of its own device, hipMemcpyPeerAsync names the devices that own the buffers -- with every slab on a device of its own, device
+    lists out of order and with repeats, 2-D rows and 3-D planes, fused tol pairs, devices that cannot reach each other (staged halos),
+    the caller's current device not 0 (and restored afterwards), clean runs and a sample of failing calls.  No session of this project has
+    had two GPUs; this is the closest the multi-device mode's device bookkeeping comes to a node before the first real one."""
+    exe = build(tmp_path, "address,undefined")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    env.pop("LD_PRELOAD", None)
+    run = subprocess.run([exe, "devices"], capture_output=True, text=True, env=env, timeout=1500)
+    tail = run.stdout[-3000:] + run.stderr[-3000:]
+    assert run.returncode == 0, tail
+    assert "fault driver: ok" in run.stdout
+    for bad in ("AddressSanitizer", "LeakSanitizer", "runtime error", "EXPECT failed"):
+        assert bad not in run.stderr, tail
+    assert run.stdout.count("fallible runtime calls") == 10, tail          # ten device scenarios ran
+
+
+def test_the_device_model_catches_a_driver_that_forgets_a_device(tmp_path):
+    """The check above is only worth something if it can fail: the same program built from a MUTATED copy of driver_multi.hip -- the
+    uploads select the first slab's device instead of each slab's own -- must report violations of the device rules."""
+    src = open(os.path.join(CSRC, "driver_multi.hip")).read()
+    good = "if (hipSetDevice(sl.dev) != hipSuccess) return EPIC_ERROR_DEVICE_MALLOC;"
+    assert src.count(good) == 2
+    mutated = tmp_path / "driver_multi_mutated.hip"
+    mutated.write_text(src.replace(good, "if (hipSetDevice(c->slabs[0].dev) != hipSuccess) return EPIC_ERROR_DEVICE_MALLOC;"))
+    exe = str(tmp_path / "fault_driver_mutated")
+    units = [str(mutated) if f == "driver_multi.hip" else os.path.join(CSRC, f) for f in DRIVER_UNITS]
+    srcs = [os.path.join(CSRC, f) for f in ("harmonic_cpu.cpp", "harmonic_path_cpu.cpp", "harmonic_legacy_cpu.cpp", "abi_checks.cpp", "driver_config.cpp")]
+    subprocess.run(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-I", FAKE, "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-x", "c++", *units,
+                    os.path.join(FAKE, "fake_hip.cpp"), os.path.join(FAKE, "driver.cpp"), *srcs, "-lpthread", "-o", exe], check=True)
+    run = subprocess.run([exe, "devices"], capture_output=True, text=True, timeout=1500)
+    assert run.returncode != 0 and "fault driver: ok" not in run.stdout
+    assert "violations of the device rules" in run.stderr and "while device 0 is current" in run.stderr, run.stderr[-2000:]
+
+
 def test_issuing_threads_are_clean_under_tsan(tmp_path):
     exe = build(tmp_path, "thread")
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0:second_deadlock_stack=1")
