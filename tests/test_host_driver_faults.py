@@ -113,8 +113,9 @@ def test_issuing_threads_are_clean_under_tsan(tmp_path):
     exe = build(tmp_path, "thread")
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0:second_deadlock_stack=1")
     env.pop("LD_PRELOAD", None)
-    run = subprocess.run([exe, "threads"], capture_output=True, text=True, env=env, timeout=1500)
-    tail = run.stdout[-3000:] + run.stderr[-3000:]
-    assert run.returncode == 0, tail
-    assert "fault driver: ok" in run.stdout
-    assert "ThreadSanitizer" not in run.stderr and "EXPECT failed" not in run.stderr, tail
+    for mode in ("threads", "devices"):     # one device named several times; four fake devices under the device rules (issuing threads in both)
+        run = subprocess.run([exe, mode], capture_output=True, text=True, env=env, timeout=1500)
+        tail = run.stdout[-3000:] + run.stderr[-3000:]
+        assert run.returncode == 0, (mode, tail)
+        assert "fault driver: ok" in run.stdout, (mode, tail)
+        assert "ThreadSanitizer" not in run.stderr and "EXPECT failed" not in run.stderr, (mode, tail)
