@@ -56,7 +56,7 @@ struct Sweep3dArgs {
 // (hs: the split of the row's two strip-edge cells hl / hr -- .x the left one's, .y the right one's)
 // In two halves, so that a wave that updates two rows can have the table reads of both in flight before it waits for any:
 // tol_row_3d_front -- everything up to the ISSUE of the reads (both pairs of cells; red-black: the one pair of this colour);
-// tol_row_3d_back<W0, W1> -- waits until at most W0 (W1) younger LDS reads are outstanding for the first (second) pair, and
+// tol_row_3d_back<W0, W1> -- waits until at most W0 (W1) younger table lookups (cells) are outstanding for the first (second) pair, and
 // finishes the cells.
 struct TolRowFront { TolPre2 pxz, pyw; TolLnPair f0, f1; };
 template <bool RB>
