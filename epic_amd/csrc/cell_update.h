@@ -97,7 +97,23 @@ __constant__ const double kLogTab[32] = {
 struct MathTab {
     const double2 *ln;   // LDS: {invc, logc + k ln2} x 64
     const double *ex;    // LDS: 2^((j & 31)/32), j = 0..255
+    // Round 5: the f64 constants of the two routines, and where two of them live.  A VOP3 instruction reads at most one scalar operand, so
+    // the first fma of each Horner chain (coefficient AND addend constant) takes its addend from a vector register pair.
+    //   kConstsPlain  literals, the compiler's choice: as rounds 1-4.
+    //   kConstsKeep   those two addends (e2, c0) are held in register pairs the compiler cannot see through and the fma is issued as the
+    //                 three-address v_fma_f64 (fma_keep_addend).  In the kernels with scalar branches in their row loop -- the red-black
+    //                 ones -- the compiler otherwise picks the two-address v_fmac_f64 and COPIES the addend first, every time (v_mov_b64 +
+    //                 v_fmac_f64: 1.6 moves per cell; 1.2-4 % of their VALU instructions, and with the two SGPR pairs gone the tracked pair
+    //                 kernel spills fewer scalars into VGPR lanes: 341 -> 281 v_readlane / v_writelane per 40 cells).  The plain Jacobi
+    //                 kernels do not make the copies and the list-driven single sweeps are at the SGPR limit, where the two scalar pairs the
+    //                 asm operands pin cost more in spills than the moves do: they stay plain.
+    // `consts` is a compile-time constant after inlining.  (All nine constants in vector registers -- 18 VGPRs, 341 -> 203 lane moves,
+    // -5 % VALU instructions in the tracked pair kernel, occupancy 7 -> 5 -- measured the same as kConstsKeep on whole relaxations,
+    // 2.31 against 2.33 s plain; not kept.  profiles/r05_experiments.txt item 12.)
+    double inv_ln2n, shift, e3, e2, e1, a1, c0, a0, ln4;
+    int consts;
 };
+constexpr int kConstsPlain = 0, kConstsKeep = 1;
 constexpr int kLnTabEntries = 64;
 constexpr int kExTabEntries = 256;
 constexpr int kMathLdsDoubles = 2 * kLnTabEntries + kExTabEntries;   // 3 KiB per workgroup
@@ -124,23 +140,42 @@ __device__ __forceinline__ MathTabRegs math_tables_fetch()
 // Where the two tables sit inside `lds`: pure address arithmetic on the kernel's __shared__ array, so that the LDS
 // offsets of the lookups are compile-time constants (keep it out of loop-carried variables: a table pointer that went
 // through the task loop of the list-driven kernels cost one v_add_u32 per lookup).
-__device__ __forceinline__ MathTab math_tables_at(double *lds)
+#ifndef EPIC_PRECISE_VGPR_CONSTS
+#define EPIC_PRECISE_VGPR_CONSTS 1   // build knob (A/B): 0 = every kernel kConstsPlain, as rounds 1-4
+#endif
+__device__ __forceinline__ double fma_keep_addend(int consts, double c, double r, double addend)
 {
-    return MathTab{reinterpret_cast<double2 *>(lds), lds + 2 * kLnTabEntries};
+    if (consts == kConstsKeep) {
+        double y;
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(y) : "s"(c), "v"(r), "v"(addend));
+        return y;
+    }
+    return __builtin_fma(c, r, addend);
+}
+__device__ __forceinline__ MathTab math_tables_at(double *lds, int consts = kConstsPlain)
+{
+    if (!EPIC_PRECISE_VGPR_CONSTS) consts = kConstsPlain;
+    // glibc e_expf.c: N / ln2, the shift, C[0..2] / N^(3..1);  e_logf.c: A[1], A[2], A[0];  harmonic_cpu.cpp:70: log(2.0 * n)
+    double inv_ln2n = 0x1.71547652b82fep+5, shift = 0x1.8p+52, e3 = 0x1.c6af84b912394p-20, e2 = 0x1.ebfce50fac4f3p-13,
+           e1 = 0x1.62e42ff0c52d6p-6, a1 = 0x1.5575b0be00b6ap-2, c0 = -0x1.ffffef20a4123p-2, a0 = -0x1.00ea348b88334p-2, ln4 = kLn4;
+    if (consts == kConstsKeep) asm volatile("" : "+v"(e2), "+v"(c0));
+    return MathTab{reinterpret_cast<double2 *>(lds), lds + 2 * kLnTabEntries, inv_ln2n, shift, e3, e2, e1, a1, c0, a0, ln4, consts};
 }
 __device__ __forceinline__ void math_tables_commit(const MathTabRegs &r, double *lds)
 {
     const int lane = threadIdx.x & 63;
-    const MathTab t = math_tables_at(lds);
+    MathTab t{};   // (addresses only)
+    t.ln = reinterpret_cast<double2 *>(lds);
+    t.ex = lds + 2 * kLnTabEntries;   // (addresses only)
     static_assert(kExTabEntries == 256 && kLnTabEntries == 64, "four exp entries and one log entry per lane");
 #pragma unroll
     for (int j = 0; j < kExTabEntries; j += 64) reinterpret_cast<uint64_t *>(const_cast<double *>(t.ex))[lane + j] = r.ex;
     const_cast<double2 *>(t.ln)[lane] = double2{r.invc, r.y0};
 }
-__device__ __forceinline__ MathTab math_tables_load(double *lds)
+__device__ __forceinline__ MathTab math_tables_load(double *lds, int consts = kConstsPlain)
 {
     math_tables_commit(math_tables_fetch(), lds);
-    return math_tables_at(lds);
+    return math_tables_at(lds, consts);
 }
 
 // e^x for x <= 0.  glibc e_expf.c: z = x N/ln2, k = round(z), r = z - k, s = 2^(k/N) from the table, cubic in r,
@@ -152,18 +187,17 @@ __device__ __forceinline__ MathTab math_tables_load(double *lds)
 __device__ __forceinline__ float precise_exp(float x, const MathTab &tab)
 {
     const double xd = (double)x;
-    const double kInvLn2N = 0x1.71547652b82fep+5, kShift = 0x1.8p+52;
-    const double ks = __builtin_fma(xd, kInvLn2N, kShift);
+    const double ks = __builtin_fma(xd, tab.inv_ln2n, tab.shift);
     const int ki = (int)(uint32_t)__builtin_bit_cast(uint64_t, ks);  // low word: k in two's complement
-    const double kd = ks - kShift;
-    const double r = __builtin_fma(xd, kInvLn2N, -kd);
+    const double kd = ks - tab.shift;
+    const double r = __builtin_fma(xd, tab.inv_ln2n, -kd);
     // glibc forms s = 2^(k/N) by adding k << 47 to the table word; 2^((k mod N)/N) scaled by ldexp is the same number
     // and, unlike the integer add, degrades to 0 for the x = -1e6 terms (neighbours that are obstacles) without a clamp.
     int off;  // (k & 0xff) << 3: byte 0 of k, shifted, in one instruction
     asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off) : "v"(3), "v"(ki));
     const double s0 = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab.ex) + off);
-    double y = __builtin_fma(0x1.c6af84b912394p-20, r, 0x1.ebfce50fac4f3p-13);
-    y = __builtin_fma(y, r, 0x1.62e42ff0c52d6p-6);
+    double y = fma_keep_addend(tab.consts, tab.e3, r, tab.e2);
+    y = __builtin_fma(y, r, tab.e1);
     y = __builtin_fma(y, r, 1.0);
     return (float)__builtin_ldexp(y * s0, ki >> 5);
 }
@@ -178,8 +212,8 @@ __device__ __forceinline__ double precise_ln_d(float sf, const MathTab &tab)  //
     const double invc = ent.x, y0 = ent.y;
     const double r = __builtin_fma((double)sf, invc, -1.0);  // = z invc_i - 1 with z = s 2^-k, see MathTab
     const double r2 = r * r;
-    double y = __builtin_fma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);
-    y = __builtin_fma(-0x1.00ea348b88334p-2, r2, y);
+    double y = fma_keep_addend(tab.consts, tab.a1, r, tab.c0);
+    y = __builtin_fma(tab.a0, r2, y);
     return __builtin_fma(y, r2, y0 + r);
 }
 __device__ __forceinline__ float precise_ln(float sf, const MathTab &tab) { return (float)precise_ln_d(sf, tab); }
@@ -678,7 +712,7 @@ __device__ __forceinline__ float cell_update_2d(float up, float down, float left
         float s = t2 + 1.0f;
         add_where(s, PQ, t2, ec);
         const float t = mx + precise_ln(s, lds);
-        return (float)((double)t - kLn4);
+        return (float)((double)t - lds.ln4);
     }
     float s = m_exp<MATH>(up - mx, lds) + m_exp<MATH>(down - mx, lds);
     s = s + m_exp<MATH>(left - mx, lds);

@@ -46,6 +46,13 @@
 #include "kernels.h"
 #include "wake.h"
 
+// where the precise routines' f64 constants live, per kernel (cell_update.h: MathTab::consts); build knobs for the A/B
+#ifndef EPIC_CONSTS_SWEEP2D
+#define EPIC_CONSTS_SWEEP2D(RB, TRACK) ((RB) && !(TRACK) ? kConstsKeep : kConstsPlain)
+#endif
+#ifndef EPIC_CONSTS_RBPAIR
+#define EPIC_CONSTS_RBPAIR(TRACK, CHECK) kConstsKeep
+#endif
 namespace epic_hip {
 
 namespace {
@@ -119,7 +126,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (SweepOcc<CHECK, MATH, RB, 
     // libm tables in LDS (precise math only): fetched here, written to LDS only after the first task's row loads are
     // under way, so that the fetch from constant memory hides behind them (the small ROS maps run one row per wave:
     // 3.45 -> 2.95 us per sweep of the 482 x 482 map)
-    const MathTab lds = math_tables_at(math_lds);
+    const MathTab lds = math_tables_at(math_lds, EPIC_CONSTS_SWEEP2D(RB, TRACK));
     MathTabRegs tab_regs = {};
     if (MATH == kMathPrecise) tab_regs = math_tables_fetch();
     bool tables_pending = MATH == kMathPrecise;
@@ -460,7 +467,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
 {
     __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];
     MathTab lds = {};
-    if (MATH == kMathPrecise) lds = math_tables_load(math_lds);
+    if (MATH == kMathPrecise) lds = math_tables_load(math_lds, EPIC_CONSTS_RBPAIR(TRACK, CHECK));
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (TRACK) wake_reset_next(a.wake);

@@ -21,6 +21,9 @@
 #include "kernels.h"
 #include "wake.h"
 
+#ifndef EPIC_CONSTS_SWEEP3D   // build knob (A/B): where the precise routines' f64 constants live (cell_update.h: MathTab::consts)
+#define EPIC_CONSTS_SWEEP3D(RB, TRACK) kConstsPlain   // (kConstsKeep for the red-black sweeps: +0.2 ... 1 % instructions; the 3-D loops keep their addends already)
+#endif
 namespace epic_hip {
 
 namespace {
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, (Sweep3dOcc<CHECK, MATH, RB
     const TolLnEntry *const tl = reinterpret_cast<const TolLnEntry *>(math_lds_bytes);
     if (TOL) TolLn<5>::stage(reinterpret_cast<TolLnEntry *>(math_lds_bytes));
     MathTab lds = {};
-    if (MATH == kMathPrecise) lds = math_tables_load(reinterpret_cast<double *>(math_lds_bytes));
+    if (MATH == kMathPrecise) lds = math_tables_load(reinterpret_cast<double *>(math_lds_bytes), EPIC_CONSTS_SWEEP3D(RB, TRACK));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (TRACK) wake_reset_next(a.wake);

@@ -27,6 +27,9 @@
 #include "cell_update.h"
 #include "kernels.h"
 
+#ifndef EPIC_CONSTS_TILE   // build knob (A/B): where the precise routines' f64 constants live (cell_update.h: MathTab::consts)
+#define EPIC_CONSTS_TILE(RB) kConstsPlain   // (kConstsKeep: -2.5 % VALU instructions, nothing measurable on the maps -- the tile kernel waits, it does not issue)
+#endif
 namespace epic_hip {
 
 namespace {
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(kTileThreads) void tile2d_kernel(Tile2dArgs a)
     __shared__ int step_done[kTileWaves];   // iterations each wave has finished (kTileWaveSync)
     __shared__ __attribute__((aligned(16))) char math_lds_bytes[TOL ? TolLn<4>::kLdsBytes : kMathLdsDoubles * (int)sizeof(double)];
     const TolLnEntry *const tl = reinterpret_cast<const TolLnEntry *>(math_lds_bytes);
-    const MathTab tab = math_tables_at(reinterpret_cast<double *>(math_lds_bytes));
+    const MathTab tab = math_tables_at(reinterpret_cast<double *>(math_lds_bytes), EPIC_CONSTS_TILE(RB));
     MathTabRegs tab_regs = {};
     if (MATH == kMathPrecise) tab_regs = math_tables_fetch();
 
