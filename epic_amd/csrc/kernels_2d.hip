@@ -1010,7 +1010,7 @@ __global__ void set_cells_2d_kernel(float *u, uint32_t *maskw, int rows, int col
 __global__ void eval_math_kernel(const float *in, float *out, size_t n, int which)
 {
     __shared__ __attribute__((aligned(16))) double math_lds[kMathLdsDoubles];
-    const MathTab lds = math_tables_load(math_lds);
+    const MathTab plain = math_tables_load(math_lds), keep = math_tables_at(math_lds, kConstsKeep);   // which & 2: the kept-addend form (MathTab::consts)
     // all 64 lanes stay active (as in the sweeps, whose update assumes it), so the loop count is wave-uniform and
     // out-of-range lanes work on a clamped index and skip the store
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1019,7 +1019,9 @@ __global__ void eval_math_kernel(const float *in, float *out, size_t n, int whic
     for (size_t t = 0; t < trips; t++) {
         const size_t i = first + t * stride;
         const float x = in[i < n ? i : n - 1];
-        const float r = which == 0 ? precise_exp(x, lds) : precise_ln(x, lds);
+        float r;
+        if (which & 2) r = (which & 1) == 0 ? precise_exp(x, keep) : precise_ln(x, keep);
+        else r = (which & 1) == 0 ? precise_exp(x, plain) : precise_ln(x, plain);
         if (i < n) out[i] = r;
     }
 }

@@ -142,7 +142,8 @@ int epic_hip_activity_stats2(EpicHarmonicT *harmonic, unsigned long long *active
  * currentIteration minus this number is what activity tracking skipped.  Synchronises the stream. */
 int epic_hip_work_done(EpicHarmonicT *harmonic, double *grid_iterations, int reset);
 
-/* Test hook: d_out[i] = which ? ln(d_in[i]) : exp(d_in[i]) with the precise device routines (which = 0 / 1). */
+/* Test hook: d_out[i] = (which & 1) ? ln(d_in[i]) : exp(d_in[i]) with the precise device routines; which & 2: in the form the red-black
+ * kernels use (the first Horner addend kept in vector registers, cell_update.h: MathTab::consts) -- same operations, same bits. */
 int epic_hip_eval_math(const float *d_in, float *d_out, size_t n, int which, void *stream);
 
 /* ---- several GPUs behind the unchanged ABI ------------------------------------------------------------------------

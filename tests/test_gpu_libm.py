@@ -16,8 +16,9 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
 E = eh._epic
 
 
-def test_device_libm_replica_exhaustive():
-    """Every input the sweeps can hand to the device's expf / logf -- ALL 1 120 927 745 floats in [-104, -0] for exp (below
+@pytest.mark.parametrize("form", [0, 2], ids=["plain", "kept-addend"])
+def test_device_libm_replica_exhaustive(form):
+    """(form 2: the same routines as the red-black kernels instantiate them, epic_hip.h: epic_hip_eval_math.)  Every input the sweeps can hand to the device's expf / logf -- ALL 1 120 927 745 floats in [-104, -0] for exp (below
     that the result is 0 on both sides, checked on a sample) and ALL floats in [1, 6] for log -- gives the bits of the
     host libm (the arithmetic harmonic_cpu.cpp:65-70 runs on).  The comparison runs in the checker
     (oracle_libm_mismatches, OpenMP), chunk by chunk."""
@@ -37,7 +38,7 @@ def test_device_libm_replica_exhaustive():
             bits = torch.where(bits >= 2 ** 31, bits - 2 ** 32, bits).to(torch.int32)
             d_in = bits.view(torch.float32)
             d_out = torch.empty_like(d_in)
-            assert E.epic_hip_eval_math(d_in.data_ptr(), d_out.data_ptr(), n, which, s) == 0
+            assert E.epic_hip_eval_math(d_in.data_ptr(), d_out.data_ptr(), n, which | form, s) == 0
             torch.cuda.synchronize()
             got = d_out.cpu().numpy()
             first_bad = ct.c_size_t(0)
@@ -57,12 +58,12 @@ def test_device_libm_replica_exhaustive():
     x = -np.geomspace(104.0, 3.0e6, 100000).astype(np.float32)
     d_in = torch.from_numpy(x).to(dev)
     d_out = torch.empty_like(d_in)
-    assert E.epic_hip_eval_math(d_in.data_ptr(), d_out.data_ptr(), x.size, 0, s) == 0
+    assert E.epic_hip_eval_math(d_in.data_ptr(), d_out.data_ptr(), x.size, form, s) == 0
     torch.cuda.synchronize()
     assert not d_out.cpu().numpy().any()
     # +0.0 is what a tie produces (w - mx with w == mx); the range above starts at -0.0
     z = torch.zeros(64, dtype=torch.float32, device=dev)
     o = torch.empty_like(z)
-    assert E.epic_hip_eval_math(z.data_ptr(), o.data_ptr(), 64, 0, s) == 0
+    assert E.epic_hip_eval_math(z.data_ptr(), o.data_ptr(), 64, form, s) == 0
     torch.cuda.synchronize()
     assert o.cpu().numpy().tolist() == [1.0] * 64
