@@ -166,7 +166,7 @@ __device__ __forceinline__ void math_tables_commit(const MathTabRegs &r, double 
     const int lane = threadIdx.x & 63;
     MathTab t{};   // (addresses only)
     t.ln = reinterpret_cast<double2 *>(lds);
-    t.ex = lds + 2 * kLnTabEntries;   // (addresses only)
+    t.ex = lds + 2 * kLnTabEntries;
     static_assert(kExTabEntries == 256 && kLnTabEntries == 64, "four exp entries and one log entry per lane");
 #pragma unroll
     for (int j = 0; j < kExTabEntries; j += 64) reinterpret_cast<uint64_t *>(const_cast<double *>(t.ex))[lane + j] = r.ex;
