@@ -78,7 +78,7 @@ Config Config::from_env()
         const float v = (float)atof(e);
         if (v >= 1.0f && v <= 1e9f) c.tol_finish_factor = v;
     }
-    c.launch.flags = int_of("EPIC_HIP_FLAGS", 3);
+    c.launch.flags = int_of("EPIC_HIP_FLAGS", 7);
     e = env("EPIC_HIP_LIST_WAVES");
     if (e && atol(e) >= 4) c.launch.list_waves = (size_t)atol(e);
     c.launch.pair3d = !is_zero("EPIC_HIP_3D_PAIR");

@@ -14,7 +14,8 @@
 namespace epic_hip {
 // What the kernel launchers (kernels_2d.hip, kernels_3d.hip, kernels.h) take from the environment.
 struct LaunchKnobs {
-    int flags = 3;             // EPIC_HIP_FLAGS: bit 0 = alternate march direction (2-D sweeps)
+    int flags = 7;             // EPIC_HIP_FLAGS: bit 0 = alternate march direction (2-D sweeps), bit 2 = the tol fused passes cut their rows into as many
+                               // chunks as fit the last round of blocks (kernels_2d.hip: tighten_chunks); speed only, never results
     size_t list_waves = 0;     // EPIC_HIP_LIST_WAVES: persistent waves of a list-driven launch (0: what the chip holds)
     bool pair3d = true;        // EPIC_HIP_3D_PAIR=0: the one-plane-per-wave 3-D kernel for every launch
     int pair3d_rows = 0;       // EPIC_HIP_3D_PAIR_ROWS: x1-rows per task of the two-plane kernel (0: the rule)

@@ -73,7 +73,8 @@ struct Sweep2dArgs {
     int rows;               // rows of the (local) grid, including ghost rows in slab mode
     int pitch;              // floats per row, multiple of 256
     int row_begin, row_end; // rows swept by this launch
-    int rows_per_task;
+    int rows_per_task;      // rows of a task's chunk ...
+    int chunk_rem;          // ... the first chunk_rem chunks have one row more (fused passes, tighten_chunks below; 0: all alike)
     int nstrips;            // ceil(pitch / 256)
     int ntasks;             // nstrips * nchunks
     int parity;             // red-black scheme only: currentIteration & 1 (which colour this half-sweep updates)
@@ -496,8 +497,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
     if (TRACK && lane == 0) a.wake.queued_in[task] = 0;
     const int strip = task % a.nstrips;
     const int chunk = task / a.nstrips;
-    const int r0 = a.row_begin + chunk * a.rows_per_task;
-    const int r1 = min(r0 + a.rows_per_task, a.row_end);
+    const int r0 = a.row_begin + chunk * a.rows_per_task + min(chunk, a.chunk_rem);
+    const int r1 = min(r0 + a.rows_per_task + (chunk < a.chunk_rem ? 1 : 0), a.row_end);
     const int col = strip * kFusedOut - kColsPerLane + lane * kColsPerLane;  // lane 0 = left halo lane
     const int lcol = min(max(col, 0), a.pitch - kColsPerLane);
     const bool owner = lane >= 1 && lane <= kWave - 2 && col < a.pitch;
@@ -700,8 +701,8 @@ __device__ __forceinline__ void tol_fused_pass(const Sweep2dArgs &a, TolLnEntry 
     if (TRACK && lane == 0) a.wake.queued_in[task] = 0;
     const int strip = task % a.nstrips;
     const int chunk = task / a.nstrips;
-    const int r0 = a.row_begin + chunk * a.rows_per_task;
-    const int r1 = min(r0 + a.rows_per_task, a.row_end);
+    const int r0 = a.row_begin + chunk * a.rows_per_task + min(chunk, a.chunk_rem);
+    const int r1 = min(r0 + a.rows_per_task + (chunk < a.chunk_rem ? 1 : 0), a.row_end);
     const int col = strip * kFusedOut - kColsPerLane + lane * kColsPerLane;  // lane 0 = left halo lane
     const int lcol = min(max(col, 0), a.pitch - kColsPerLane);
     const bool owner = lane >= 1 && lane <= kWave - 2 && col < a.pitch;
@@ -1044,6 +1045,34 @@ int resident_blocks_of(const void *kernel)
     return cache[kernel] = blocks * cus;
 }
 
+// The fused passes without work lists: how many chunks the rows are cut into.  A launch's workgroups (four waves, one per SIMD) are dealt
+// over the CUs, so what a launch costs is the CU with the most blocks: ceil(blocks / CUs) of them, each as long as its chunk is high.
+// 8192 rows at 40 per task are 205 chunks x 34 strips = 1743 blocks = 6.81 per CU -- seven on most CUs; 210 chunks still make seven
+// (1785 blocks = 6.97) and are 39 rows high.  So: the most chunks that keep ceil(blocks / CUs) where the requested height puts it, the
+// rows dealt evenly over them (heights q and q + 1, never above the requested one).  Measured (profiles/r05_experiments.txt item 15):
+// the pass steps up by 7-10 % where one block more than a multiple of the CU count appears (54 -> 55, 68 -> 69 rows per task), and
+// 8190 rows = 210 x 39 run 1.4 % faster than as 205 x 40.  EPIC_HIP_FLAGS bit 2 (default on) switches it.
+void tighten_chunks(Sweep2dArgs &a, int rows)
+{
+    a.chunk_rem = 0;
+    if (!(a.flags & 4)) return;
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0, n = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 0;
+        (void)hipGetLastError();
+    }
+    if (cus <= 0 || a.nstrips <= 0) return;
+    const long long blocks = ((long long)a.nchunks * a.nstrips + kWavesPerBlock - 1) / kWavesPerBlock;
+    const long long per_cu = (blocks + cus - 1) / cus;
+    long long n = per_cu * cus * kWavesPerBlock / a.nstrips;          // chunks that still fit
+    n = std::min<long long>(n, rows / std::max(8, a.rows_per_task / 2));   // (never less than half the requested height, or 8 rows)
+    if (n <= a.nchunks) return;
+    a.nchunks = (int)n;
+    a.rows_per_task = rows / (int)n;
+    a.chunk_rem = rows % (int)n;
+}
+
 hipError_t launch_eval_math(const float *in, float *out, size_t n, int which, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
@@ -1112,6 +1141,7 @@ hipError_t launch_sweep_2d(const float *in, float *out, const uint32_t *maskw, i
     a.row_begin = row_begin;
     a.row_end = row_end;
     a.rows_per_task = rows_per_task;
+    a.chunk_rem = 0;
     a.nstrips = (pitch + kStripCols - 1) / kStripCols;
     const int nchunks = (row_end - row_begin + rows_per_task - 1) / rows_per_task;
     a.ntasks = a.nstrips * nchunks;
@@ -1175,6 +1205,7 @@ hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw
     a.row_begin = 0;
     a.row_end = rows;
     a.rows_per_task = rows_per_task;
+    a.chunk_rem = 0;   // (one workgroup per block here, dealt as they finish: the tol passes' chunk tightening is not measured for it)
     a.nstrips = (pitch + kFusedOut - 1) / kFusedOut;
     a.nchunks = (rows + rows_per_task - 1) / rows_per_task;
     a.ntasks = a.nstrips * a.nchunks;
@@ -1237,11 +1268,13 @@ hipError_t launch_jacobi_fused_2d(const float *in, float *out, const uint32_t *m
     a.row_begin = 0;
     a.row_end = rows;
     a.rows_per_task = rows_per_task;
+    a.chunk_rem = 0;
     a.nstrips = (pitch + kFusedOut - 1) / kFusedOut;
     a.nchunks = (rows + rows_per_task - 1) / rows_per_task;
+    a.flags = sweep_flags();
+    if (!act) tighten_chunks(a, rows);   // (work lists number uniform tiles: those launches keep the requested height)
     a.ntasks = a.nstrips * a.nchunks;
     a.parity = parity < 0 ? 0 : parity & 1;
-    a.flags = sweep_flags();
     a.wake = wake_args(act, (size_t)a.ntasks);
     a.nblocks = (a.ntasks + kWavesPerBlock - 1) / kWavesPerBlock;
     a.maskf = maskf;

@@ -47,7 +47,7 @@ def test_defaults_are_the_librarys(harness):
     assert c["no_fuse"] is False and c["no_graph"] is False and c["fuse_min_cells"] == 1 << 22 and c["tune"] is True
     assert c["tile"] is True and c["tile_max_cells"] == 3 << 20 and c["tile_pipeline"] is True and c["track_pairs"] is True
     assert c["track_switch"] == -1 and c["tol_finish"] == -1 and c["tol_finish_factor"] == 0
-    assert k == {"flags": 3, "list_waves": 0, "pair3d": 1, "pair3d_rows": 0, "march_x0": 0}
+    assert k == {"flags": 7, "list_waves": 0, "pair3d": 1, "pair3d_rows": 0, "march_x0": 0}
 
 
 def test_every_knob_is_parsed(harness):

@@ -257,6 +257,29 @@ def test_tol_fused_double_sweeps_equal_the_checker_bit_for_bit(m, seed, dens, ro
             assert gdelta == wdelta
 
 
+@pytest.mark.parametrize("scheme", [eh.SCHEME_JACOBI, eh.SCHEME_REDBLACK], ids=["jacobi", "redblack"])
+@pytest.mark.parametrize("m,rows", [([1237, 1500], 40), ([1237, 1500], 100), ([1237, 1500], 17), ([2051, 520], 64), ([999, 8200], 46)])
+def test_fused_passes_cut_into_as_many_chunks_as_fit_the_last_round_change_nothing(m, rows, scheme, monkeypatch):
+    """kernels_2d.hip: tighten_chunks -- a fused pass without work lists cuts its rows into the most chunks that still make the same
+    number of blocks per CU, heights q and q + 1 (the first `rows % chunks` chunks one row higher).  EPIC_HIP_FLAGS bit 2 switches it:
+    with and without, on row counts that divide by nothing, the field and delta equal the checker's bit for bit."""
+    monkeypatch.setenv("EPIC_HIP_FUSE_MIN_CELLS", "0")
+    monkeypatch.setenv("EPIC_HIP_NO_GRAPH", "1")
+    monkeypatch.setenv("EPIC_HIP_FUSED_ROWS", str(rows))
+    u0, locked = with_extra_goals(m, 21, 0.05)
+    k = 7                                               # three pairs and the check
+    want, wdelta = checker_iterations(m, u0, locked, k, scheme)
+    try:
+        for flags in ("7", "3"):
+            monkeypatch.setenv("EPIC_HIP_FLAGS", flags)
+            assert E.epic_hip_config_reload(None) == 0       # the launch knobs are the process's
+            got, gdelta = gpu_iterations(m, u0, locked, k, scheme, 0)
+            assert np.array_equal(got, want) and gdelta == wdelta, f"{m}, {rows} rows per task, flags {flags}"
+    finally:
+        monkeypatch.delenv("EPIC_HIP_FLAGS", raising=False)
+        assert E.epic_hip_config_reload(None) == 0
+
+
 def test_tol_fused_pairs_with_live_edits_and_model_updates(monkeypatch):
     """The navigation node's flow (src/epic_navigation_node_harmonic.cpp:165-189, :357-380) with the fused passes forced on:
     update(k) batches (a check, then k - 1 plain iterations = pairs and an odd one), live cell edits on the resident state
