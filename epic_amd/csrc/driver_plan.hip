@@ -93,6 +93,10 @@ int jacobi_fused_rows_per_task(const Ctx *c)
 // is about to run on a grid of at least 4 Mcell: every candidate runs three times from the current buffer into the other
 // one (which the next real pass overwrites anyway; nothing else is touched) between two events, ~10 ms in all.  Results do
 // not depend on the height (tests/test_gpu_tol.py, test_gpu_parity.py sweep it).  EPIC_HIP_TUNE=0: the rules only.
+// (Round 5 found the largest part of it for the tol passes -- the CU with the most blocks sets the time, ceil(blocks / CUs) of them: the
+// steps of 7-10 % sit where one block more than a multiple of the CU count appears -- and the launcher now cuts the rows into as many
+// chunks as fit that count (kernels_2d.hip: tighten_chunks), so that a height only chooses the number of blocks per CU: the measurement
+// stays, its table is flat within 2 % around the best where it was a saw.)
 void tune_fused_rows(Ctx *c, int kind, unsigned iteration)
 {
     if (c->tuned_rows[kind] != 0) return;
