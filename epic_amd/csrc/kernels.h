@@ -156,35 +156,20 @@ hipError_t launch_follow_paths_2d(const float *u, const uint32_t *maskw, int row
 #endif
 constexpr int kTolRowsAhead = EPIC_TOL_AHEAD;
 constexpr int kTolTripRows = (kTolRowsAhead + 3) % 2 == 0 ? kTolRowsAhead + 3 : 2 * (kTolRowsAhead + 3);
-// Rows per task of the fused double sweep (jacobi_fused2d_kernel) for a grid -- or a slab -- of `rows` rows.  A task
-// recomputes the first iteration of one row above and one below its chunk, so taller is cheaper; the chip holds 4096 of
-// these waves at a time (256 CUs x 16), and a launch whose tasks fill a whole number of such rounds wastes no tail: the
-// height is chosen so that the tasks come to just under k x 4096 for the k = 2 .. 8 that fills its last round best
-// (8192^2: 23 rows, 357 x 34 tasks = 2.96 rounds -- 97.4-98.0 us per iteration against 100.0 at 17 rows = 4.001 rounds,
-// 101 at 18, 29, 36, same box).  Short grids (slabs): one round, at least 12 rows -- measured, us per iteration at 4 / 8 /
-// 12 / 16 / 24 / 32 rows: 1024 x 8192 16.8 / 17.6 / 16.0 / 19.8 / 22.0 / 27.7; 2048 x 8192 30.1 / 28.2 / 28.0 / 30.3 /
-// 28.8 / 36.2 (18: 27.7); 4096 x 8192 56.3 / 50.0 / 50.0 / 49.6 / 50.6 / 55.8 (18: 49.9).  Many rounds: 24.
+// Rows per task of the fused double sweep (jacobi_fused2d_kernel) for a grid -- or a slab -- of `rows` rows, before anything is
+// measured (driver_plan.hip: tune_fused_rows measures on grids of 4 Mcell and more).  A task recomputes the first iteration of one row
+// above and one below its chunk and fills its pipeline once, so taller is cheaper -- up to about 40 rows, where the gain levels off --,
+// but the chip wants a round of waves: 4096 of them (256 CUs x 16), i.e. rows x strips / 4096 rows per task at most.  Since round 5 the
+// launcher cuts the rows into as many chunks as fit the last round of blocks (kernels_2d.hip: tighten_chunks), so the height no longer
+// has to hit a whole number of rounds itself (rounds 3-4 searched for that: 23 rows at 8192^2, 180 us per launch against 163 at 40).
+// Measured with the tightening on, us per iteration of the pass at 8 / 12 / 16 / 20 / 24 / 32 / 40 / 48 rows (tools/exp_slab_heights.py):
+// 1024 x 8192: 13.7 / 12.4 / 12.4 / 12.5 / 12.5 / 12.4 / 15.4 / 15.6;  2048 x 8192: 23.4 / 21.3 / 21.1 / 20.8 / 21.0 / 21.1 / 22.0 / 22.0;
+// 4096 x 8192: 42.8 / 42.3 / 40.0 / 38.3 / 37.9 / 37.8 / 38.0 / 39.0;  8192 x 8192 (per launch of two): 35: 172, 40: 163, 44: 164, 48: 166, 64: 167.
 inline int jacobi_fused_auto_rows(int rows, int pitch)
 {
     const long long nstrips = (pitch + 247) / 248, slots = 4096;
-    int best = 0;
-    double best_fill = 0.0;
-    for (int k = 2; k <= 8; ++k) {
-        const long long chunks_max = k * slots / nstrips;
-        if (chunks_max < 1) continue;
-        const int r = (int)((rows + chunks_max - 1) / chunks_max);
-        if (r < 12 || r > 40) continue;
-        const long long tasks = ((rows + r - 1) / r) * nstrips;
-        const double fill = (double)tasks / (double)(k * slots);
-        if (fill > best_fill) { best_fill = fill; best = r; }
-    }
-    if (best) return best;
-    if ((long long)rows * nstrips / 12 <= 2 * slots) {  // short: one round
-        const long long chunks_max = slots / nstrips > 0 ? slots / nstrips : 1;
-        const long long r = (rows + chunks_max - 1) / chunks_max;
-        return (int)(r < 12 ? 12 : r > 40 ? 40 : r);
-    }
-    return 24;
+    const long long r = (long long)rows * nstrips / slots;
+    return (int)(r < 12 ? 12 : r > 40 ? 40 : r);
 }
 // rows are padded to whole wave-strips (256 floats = 1 KiB): every lane of every wave is in bounds, always
 inline int pitch_for_cols(int cols) { return (cols + 255) / 256 * 256; }
