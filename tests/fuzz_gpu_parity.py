@@ -29,7 +29,7 @@ from epic_amd.synthetic import synthetic_grid  # noqa: E402
 
 E = eh._epic
 KNOBS = ("EPIC_HIP_DEVICES", "EPIC_HIP_HALO", "EPIC_HIP_NO_PEER", "EPIC_HIP_THREADS", "EPIC_HIP_TILE", "EPIC_HIP_TILE_HALO", "EPIC_HIP_TILE_ROWS", "EPIC_HIP_TILE_WIDTH", "EPIC_HIP_TILE_PIPELINE", "EPIC_HIP_FUSE_MIN_CELLS",
-         "EPIC_HIP_NO_FUSE", "EPIC_HIP_NO_GRAPH", "EPIC_HIP_TRACK", "EPIC_HIP_TRACK_PAIRS", "EPIC_HIP_TRACK_PAIR_ROWS", "EPIC_HIP_FUSED_ROWS",
+         "EPIC_HIP_NO_FUSE", "EPIC_HIP_NO_GRAPH", "EPIC_HIP_FLAGS", "EPIC_HIP_TRACK", "EPIC_HIP_TRACK_PAIRS", "EPIC_HIP_TRACK_PAIR_ROWS", "EPIC_HIP_FUSED_ROWS",
          "EPIC_HIP_ROWS_PER_TASK", "EPIC_HIP_3D_PAIR", "EPIC_HIP_3D_MARCH", "EPIC_HIP_3D_PAIR_ROWS", "EPIC_HIP_TRACK_SWITCH", "EPIC_HIP_MATH",
          "EPIC_HIP_SCHEME")
 MODES = [("default", eh.MATH_PRECISE, eh.SCHEME_REDBLACK), ("precise jacobi", eh.MATH_PRECISE, eh.SCHEME_JACOBI),
@@ -76,6 +76,7 @@ def draw_case(rng):
             env["EPIC_HIP_TILE"] = "0"
             if rng.random() < 0.5:
                 env["EPIC_HIP_FUSED_ROWS"] = str(int(rng.integers(4, 60)))
+            env["EPIC_HIP_FLAGS"] = rng.choice(["3", "6", None])   # (bit 2: the fused passes' chunk tightening; bit 0: march direction)
         env["EPIC_HIP_TRACK_PAIRS"] = rng.choice(["0", None])
         if rng.random() < 0.3:
             env["EPIC_HIP_TRACK_PAIR_ROWS"] = str(int(rng.integers(2, 40)))
@@ -144,6 +145,7 @@ def library(m, u0, locked, mode, k, env, edits=None):
     for a, b in env.items():
         if b is not None:
             os.environ[a] = b
+    assert E.epic_hip_config_reload(None) == 0   # EPIC_HIP_FLAGS is the process's
     try:
         h = Harmonic()
         h.set_grid(m, u0, locked)
@@ -171,6 +173,7 @@ def library(m, u0, locked, mode, k, env, edits=None):
     finally:
         for a, b in prev.items():
             os.environ.pop(a, None) if b is None else os.environ.__setitem__(a, b)
+        E.epic_hip_config_reload(None)
 
 
 def campaign(cases, seed, verbose=True):
@@ -252,6 +255,7 @@ def campaign_complete(cases, seed, verbose=True):
                 os.environ[a] = b
         os.environ["EPIC_HIP_MATH"] = names[mode[1]]
         os.environ["EPIC_HIP_SCHEME"] = "redblack" if mode[2] == eh.SCHEME_REDBLACK else "jacobi"
+        assert E.epic_hip_config_reload(None) == 0
         try:
             h = Harmonic()
             h.set_grid(m, u0, locked)
@@ -262,6 +266,7 @@ def campaign_complete(cases, seed, verbose=True):
         finally:
             for a, b in prev.items():
                 os.environ.pop(a, None) if b is None else os.environ.__setitem__(a, b)
+            E.epic_hip_config_reload(None)
         ok = np.array_equal(got, p.u) and its == int(p.h.currentIteration) and delta == float(p.h.delta)
         if verbose or not ok:
             print(f"complete {i:4d} {'ok  ' if ok else 'FAIL'} {str(m):14s} {mode[0]:15s} eps {eps:g} stagger {stagger:3d} iterations {its} (checker {int(p.h.currentIteration)}) "
