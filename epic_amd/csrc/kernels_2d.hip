@@ -1056,12 +1056,14 @@ void tighten_chunks(Sweep2dArgs &a, int rows)
 {
     a.chunk_rem = 0;
     if (!(a.flags & 4)) return;
-    static int cus = -1;
-    if (cus < 0) {
+    // (the issuing threads of the multi-device mode come here concurrently: a function-local static is initialised once, thread-safely;
+    //  the devices of a node are alike)
+    static const int cus = [] {
         int dev = 0, n = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 0;
-        (void)hipGetLastError();
-    }
+        const bool ok = hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0;
+        if (!ok) (void)hipGetLastError();
+        return ok ? n : 0;
+    }();
     if (cus <= 0 || a.nstrips <= 0) return;
     const long long blocks = ((long long)a.nchunks * a.nstrips + kWavesPerBlock - 1) / kWavesPerBlock;
     const long long per_cu = (blocks + cus - 1) / cus;
