@@ -100,6 +100,7 @@ def parse():
     ap.add_argument("--no-parity", action="store_true", help="skip the parity object (maps, 512^2 / 1024^2, 512^3 relaxations)")
     ap.add_argument("--no-config4", action="store_true", help="skip the 32768^2 leg (BASELINE configs[3]'s grid on one GPU: ~1 minute of host-side grid generation)")
     ap.add_argument("--no-maps", action="store_true", help="skip the timing of the reference's maps (BASELINE configs[0] / [1])")
+    ap.add_argument("--no-node-flow", action="store_true", help="skip the navigation node's call sequence (1 check + 49 / 99 single updates per tick) on maze, umass and the timed grid")
     ap.add_argument("--only-config5", action="store_true", help="(internal) run only the 512^3 leg and print its object: the child of the PMC passes")
     return ap.parse_args()
 
@@ -762,6 +763,87 @@ def main():
                 os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
         return res
 
+    def node_flow_leg(big=None):
+        """The reference's SECOND caller, the navigation node: every tick one harmonic_update_and_check_gpu and steps_per_update - 1
+        single harmonic_update_gpu calls (src/epic_navigation_node_harmonic.cpp:165-189; 50 steps at 10 Hz by default, 100 at 30 Hz in
+        launch/epic_navigation_node_umass.launch).  Since round 6 a plain update only counts and the library enqueues whole blocks
+        (epic_amd/csrc/driver_loop.hip: deferred iterations).  Per grid, library defaults (no environment), from the initial field:
+          execute    harmonic_execute_gpu to eps = 1e-6 (N iterations; its own final D2H included),
+          node_flow  exactly N iterations in ticks of 50 / 100 through the two fine-grained calls + the final
+                     harmonic_get_potential_values_gpu, the field compared bit for bit with execute's,
+          undeferred the same with EPIC_HIP_DEFER=0: one single-iteration launch per call, what the calls did before round 6.
+        The call loop itself is C++ (tests/plugin_replay/node_flow.cpp: -lepic through the reference's header paths, like
+        replay.cpp); grids: maze.png, umass.png (BASELINE configs[0] / [1]) and the timed 8192^2 grid (`big`)."""
+        from epic_amd.harmonic import Harmonic
+        from epic_amd.harmonic_map import HarmonicMap
+
+        so = os.path.join(ROOT, "tests", "plugin_replay", "libnodeflow.so")
+        if not os.path.exists(so):
+            return {"error": "tests/plugin_replay/libnodeflow.so is not built (python -c 'import __graft_entry__ as g; g.build()')"}
+        nf = ct.CDLL(so)
+        nf.node_flow_run.restype = ct.c_int
+        nf.node_flow_execute.restype = ct.c_int
+        res = {"note": "us_per_iteration = wall seconds / iterations, final D2H of u included on both sides; ratio = node_flow / execute "
+                       "(VERDICT r05 item 1 asks <= 1.25); undeferred = EPIC_HIP_DEFER=0, one launch per call as before round 6; "
+                       "bit_identical: the field after the same number of iterations equals harmonic_execute_gpu's"}
+        grids = []
+        for name in ("maze", "umass"):
+            hm = HarmonicMap().load(os.path.join(ROOT, "tests", "golden", "maps", name + ".png"))
+            grids.append((name, list(hm.shape), hm.u_array().ravel().copy(), hm.locked_array().ravel().copy()))
+        if big is not None:
+            grids.append(big)
+        for name, grid, u0, locked in grids:
+            h = Harmonic()
+            h.set_grid(grid, u0, locked)
+            h.epsilon = 1e-6
+            h.numIterationsToStaggerCheck = 100
+            for fn in (E.harmonic_initialize_dimension_size_gpu, E.harmonic_initialize_potential_values_gpu, E.harmonic_initialize_locked_gpu):
+                assert fn(h) == 0, fn.__name__
+            sec = ct.c_double(0.0)
+            done, conv = ct.c_uint(0), ct.c_uint(0)
+            entry = {}
+            try:
+                ex_s, want, its = None, None, 0
+                for rep in range(2):   # second of two
+                    h.u_array().ravel()[:] = u0
+                    assert E.harmonic_update_model_gpu(h) == 0
+                    assert nf.node_flow_execute(ct.byref(h), 1024, ct.byref(sec)) == 0
+                    ex_s, its = sec.value, int(h.currentIteration)
+                want = h.u_array().ravel().copy()
+                entry["execute"] = {"iterations": its, "seconds": round(ex_s, 4), "us_per_iteration": round(ex_s / its * 1e6, 3)}
+
+                def flow(steps, reps):
+                    best, same = None, None
+                    for rep in range(reps):
+                        h.u_array().ravel()[:] = u0
+                        assert E.harmonic_update_model_gpu(h) == 0
+                        if not h.d_delta:
+                            assert E.harmonic_initialize_gpu(h, 1024) == 0
+                        h.currentIteration = 0
+                        rc = nf.node_flow_run(ct.byref(h), its, steps, 1024, 1, ct.byref(sec), ct.byref(done), ct.byref(conv))
+                        assert rc == 0 and done.value == its, (rc, done.value, its)
+                        best = sec.value if best is None or rep == 1 else min(best, sec.value)
+                        same = bool(np.array_equal(h.u_array().ravel(), want))
+                    return {"steps_per_tick": steps, "seconds": round(best, 4), "us_per_iteration": round(best / its * 1e6, 3),
+                            "ratio_to_execute": round(best / ex_s, 3), "bit_identical": same, "converged_ticks": int(conv.value)}
+
+                reps = 2 if len(u0) < (1 << 24) else 1
+                entry["node_flow"] = [flow(50, reps + 1), flow(100, reps + 1)]
+                os.environ["EPIC_HIP_DEFER"] = "0"
+                assert E.epic_hip_config_reload(h) == 0
+                try:
+                    entry["undeferred"] = [flow(50, reps)]
+                finally:
+                    del os.environ["EPIC_HIP_DEFER"]
+                    assert E.epic_hip_config_reload(h) == 0
+                dump = eh.config_dump(h)
+                if dump:
+                    entry["kernel_path"] = dump["path"]["plain_batch"]
+            finally:
+                abi_release(h)
+            res[name] = entry
+        return res
+
     if args.only_config5:   # (internal: the child of the PMC passes for config5's roofline object)
         print(json.dumps({"config5": config5_leg(100)}), flush=True)
         return
@@ -958,6 +1040,8 @@ def main():
             out["config4"] = config4_leg()
         if not args.no_maps:
             out["maps"] = maps_leg()
+        if not args.no_node_flow:
+            out["node_flow"] = node_flow_leg(("8192^2" if n == 8192 else "%d^2" % n, grid, u0, locked))
         if not args.no_parity:
             out["parity"] = parity_object(args, E, MODES, relaxed, locked)
         if not args.no_cpu:

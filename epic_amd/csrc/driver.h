@@ -220,6 +220,22 @@ struct Ctx {
     int halo = 8, since = 0;       // ghost rows per interior side in use; iterations since the last exchange
     int halo_env = 0;              // EPIC_HIP_HALO (0 = not given: chosen by slab height in multi_plan)
     Config cfg;                    // every EPIC_HIP_* knob as the environment had it when this context was created (driver_config.h)
+    // Deferred iterations (driver_loop.hip, "harmonic_update_gpu counts"): plain iterations the caller has asked for one call at a
+    // time and that are not enqueued yet -- iterations [pending_first, pending_first + pending).  They are enqueued as ONE block (LDS
+    // tiles, fused pairs, a captured graph: whatever a block of harmonic_execute_gpu takes) when `defer_cap` of them have been
+    // counted and at every ordering point of the boundary (flush_pending).  defer_bypass: whether those blocks run without the
+    // work lists, decided at the latest check (bypass_lists_for_batch reads counters back: not once per block of two iterations).
+    unsigned pending = 0, pending_first = 0, pending_cap = 1;
+    bool defer_bypass = false;
+    // Run-ahead at the check (small grids on the tile path; driver_loop.hip): the caller's thread has to wait for a check's result,
+    // and while it does -- and until its next plain updates have been counted and enqueued -- the device would sit idle, 40 % of a
+    // tick on the reference's maps.  A caller that followed its previous check with plain updates is expected to do so again: the
+    // first block after the check (`count` iterations from iteration `first`, ONE tile launch from the current buffer into
+    // Ctx::spare) is enqueued behind the check before the wait.  When the caller has then counted exactly those iterations the
+    // block is adopted (the buffers change roles, nothing is launched); anything else -- a read-back, an edit, another check, a
+    // renumbered iteration -- discards it: the state the check refers to was never touched.
+    struct Ahead { bool live = false; unsigned first = 0, count = 0; } ahead;
+    unsigned tick_plain = 0;       // plain updates counted since the latest harmonic_update_and_check_gpu
     bool multi() const { return !slabs.empty(); }
     size_t u_bytes() const { return (size_t)rows * pitch * sizeof(float); }
     // 2-D: the lane masks are kept twice in one block -- the standard layout, and behind it the same bits cut for the fused
@@ -281,10 +297,19 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first, bool check_
 hipError_t enqueue_rb_pairs_tracked(Ctx *c, unsigned npairs, unsigned first, bool check_last, bool bypass);
 hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first, bool check_last = false);
 bool tiles_pipeline_ready(Ctx *c);
-int read_tile_delta(Harmonic *h, Ctx *c, const char *fn);
+hipError_t enqueue_ahead(Ctx *c, unsigned first);   // one tile launch of plain iterations from the current buffer into Ctx::spare (Ctx::ahead)
+int read_tile_delta(Harmonic *h, Ctx *c, const char *fn, hipEvent_t after = nullptr);   // after: the event behind the check launch (else: the whole stream)
 int read_delta(Harmonic *h, Ctx *c, const char *fn);
 void force_all(Ctx *c);    // the next two iterations run every tile (after any change of values, masks, mode or tiling)
 bool due_tiles(Ctx *c, unsigned long long *due, unsigned long long *tiles, bool forced_runs_all);
+
+// ---- driver_loop.hip ----------------------------------------------------------------------------------------------------
+// `plain` unchecked iterations from iteration `first` and then -- check -- one check iteration whose max |du| is read back into
+// h->delta, on the kernel family the context's state calls for.  bypass: -1 decide here (reads the list counters back), 0 / 1 given.
+// Does not touch h->currentIteration (the callers count); an EPIC_* code.
+int run_block(Harmonic *h, Ctx *c, unsigned plain, unsigned first, bool check, const char *fn, int bypass, bool run_ahead = false);
+unsigned defer_cap(const Harmonic *h, const Ctx *c);   // deferred iterations that make a block worth enqueueing (1: no deferral)
+int flush_pending(Harmonic *h, Ctx *c, const char *fn);   // c may be null; an EPIC_* code (the failure of a deferred launch surfaces here)
 
 // ---- driver_multi.hip (EPIC_HIP_DEVICES: see that file) -------------------------------------------------------------------
 bool multi_plan(Ctx *c);

@@ -66,6 +66,7 @@ Config Config::from_env()
     e = env("EPIC_HIP_TILE_HALO");
     if (e && atoi(e) > 0) c.tile_halo = atoi(e);
     c.tile_pipeline = !is_zero("EPIC_HIP_TILE_PIPELINE");
+    c.defer = !is_zero("EPIC_HIP_DEFER");
     c.track_pairs = !is_zero("EPIC_HIP_TRACK_PAIRS");
     e = env("EPIC_HIP_TRACK_PAIR_ROWS");
     if (e && atoi(e) > 0) c.track_pair_rows = atoi(e);
@@ -91,19 +92,33 @@ Config Config::from_env()
 
 std::string Config::json() const
 {
+    // EPIC_HIP_DEVICES is the caller's text: clipped and escaped, so that whatever the environment holds this stays one JSON object
+    std::string dev;
+    for (char ch : devices_text.substr(0, 256)) {
+        if (ch == '"' || ch == '\\') { dev += '\\'; dev += ch; }
+        else if ((unsigned char)ch < 0x20) dev += ' ';
+        else dev += ch;
+    }
     char t[1536];
+    std::string out = "{";
+    snprintf(t, sizeof t, "\"math\": %d, \"scheme\": \"%s\", \"track_mode\": %d, \"rows_per_task\": %d, \"devices\": \"", math,
+             redblack ? "redblack" : "jacobi", track_mode, rows_per_task);
+    out += t;
+    out += dev;
     snprintf(t, sizeof t,
-             "{\"math\": %d, \"scheme\": \"%s\", \"track_mode\": %d, \"rows_per_task\": %d, \"devices\": \"%s\", \"halo\": %d, \"no_peer\": %s, "
+             "\", \"halo\": %d, \"no_peer\": %s, "
              "\"threads\": %s, \"spin_us\": %d, \"no_fuse\": %s, \"no_graph\": %s, \"fuse_min_cells\": %lld, \"fused_rows\": %d, \"tune\": %s, "
-             "\"tile\": %s, \"tile_max_cells\": %lld, \"tile_rows\": %d, \"tile_width\": %d, \"tile_halo\": %d, \"tile_pipeline\": %s, "
+             "\"tile\": %s, \"tile_max_cells\": %lld, \"tile_rows\": %d, \"tile_width\": %d, \"tile_halo\": %d, \"tile_pipeline\": %s, \"defer\": %s, "
              "\"track_pairs\": %s, \"track_pair_rows\": %d, \"track_switch\": %g, \"tol_finish\": %d, \"tol_finish_factor\": %g, "
              "\"flags\": %d, \"list_waves\": %zu, \"pair3d\": %s, \"pair3d_rows\": %d, \"march_x0\": %s}",
-             math, redblack ? "redblack" : "jacobi", track_mode, rows_per_task, devices_text.c_str(), halo, no_peer ? "true" : "false",
+             halo, no_peer ? "true" : "false",
              threads ? "true" : "false", spin_us, no_fuse ? "true" : "false", no_graph ? "true" : "false", fuse_min_cells, fused_rows,
              tune ? "true" : "false", tile ? "true" : "false", tile_max_cells, tile_rows, tile_width, tile_halo, tile_pipeline ? "true" : "false",
+             defer ? "true" : "false",
              track_pairs ? "true" : "false", track_pair_rows, track_switch, tol_finish, (double)tol_finish_factor, launch.flags, launch.list_waves,
              launch.pair3d ? "true" : "false", launch.pair3d_rows, launch.march_x0 ? "true" : "false");
-    return t;
+    out += t;
+    return out;
 }
 
 namespace {

@@ -53,6 +53,7 @@ struct Config {
     long long tile_max_cells = 3ll << 20;   // EPIC_HIP_TILE_MAX_CELLS
     int tile_rows = 0, tile_width = 0, tile_halo = 0;   // EPIC_HIP_TILE_ROWS / _WIDTH / _HALO (0: the cost model)
     bool tile_pipeline = true;       // EPIC_HIP_TILE_PIPELINE=0
+    bool defer = true;               // EPIC_HIP_DEFER=0: harmonic_update_gpu launches one single iteration per call (as before round 6) instead of counting
     bool track_pairs = true;         // EPIC_HIP_TRACK_PAIRS=0
     int track_pair_rows = 0;         // EPIC_HIP_TRACK_PAIR_ROWS (0: 16, then 4 in the tail)
     double track_switch = -1.0;      // EPIC_HIP_TRACK_SWITCH (< 0: by configuration)

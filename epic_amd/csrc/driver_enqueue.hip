@@ -200,6 +200,7 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first, bool chec
     // (the fused-pass switches are read per batch -- EPIC_HIP_NO_FUSE, EPIC_HIP_FUSE_MIN_CELLS, EPIC_HIP_FUSED_ROWS --, so they
     // belong to the key: 0 = single sweeps, otherwise the task height of the pass)
     const epic_hip::TilePlan tp = tile_plan(c);
+    if (tp.halo > 0 && count + (check_last ? 1u : 0u) <= (unsigned)tp.halo) return enqueue_plain_run(c, count, first, check_last);   // one launch: nothing to replay
     const int fuse_cfg = tp.halo > 0 ? -((tp.halo * 1024 + tp.tile_rows) * 4 + tp.tile_cols / 64) : fuses_tol(c) ? jacobi_fused_rows_per_task(c) : 0;
     const auto key = std::make_tuple(2u * count + (check_last ? 1u : 0u), c->cur + 2 * (c->track ? 1 + c->trk.phase : 0), (int)(first & 1u), c->math,
                                      (int)c->redblack, auto_rows_per_task(c), fuse_cfg);
@@ -273,11 +274,38 @@ bool tiles_pipeline_ready(Ctx *c)
     return true;
 }
 
-// max |du| of a check iteration that ran as the last step of a tile launch (enqueue_plain_run, check_last): wait for the
-// stream, take the maximum over the tiles' words in pinned memory
-int read_tile_delta(Harmonic *h, Ctx *c, const char *fn)
+// Run-ahead at a check (Ctx::ahead): the first block of plain iterations after the check that has just been enqueued, as ONE tile
+// launch from the current buffer into the spare one.  Nothing of the context's state changes until the block is adopted.
+hipError_t enqueue_ahead(Ctx *c, unsigned first)
 {
-    if (hipStreamSynchronize(c->stream) != hipSuccess) {
+    c->ahead.live = false;
+    const epic_hip::TilePlan tp = tile_plan(c);
+    if (tp.halo <= 0 || !c->spare) return hipErrorInvalidValue;
+    hipError_t e = epic_hip::launch_tile_2d(c->buf[c->cur], c->spare, c->maskw, c->rows, c->pitch, tp, tp.halo, c->math,
+                                            c->redblack ? (int)(first & 1u) : -1, nullptr, c->stream, nullptr);
+    if (e != hipSuccess) return e;
+    c->ahead.live = true;
+    c->ahead.first = first;
+    c->ahead.count = (unsigned)tp.halo;
+    return hipSuccess;
+}
+
+// max |du| of a check iteration that ran as the last step of a tile launch (enqueue_plain_run, check_last): wait for the
+// stream -- or, with `after`, for that event only (work enqueued behind the check is not waited for) --, take the maximum over the
+// tiles' words in pinned memory.  The wait for an event polls for a bounded while first: the blocks in question run for ~10 us, an
+// interrupt-driven wake-up alone takes longer than that.
+int read_tile_delta(Harmonic *h, Ctx *c, const char *fn, hipEvent_t after)
+{
+    hipError_t e = hipSuccess;
+    if (after) {
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
+        do e = hipEventQuery(after);
+        while (e == hipErrorNotReady && std::chrono::steady_clock::now() < until);
+        if (e == hipErrorNotReady) { (void)hipGetLastError(); e = hipEventSynchronize(after); }
+    } else {
+        e = hipStreamSynchronize(c->stream);
+    }
+    if (e != hipSuccess) {
         report(fn, "Failed to synchronize the device after the 'update and check' kernel.");
         return EPIC_ERROR_DEVICE_SYNCHRONIZE;
     }

@@ -27,22 +27,16 @@ int epic_hip_update_n_gpu(Harmonic *harmonic, unsigned int sweeps, int check_las
         report(fn, "Invalid data.");
         return EPIC_ERROR_INVALID_DATA;
     }
-    const unsigned plain = sweeps - ((check_last && sweeps > 0) ? 1u : 0u);
-    const bool tiled_check = plain < sweeps && plain > 0 && tile_checks(c, tile_plan(c));   // the check rides the last tile launch
-    if (enqueue_plain_batch(c, plain, harmonic->currentIteration, tiled_check) != hipSuccess ||
-        (plain < sweeps && !tiled_check && enqueue_sweep(c, true, harmonic->currentIteration + plain) != hipSuccess)) {
-        report(fn, "Failed to execute the 'Jacobi update' kernel.");
-        return EPIC_ERROR_KERNEL_EXECUTION;
-    }
-    harmonic->currentIteration += plain;
-    harmonic->d_u = current_u(c);
-    if (check_last && sweeps > 0) {
-        int rc = tiled_check ? read_tile_delta(harmonic, c, fn) : read_delta(harmonic, c, fn);
-        if (rc != EPIC_SUCCESS) return rc;
-        harmonic->currentIteration++;
-        return harmonic->delta < harmonic->epsilon ? EPIC_SUCCESS_AND_CONVERGED : EPIC_SUCCESS;
-    }
-    return EPIC_SUCCESS;
+    if (const int frc = flush_pending(harmonic, c, fn)) return frc;
+    if (sweeps == 0) return EPIC_SUCCESS;
+    // one block of harmonic_execute_gpu's loop (driver_loop.hip: run_block -- tiles with the check folded in, tracked pairs, fused
+    // passes, a captured graph), decided from the context's state as that loop decides it
+    const bool check = check_last != 0;
+    const unsigned plain = sweeps - (check ? 1u : 0u);
+    const int rc = run_block(harmonic, c, plain, harmonic->currentIteration, check, fn, -1);
+    if (rc != EPIC_SUCCESS) return rc;
+    harmonic->currentIteration += sweeps;
+    return check && harmonic->delta < harmonic->epsilon ? EPIC_SUCCESS_AND_CONVERGED : EPIC_SUCCESS;
 }
 
 int epic_hip_timed_sweeps_gpu(Harmonic *harmonic, unsigned int sweeps, unsigned int check_every, float *elapsed_ms)
@@ -53,6 +47,7 @@ int epic_hip_timed_sweeps_gpu(Harmonic *harmonic, unsigned int sweeps, unsigned 
         report(fn, "Invalid data.");
         return EPIC_ERROR_INVALID_DATA;
     }
+    if (const int frc = flush_pending(harmonic, c, fn)) return frc;
     if (c->multi()) {
         // several devices: no single stream sees the whole batch, so the batch is bracketed by host clocks around
         // "every stream of every slab idle" (the batches this is used for run for milliseconds to seconds)
@@ -152,6 +147,7 @@ int epic_hip_set_rows_per_task(Harmonic *harmonic, unsigned int rows_per_task)
 {
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
     if (!c || rows_per_task > 65536) return EPIC_ERROR_INVALID_DATA;
+    if (const int frc = flush_pending(harmonic, c, "epic_hip_set_rows_per_task")) return frc;
     c->rows_per_task = (int)rows_per_task;
     c->tuned_rows[0] = c->tuned_rows[1] = c->tuned_rows[2] = 0;   // back to "not measured": a height of 0 here means automatic again
     force_all(c);
@@ -162,6 +158,7 @@ int epic_hip_set_math_mode(Harmonic *harmonic, int mode)
 {
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
     if (!c || mode < 0 || mode > 4 || mode == 3) return EPIC_ERROR_INVALID_DATA;  // 2 = traffic-only diagnostic (2-D), 4 = tol; 3 was round 1's df32
+    if (const int frc = flush_pending(harmonic, c, "epic_hip_set_math_mode")) return frc;   // iterations counted so far run in the mode they were asked for in
     if (c->math != mode) c->tuned_rows[0] = c->tuned_rows[1] = c->tuned_rows[2] = 0;   // (kind 2 serves precise and fast: measured per arithmetic)
     c->math = mode;
     force_all(c);
@@ -172,6 +169,7 @@ int epic_hip_set_scheme(Harmonic *harmonic, int scheme)
 {
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
     if (!c || (scheme != 0 && scheme != 1)) return EPIC_ERROR_INVALID_DATA;
+    if (const int frc = flush_pending(harmonic, c, "epic_hip_set_scheme")) return frc;
     c->redblack = scheme == 1;
     force_all(c);
     return EPIC_SUCCESS;
@@ -181,6 +179,7 @@ int epic_hip_set_activity_tracking(Harmonic *harmonic, int on)
 {
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
     if (!c || on < 0 || on > 2) return EPIC_ERROR_INVALID_DATA;
+    if (const int frc = flush_pending(harmonic, c, "epic_hip_set_activity_tracking")) return frc;
     c->track_mode = on;
     resolve_tracking(c);
     force_all(c);
@@ -202,6 +201,7 @@ int epic_hip_compute_paths_2d_gpu(Harmonic *harmonic, unsigned int n_paths, cons
         report(fn, "Invalid data (not available in multi-device mode: use harmonic_get_potential_values_gpu and the CPU walk).");
         return EPIC_ERROR_INVALID_DATA;
     }
+    if (const int frc = flush_pending(harmonic, c, fn)) return frc;   // the walk reads the field of every iteration asked for
     // the host walk stops at size() < 2u * maxLength values (unsigned product, harmonic_path_cpu.cpp:185)
     const unsigned max_points = (2u * maxLength) / 2u;
     const size_t row = 2 * (size_t)max_points;
@@ -282,6 +282,7 @@ int epic_hip_activity_stats2(Harmonic *harmonic, unsigned long long *active_tile
 {
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
     if (!c || !active_tiles || !tiles) return EPIC_ERROR_INVALID_DATA;
+    if (const int frc = flush_pending(harmonic, c, "epic_hip_activity_stats")) return frc;
     *active_tiles = *tiles = 0;
     if (due_tiles) *due_tiles = 0;
     if (!c->track) return EPIC_SUCCESS;
@@ -300,6 +301,7 @@ int epic_hip_work_done(Harmonic *harmonic, double *grid_iterations, int reset)
 {
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
     if (!c || !grid_iterations) return EPIC_ERROR_INVALID_DATA;
+    if (const int frc = flush_pending(harmonic, c, "epic_hip_work_done")) return frc;
     if (c->multi()) { DeviceGuard g; multi_sync(c); }
     fold_listed_work(c);
     *grid_iterations = c->work_full;
@@ -347,6 +349,7 @@ int epic_hip_multi_report(Harmonic *harmonic, char *buf, size_t cap)
 {
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
     if (!c || !buf || cap < 64 || !c->multi() || !ready(harmonic, c)) return 0;
+    if (flush_pending(harmonic, c, "epic_hip_multi_report") != EPIC_SUCCESS) return 0;   // (the probe below runs an iteration of its own)
     std::string out = "{";
     auto add = [&](const char *fmt, auto... a) { char t[256]; snprintf(t, sizeof t, fmt, a...); out += t; };
     add("\"slabs\": %d, \"halo\": %d, \"issuing_threads\": %s, \"seams\": [", (int)c->slabs.size(), c->halo,
@@ -566,8 +569,9 @@ int epic_hip_config_dump(Harmonic *harmonic, char *buf, size_t cap)
 }
 
 // Re-reads the environment: for this Harmonic's context (its Config and the mode fields derived from it -- math, scheme, tracking,
-// task height; the device list only takes effect at the next initialisation of the dimensions), or, with NULL, the process-wide
-// knobs the raw operators go by.  The library reads the environment ONCE per context; a caller (a test, bench.py) that changes
+// task height; the device list and halo depth are taken over when no field or mask is resident, i.e. they shape the NEXT
+// initialisation) AND the process-wide knobs; with NULL, the process-wide knobs only (what the raw operators and the 2-D launchers'
+// EPIC_HIP_FLAGS / EPIC_HIP_LIST_WAVES go by).  The library reads the environment ONCE per context; a caller (a test, bench.py) that changes
 // a variable on a live context says so with this call.
 int epic_hip_config_reload(Harmonic *harmonic)
 {
@@ -577,6 +581,7 @@ int epic_hip_config_reload(Harmonic *harmonic)
     }
     Ctx *c = find_ctx(harmonic);
     if (!c) return EPIC_ERROR_INVALID_DATA;
+    if (const int frc = flush_pending(harmonic, c, "epic_hip_config_reload")) return frc;   // iterations counted so far run under the knobs they were asked for under
     const Config before = c->cfg;
     c->cfg = Config::from_env();
     // a mode set through epic_hip_set_* stays unless ITS variable changed
@@ -585,7 +590,19 @@ int epic_hip_config_reload(Harmonic *harmonic)
     if (c->cfg.track_mode != before.track_mode) c->track_mode = c->cfg.track_mode;
     if (c->cfg.rows_per_task != before.rows_per_task) { c->rows_per_task = c->cfg.rows_per_task; c->tuned_rows[0] = c->tuned_rows[1] = c->tuned_rows[2] = 0; }
     if (c->cfg.fused_rows != before.fused_rows) c->tuned_rows[0] = c->tuned_rows[1] = c->tuned_rows[2] = 0;
-    // (the device list, the halo depth and the transport belong to the slab layout: in force until the dimensions are initialised again)
+    // The device list, the halo depth and the transport belong to the slab layout: they are taken over now if no field or mask is
+    // resident (the next initialisation lays the slabs out from them), otherwise the layout in force stays until the caller has
+    // uninitialised both and initialises again (config_dump shows the layout in force under "state").
+    if (!c->buf[0] && !c->maskw && !multi_holds_anything(c)) {
+        const int math = c->math, track_mode = c->track_mode, rpt = c->rows_per_task;
+        const bool rb = c->redblack;
+        if (c->multi()) multi_destroy(c);
+        apply_config(c);   // devices (validated) and halo; the mode fields are put back: only a variable that CHANGED moves them (above)
+        c->math = math; c->track_mode = track_mode; c->rows_per_task = rpt; c->redblack = rb;
+    }
+    // EPIC_HIP_FLAGS and EPIC_HIP_LIST_WAVES are read by the 2-D launchers from the process-wide knobs (kernels_2d.hip: speed only,
+    // never results): a reload on behalf of one context refreshes those too, so that what config_dump prints is what the launches use
+    reload_process_config();
     if (c->pitch > 0) resolve_tracking(c);
     drop_graphs(c);           // captured sequences were made under the old knobs
     force_all(c);

@@ -5,6 +5,131 @@
 
 using namespace epic_drv;
 
+namespace epic_drv {
+
+// ---------------------------------------------------------------------------------------------------------
+// One block of iterations on the kernel family the context's state calls for -- the ONE place that picks it, for
+// harmonic_execute_gpu's loop, for the deferred iterations of harmonic_update_gpu and for epic_hip_update_n_gpu alike:
+//   * several devices: the slabs' stretches between exchanges (multi_run), the check as a sweep of its own;
+//   * large 2-D grids with work lists (the library's defaults at the benchmark's size): pairs of iterations as list-driven fused
+//     passes, the check as the second iteration of the last pair (an odd count starts with one plain half-sweep);
+//   * small 2-D grids: several iterations per launch on LDS tiles, the check folded into the last launch;
+//   * everything else: enqueue_plain_batch (fused pairs without lists, a captured graph of single sweeps, single sweeps) and the
+//     check as a sweep of its own.
+// Same iterations in the same order whichever it takes: the fields are bit-identical (tests/test_gpu_node_flow.py).
+// ---------------------------------------------------------------------------------------------------------
+int run_block(Harmonic *h, Ctx *c, unsigned plain, unsigned first, bool check, const char *fn, int bypass, bool run_ahead)
+{
+    if (plain == 0 && !check) return EPIC_SUCCESS;
+    hipError_t e = hipSuccess;
+    bool tiled_check = false;
+    hipEvent_t after_check = nullptr;   // run_ahead: the event between the check's launch and the block enqueued ahead of the caller
+    const unsigned total = plain + (check ? 1u : 0u);
+    if (c->n == 4) {
+        // the reference's empty n == 4 branch: nothing is swept, the caller counts
+    } else if (c->multi()) {
+        if (plain > 0) e = multi_run(c, plain, first, false);
+        if (e == hipSuccess && check) e = multi_sweep(c, true, first + plain);
+    } else if (total >= 2 && rb_pairs_tracked(c) && (!check || has_delta(c))) {
+        unsigned done = 0;
+        if (total & 1u) {
+            e = enqueue_sweep(c, false, first);
+            done = 1;
+        }
+        if (e == hipSuccess) {
+            // (the task height of the tracked pass is reconsidered where a check has just been read or is about to be: it reads the
+            //  list counters back, which a block of two deferred iterations cannot afford)
+            if (bypass < 0 || check) rb_pairs_choose_rows(c);
+            else if (c->pair_rows == 0) c->pair_rows = 16;
+            const bool by = bypass < 0 ? bypass_lists_for_batch(c, true) : bypass != 0;
+            if (by) tune_fused_rows(c, c->math != 4 ? 2 : c->redblack ? 1 : 0, first);   // the untracked pass's task height, measured once per grid
+            e = enqueue_rb_pairs_tracked(c, (total - done) / 2, first + done, check, by);
+        }
+    } else if (check && plain > 0 && tile_checks(c, tile_plan(c))) {
+        e = enqueue_plain_batch(c, plain, first, true);
+        tiled_check = true;
+        // Run-ahead (Ctx::ahead): the caller's next block behind the check, before the wait for the check's result.  An optimisation:
+        // whatever fails in it is cleared and the check goes on as without it.
+        if (e == hipSuccess && run_ahead && tiles_pipeline_ready(c)) {
+            if (hipEventRecord(c->ev_blk[0], c->stream) == hipSuccess) {
+                after_check = c->ev_blk[0];
+                if (enqueue_ahead(c, first + total) != hipSuccess) (void)hipGetLastError();
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+    } else {
+        if (plain > 0) {
+            // Work lists pay while a good part of the tiles is at rest; in the phase in which nearly every tile is due (the
+            // middle third of a relaxation from scratch) a list-driven sweep costs more than the plain one -- 12 us + 115 us
+            // x share against 97 us per iteration of the fused pass at 8192^2, tol math.  The check that has just completed
+            // counted the tiles due next: above the switch share this batch runs without lists, and the next two
+            // iterations rebuild them (force = 2, as after an upload).  2-D, one device, tracking in its automatic mode;
+            // measured on 8192^2 with every arithmetic and scheme (seconds to eps = 1e-6, never / 0.8): tol Jacobi 2.91 / 2.75,
+            // tol red-black 2.62 / 2.52, precise Jacobi 3.78 / 3.69, precise red-black 3.01 / 2.62.  Fields and iteration
+            // counts do not depend on it.
+            const bool by = bypass < 0 ? bypass_lists_for_batch(c) : (bypass != 0 && c->track);
+            if (by) c->track = false;
+            e = enqueue_plain_batch(c, plain, first);
+            if (by) { c->track = true; force_all(c); }
+        }
+        if (e == hipSuccess && check) e = enqueue_sweep(c, true, first + plain);
+    }
+    if (e != hipSuccess) {
+        report(fn, check && plain == 0 ? "Failed to execute the 'Jacobi update and check' kernel." : "Failed to execute the 'Jacobi update' kernel.");
+        return EPIC_ERROR_KERNEL_EXECUTION;
+    }
+    h->d_u = current_u(c);
+    if (!check) return EPIC_SUCCESS;
+    return tiled_check ? read_tile_delta(h, c, fn, after_check) : read_delta(h, c, fn);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// harmonic_update_gpu counts (round 6).  The navigation node drives the solver one call per iteration -- one
+// harmonic_update_and_check_gpu and steps_per_update - 1 harmonic_update_gpu calls per tick
+// (src/epic_navigation_node_harmonic.cpp:165-189; 50 / 100 steps at 10 / 30 Hz) -- and one launch per call would keep it away from
+// every kernel that advances more than one iteration per pass (the LDS tiles of the maps it really runs on: 10 iterations per
+// launch; the fused pairs of large grids).  So a plain update only COUNTS: currentIteration advances, the iteration joins the
+// pending run, and the run is enqueued as ONE block when it has reached the size the kernel family in use is built for
+// (defer_cap) and at every point of the boundary at which the caller can see the field or change what the iterations act on:
+// harmonic_update_and_check_gpu (the pending run and the check are one block), get_potential_values, update_model, set_cells,
+// execute / complete, (un)initialize_*, every epic_hip_* entry point that reads or changes the context (flush_pending).  At most
+// cap - 1 iterations are ever outstanding, so the device is never more than one launch behind the caller.  A launch that fails
+// surfaces at the call that enqueues it, with the code the reference gives a failed update (EPIC_ERROR_KERNEL_EXECUTION).
+// The reference's own update returns after cudaDeviceSynchronize (harmonic_gpu.cu:343-346); none of its callers reads d_u
+// itself (they all go through harmonic_get_potential_values_gpu), and d_u has never been directly readable here (pitched rows,
+// a private stream).  EPIC_HIP_DEFER=0: one launch per call, as before.
+// ---------------------------------------------------------------------------------------------------------
+unsigned defer_cap(const Harmonic *h, const Ctx *c)
+{
+    if (!c->cfg.defer || c->n == 4) return 1;
+    unsigned cap = 1;
+    if (c->multi()) cap = (unsigned)std::max(1, c->halo);                 // a stretch between two exchanges: one hand-over to the issuing threads
+    else if (rb_pairs_tracked(c)) cap = 2;                               // list-driven fused pairs
+    else {
+        const epic_hip::TilePlan tp = tile_plan(c);
+        if (tp.halo > 0) cap = (unsigned)tp.halo;                        // LDS tiles: iterations per launch
+        else if (fuses_jacobi(c) || fuses_rb_tol(c) || fuses_rb_precise(c)) cap = 2;   // fused pairs without lists
+        else if (c->n == 2 && (long long)c->rows * c->pitch <= (1ll << 22) && !c->cfg.no_graph && !c->graphs_broken && !c->track) cap = 16;   // launch-bound single sweeps: a captured graph
+    }
+    // never past the caller's own checking period: a block that long would be two of the solver loop's
+    const unsigned stagger = h->numIterationsToStaggerCheck ? h->numIterationsToStaggerCheck : 100u;
+    return std::max(1u, std::min(cap, stagger));
+}
+
+int flush_pending(Harmonic *h, Ctx *c, const char *fn)
+{
+    if (!c) return EPIC_SUCCESS;
+    c->ahead.live = false;   // an ordering point: whatever was enqueued ahead of the caller is not what the caller did next
+    if (c->pending == 0) return EPIC_SUCCESS;
+    const unsigned n = c->pending, first = c->pending_first;
+    c->pending = 0;
+    if (!h || !ready(h, c)) return EPIC_SUCCESS;   // part of the device state is gone already (the caller is tearing it down): nothing to advance
+    return run_block(h, c, n, first, false, fn, c->defer_bypass ? 1 : 0);
+}
+
+}  // namespace epic_drv
+
 namespace epic {
 extern "C" {
 
@@ -21,33 +146,74 @@ int harmonic_update_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmoni
         report(fn, "Invalid data.");
         return EPIC_ERROR_INVALID_DATA;
     }
-    if (enqueue_sweep(c, false, harmonic->currentIteration) != hipSuccess) {
-        report(fn, "Failed to execute the 'Jacobi update' kernel.");
-        return EPIC_ERROR_KERNEL_EXECUTION;
+    // (a caller that has set currentIteration itself since the last call starts a new run: the colour of a red-black iteration is its number's parity)
+    if (c->pending > 0 && c->pending_first + c->pending != harmonic->currentIteration) {
+        const int rc = flush_pending(harmonic, c, fn);
+        if (rc != EPIC_SUCCESS) return rc;
     }
-    harmonic->d_u = current_u(c);
+    if (c->pending == 0) {
+        c->pending_first = harmonic->currentIteration;
+        c->pending_cap = defer_cap(harmonic, c);   // (nothing the cap depends on changes while iterations are pending: every such change flushes)
+    }
+    c->pending++;
+    c->tick_plain++;
     harmonic->currentIteration++;
+    if (c->ahead.live) {
+        if (c->pending_first != c->ahead.first) {
+            c->ahead.live = false;   // the caller went elsewhere
+        } else if (c->pending == c->ahead.count) {
+            // exactly the block that was enqueued behind the latest check: its result becomes the current buffer, nothing is launched
+            std::swap(c->spare, c->buf[c->cur]);
+            drop_graphs(c);          // (captured sequences hold buffer addresses)
+            c->work_full += (double)c->ahead.count;
+            c->ahead.live = false;
+            c->pending = 0;
+            harmonic->d_u = current_u(c);
+            return EPIC_SUCCESS;
+        } else {
+            return EPIC_SUCCESS;     // still inside that block
+        }
+    }
+    if (c->pending >= c->pending_cap) return flush_pending(harmonic, c, fn);
     return EPIC_SUCCESS;
 }
 
-int harmonic_update_and_check_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmonic_gpu.cu:353-415
+// decide: also settle whether the deferred blocks up to the next check run with or without the work lists (one read-back of the
+// list counters, tracked 2-D grids only); harmonic_execute_gpu's own loop decides per block and passes false.
+static int update_and_check(Harmonic *harmonic, bool decide)
 {
     static const char *fn = "harmonic_update_and_check_gpu";
-    (void)numThreads;
     Ctx *c = harmonic ? find_ctx(harmonic) : nullptr;
     if (!harmonic || !ready(harmonic, c) || !has_delta(c) || harmonic->d_delta == nullptr) {
         report(fn, "Invalid data.");
         return EPIC_ERROR_INVALID_DATA;
     }
-    if (enqueue_sweep(c, true, harmonic->currentIteration) != hipSuccess) {
-        report(fn, "Failed to execute the 'Jacobi update and check' kernel.");
-        return EPIC_ERROR_KERNEL_EXECUTION;
+    // Run-ahead: a caller that followed its previous check with at least one block of plain updates (the navigation node's tick) is
+    // expected to do so again; harmonic_execute_gpu's own loop (decide == false) pipelines whole blocks itself.
+    const bool run_ahead = decide && c->cfg.defer && c->pending_cap > 1 && c->tick_plain >= c->pending_cap;
+    c->tick_plain = 0;
+    c->ahead.live = false;
+    // the pending run and this check are one block -- unless the caller has moved currentIteration in between
+    unsigned plain = 0, first = harmonic->currentIteration;
+    if (c->pending > 0 && c->pending_first + c->pending == harmonic->currentIteration) {
+        plain = c->pending;
+        first = c->pending_first;
+        c->pending = 0;
+    } else if (c->pending > 0) {
+        const int rc = flush_pending(harmonic, c, fn);
+        if (rc != EPIC_SUCCESS) return rc;
     }
-    harmonic->d_u = current_u(c);
-    int rc = read_delta(harmonic, c, fn);
+    const int rc = run_block(harmonic, c, plain, first, true, fn, c->defer_bypass ? 1 : 0, run_ahead);
     if (rc != EPIC_SUCCESS) return rc;
     harmonic->currentIteration++;
+    if (decide) c->defer_bypass = c->cfg.defer && bypass_lists_for_batch(c, rb_pairs_tracked(c));
     return harmonic->delta < harmonic->epsilon ? EPIC_SUCCESS_AND_CONVERGED : EPIC_SUCCESS;
+}
+
+int harmonic_update_and_check_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmonic_gpu.cu:353-415
+{
+    (void)numThreads;
+    return update_and_check(harmonic, true);
 }
 
 int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmonic_gpu.cu:226-304
@@ -75,6 +241,10 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
     if (c->n == 4) {   // no sweep ever changes delta: the reference's loop (harmonic_gpu.cu:266-290) would never return
         report(fn, "Invalid data (n = 4 is a counting no-op: there is nothing to relax).");
         return EPIC_ERROR_INVALID_DATA;
+    }
+    {
+        const int frc = flush_pending(harmonic, c, fn);   // iterations counted by harmonic_update_gpu: the relaxation starts from their field
+        if (frc != EPIC_SUCCESS) return frc;
     }
 
     harmonic->currentIteration = 0;
@@ -189,7 +359,7 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
     };
     while (result != EPIC_SUCCESS_AND_CONVERGED || harmonic->currentIteration < mMax) {
         if (harmonic->currentIteration % stagger == 0) {
-            result = harmonic_update_and_check_gpu(harmonic, numThreads);
+            result = update_and_check(harmonic, false);
             if (result != EPIC_SUCCESS && result != EPIC_SUCCESS_AND_CONVERGED) {
                 report(fn, "Failed to perform the Jacobi update and check step.");
                 return result;
@@ -200,28 +370,9 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
             // iterations up to the next check AND that check as PAIRS, each one list-driven fused pass; the check is the second
             // iteration of the last pair (an odd count starts with one plain half-sweep).  Same iterations, same order, same bits.
             const unsigned batch = stagger - harmonic->currentIteration % stagger;
-            const unsigned total = batch + 1;
-            unsigned done = 0;
-            hipError_t pe = hipSuccess;
-            if (total & 1u) {
-                pe = enqueue_sweep(c, false, harmonic->currentIteration);
-                done = 1;
-            }
-            if (pe == hipSuccess) {
-                rb_pairs_choose_rows(c);
-                const bool bypass = bypass_lists_for_batch(c, true);
-                if (bypass) tune_fused_rows(c, c->math != 4 ? 2 : c->redblack ? 1 : 0, harmonic->currentIteration);   // the untracked pass's task height, measured once per grid
-                pe = enqueue_rb_pairs_tracked(c, (total - done) / 2, harmonic->currentIteration + done, true, bypass);
-            }
-            if (pe != hipSuccess) {
-                report(fn, "Failed to perform the Jacobi update step.");
-                return EPIC_ERROR_KERNEL_EXECUTION;
-            }
-            harmonic->d_u = current_u(c);
-            harmonic->currentIteration += batch;
-            result = read_delta(harmonic, c, fn);
+            result = run_block(harmonic, c, batch, harmonic->currentIteration, true, fn, -1);
             if (result != EPIC_SUCCESS) return result;
-            harmonic->currentIteration++;
+            harmonic->currentIteration += batch + 1;
             result = harmonic->delta < harmonic->epsilon ? EPIC_SUCCESS_AND_CONVERGED : EPIC_SUCCESS;
             after_check();
         } else if (tile_checks(c, tile_plan(c)) && tiles_pipeline_ready(c)) {
@@ -312,38 +463,17 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
             // launches (one captured graph); the check is the last step of the last launch and leaves its max |du| per tile in
             // pinned memory.  Same iterations in the same order as the branches above and below run them.
             const unsigned batch = stagger - harmonic->currentIteration % stagger;
-            if (enqueue_plain_batch(c, batch, harmonic->currentIteration, true) != hipSuccess) {
-                report(fn, "Failed to perform the Jacobi update step.");
-                return EPIC_ERROR_KERNEL_EXECUTION;
-            }
-            harmonic->d_u = current_u(c);
-            harmonic->currentIteration += batch;
-            result = read_tile_delta(harmonic, c, fn);
+            result = run_block(harmonic, c, batch, harmonic->currentIteration, true, fn, -1);
             if (result != EPIC_SUCCESS) return result;
-            harmonic->currentIteration++;
+            harmonic->currentIteration += batch + 1;
             result = harmonic->delta < harmonic->epsilon ? EPIC_SUCCESS_AND_CONVERGED : EPIC_SUCCESS;
             after_check();
         } else {
             // every plain iteration returns SUCCESS (which clears a previous CONVERGED), so the ones up to the next
-            // check need no host decision in between: enqueue them as one batch
+            // check need no host decision in between: enqueue them as one batch (with or without the work lists: run_block)
             const unsigned batch = stagger - harmonic->currentIteration % stagger;
-            // Work lists pay while a good part of the tiles is at rest; in the phase in which nearly every tile is due (the
-            // middle third of a relaxation from scratch) a list-driven sweep costs more than the plain one -- 12 us + 115 us
-            // x share against 97 us per iteration of the fused pass at 8192^2, tol math.  The check that has just completed
-            // counted the tiles due next: above the switch share this batch runs without lists, and the next two
-            // iterations rebuild them (force = 2, as after an upload).  2-D, one device, tracking in its automatic mode;
-            // measured on 8192^2 with every arithmetic and scheme (seconds to eps = 1e-6, never / 0.8): tol Jacobi 2.91 / 2.75,
-            // tol red-black 2.62 / 2.52, precise Jacobi 3.78 / 3.69, precise red-black 3.01 / 2.62.  Fields and iteration
-            // counts do not depend on it.
-            const bool bypass = bypass_lists_for_batch(c);
-            if (bypass) c->track = false;
-            const hipError_t be = enqueue_plain_batch(c, batch, harmonic->currentIteration);
-            if (bypass) { c->track = true; force_all(c); }
-            if (be != hipSuccess) {
-                report(fn, "Failed to perform the Jacobi update step.");
-                return EPIC_ERROR_KERNEL_EXECUTION;
-            }
-            harmonic->d_u = current_u(c);
+            result = run_block(harmonic, c, batch, harmonic->currentIteration, false, fn, -1);
+            if (result != EPIC_SUCCESS) return result;
             harmonic->currentIteration += batch;
             result = EPIC_SUCCESS;
         }
@@ -399,6 +529,10 @@ int harmonic_utilities_set_cells_2d_gpu(Harmonic *harmonic, unsigned int numThre
     if (!ready(harmonic, c) || c->n != 2) {
         report(fn, "Invalid data.");
         return EPIC_ERROR_INVALID_DATA;
+    }
+    {
+        const int frc = flush_pending(harmonic, c, fn);   // the iterations counted so far act on the cells as they were
+        if (frc != EPIC_SUCCESS) return frc;
     }
     if (c->multi()) return multi_set_cells(c, k, v, types, fn);
     unsigned *d_v = nullptr, *d_types = nullptr;

@@ -84,6 +84,15 @@ Ctx *get_ctx(Harmonic *h, bool create)
             if (c->d_m) (void)hipFree(c->d_m);
             if (c->d_delta) (void)hipFree(c->d_delta);
             c->maskw = nullptr; c->d_m = nullptr; c->d_delta = nullptr;
+            // logically a NEW context: nothing pending, the environment read again, nothing measured
+            c->pending = 0;
+            c->ahead.live = false;
+            c->tick_plain = 0;
+            c->defer_bypass = false;
+            c->cfg = Config::from_env();
+            apply_config(c);
+            c->tuned_rows[0] = c->tuned_rows[1] = c->tuned_rows[2] = c->pair_rows = 0;
+            c->graphs_broken = false;
         }
         return c;
     }
@@ -237,6 +246,10 @@ int harmonic_initialize_dimension_size_gpu(Harmonic *harmonic)  // harmonic_mode
         report(fn, "Failed to allocate device-side memory for the dimension size.");
         return EPIC_ERROR_DEVICE_MALLOC;
     }
+    {
+        const int frc = flush_pending(harmonic, c, fn);   // (iterations counted by harmonic_update_gpu: driver_loop.hip)
+        if (frc != EPIC_SUCCESS) return frc;
+    }
     if (c->d_m) { (void)hipFree(c->d_m); c->d_m = nullptr; }  // re-initialise without uninitialise (harmonic.py:67-71 then harmonic_gpu.cu:172)
     if (hipMalloc((void **)&c->d_m, harmonic->n * sizeof(unsigned)) != hipSuccess) {
         (void)hipGetLastError();
@@ -259,8 +272,8 @@ int harmonic_initialize_dimension_size_gpu(Harmonic *harmonic)  // harmonic_mode
 int harmonic_uninitialize_dimension_size_gpu(Harmonic *harmonic)  // harmonic_model_gpu.cu:62-75
 {
     if (harmonic == nullptr) return EPIC_ERROR_INVALID_DATA;
-    int rc = EPIC_SUCCESS;
     Ctx *c = find_ctx(harmonic);
+    int rc = flush_pending(harmonic, c, "harmonic_uninitialize_dimension_size_gpu");   // (the field lives on: the iterations counted so far belong to it)
     if (c && c->d_m) {
         if (hipFree(c->d_m) != hipSuccess) {
             report("harmonic_uninitialize_dimension_size_gpu", "Failed to free device-side memory for the dimension size.");
@@ -294,6 +307,8 @@ int harmonic_initialize_potential_values_gpu(Harmonic *harmonic)  // harmonic_mo
         report(fn, "Invalid input (dimensions differ from the locked cells already on the device).");
         return EPIC_ERROR_INVALID_DATA;
     }
+    c->pending = 0;   // iterations counted on a field that is being replaced
+    c->ahead.live = false;
     drop_graphs(c);
     for (float *&b : c->buf) { if (b) (void)hipFree(b); b = nullptr; }
     free_spare(c);
@@ -339,6 +354,8 @@ int harmonic_uninitialize_potential_values_gpu(Harmonic *harmonic)  // harmonic_
     int rc = EPIC_SUCCESS;
     Ctx *c = find_ctx(harmonic);
     if (c) {
+        c->pending = 0;   // iterations counted on a field that is being dropped
+        c->ahead.live = false;
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         drop_graphs(c);
         if (c->multi()) { DeviceGuard g; multi_free_u(c); }
@@ -376,6 +393,10 @@ int harmonic_initialize_locked_gpu(Harmonic *harmonic)  // harmonic_model_gpu.cu
     if ((c->buf[0] || (c->multi() && c->slabs[0].buf[0])) && !same_dims(harmonic, c)) {
         report(fn, "Invalid input (dimensions differ from the potential values already on the device).");
         return EPIC_ERROR_INVALID_DATA;
+    }
+    {
+        const int frc = flush_pending(harmonic, c, fn);   // the iterations counted so far act under the mask as it was
+        if (frc != EPIC_SUCCESS) return frc;
     }
     drop_graphs(c);
     if (c->maskw) { (void)hipFree(c->maskw); c->maskw = nullptr; }
@@ -420,8 +441,8 @@ int harmonic_initialize_locked_gpu(Harmonic *harmonic)  // harmonic_model_gpu.cu
 int harmonic_uninitialize_locked_gpu(Harmonic *harmonic)  // harmonic_model_gpu.cu:164-177
 {
     if (harmonic == nullptr) return EPIC_ERROR_INVALID_DATA;
-    int rc = EPIC_SUCCESS;
     Ctx *c = find_ctx(harmonic);
+    int rc = flush_pending(harmonic, c, "harmonic_uninitialize_locked_gpu");   // (the field can still be read back afterwards)
     if (c && c->multi()) { DeviceGuard g; multi_free_mask(c); }
     if (c && c->maskw) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -450,6 +471,8 @@ int harmonic_update_model_gpu(Harmonic *harmonic)  // harmonic_model_gpu.cu:172-
         report(fn, "Invalid data.");
         return EPIC_ERROR_INVALID_DATA;
     }
+    c->pending = 0;   // field and mask are both replaced: iterations counted on the old ones have nothing left to show
+    c->ahead.live = false;
     if (c->multi()) { DeviceGuard g; multi_sync(c); }
     if (hipStreamSynchronize(c->stream) != hipSuccess) return EPIC_ERROR_DEVICE_SYNCHRONIZE;
     int rc = upload_u(harmonic, c, fn);
@@ -498,8 +521,8 @@ int harmonic_initialize_gpu(Harmonic *harmonic, unsigned int numThreads)  // har
 int harmonic_uninitialize_gpu(Harmonic *harmonic)  // harmonic_gpu.cu:307-324
 {
     if (harmonic == nullptr) return EPIC_ERROR_INVALID_DATA;
-    int rc = EPIC_SUCCESS;
     Ctx *c = find_ctx(harmonic);
+    int rc = flush_pending(harmonic, c, "harmonic_uninitialize_gpu");
     if (c && c->multi()) { DeviceGuard g; multi_free_delta(c); }
     if (c && c->d_delta) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -521,6 +544,10 @@ int harmonic_get_potential_values_gpu(Harmonic *harmonic)  // harmonic_gpu.cu:41
     if (!harmonic || harmonic->u == nullptr || !c || !(c->buf[0] || (c->multi() && c->slabs[0].buf[0])) || harmonic->d_u == nullptr) {
         report(fn, "Invalid data.");
         return EPIC_ERROR_INVALID_DATA;
+    }
+    {
+        const int frc = flush_pending(harmonic, c, fn);   // the caller sees the field of every iteration it has asked for
+        if (frc != EPIC_SUCCESS) return frc;
     }
     if (c->multi()) return multi_get_values(harmonic, c, fn);
     if (hipStreamSynchronize(c->stream) != hipSuccess) {

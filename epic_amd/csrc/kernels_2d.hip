@@ -1029,20 +1029,45 @@ __global__ void eval_math_kernel(const float *in, float *out, size_t n, int whic
 
 }  // namespace
 
+// CUs of the CURRENT device (cached per device ordinal: the slabs of the multi-device mode may sit on devices that differ, and their
+// issuing threads come here concurrently).  0: unknown.
+static int current_device_cus(int *dev_out = nullptr)
+{
+    static std::mutex mu;
+    static std::map<int, int> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    if (dev_out) *dev_out = dev;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(dev);
+    if (it != cache.end()) return it->second;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    return cache[dev] = n;
+}
+
 int resident_blocks_of(const void *kernel)
 {
     static std::mutex mu;
-    static std::map<const void *, int> cache;
+    static std::map<std::pair<int, const void *>, int> cache;   // per device and kernel
+    int dev = 0;
+    const int cus = current_device_cus(&dev);
     std::lock_guard<std::mutex> lk(mu);
-    auto it = cache.find(kernel);
+    const auto key = std::make_pair(dev, kernel);
+    auto it = cache.find(key);
     if (it != cache.end()) return it->second;
-    int blocks = 0, dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, kWave * kWavesPerBlock, 0) != hipSuccess || blocks < 1 || cus < 1) {
+    int blocks = 0;
+    if (cus < 1 || hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, kWave * kWavesPerBlock, 0) != hipSuccess || blocks < 1) {
         (void)hipGetLastError();
-        return cache[kernel] = 0;   // unknown: the caller's default
+        return cache[key] = 0;   // unknown: the caller's default
     }
-    return cache[kernel] = blocks * cus;
+    return cache[key] = blocks * cus;
 }
 
 // The fused passes without work lists: how many chunks the rows are cut into.  A launch's workgroups (four waves, one per SIMD) are dealt
@@ -1056,14 +1081,7 @@ void tighten_chunks(Sweep2dArgs &a, int rows)
 {
     a.chunk_rem = 0;
     if (!(a.flags & 4)) return;
-    // (the issuing threads of the multi-device mode come here concurrently: a function-local static is initialised once, thread-safely;
-    //  the devices of a node are alike)
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        const bool ok = hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0;
-        if (!ok) (void)hipGetLastError();
-        return ok ? n : 0;
-    }();
+    const int cus = current_device_cus();   // (per device: see there)
     if (cus <= 0 || a.nstrips <= 0) return;
     const long long blocks = ((long long)a.nchunks * a.nstrips + kWavesPerBlock - 1) / kWavesPerBlock;
     const long long per_cu = (blocks + cus - 1) / cus;

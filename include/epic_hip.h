@@ -181,8 +181,11 @@ int epic_hip_multi_report(EpicHarmonicT *harmonic, char *buf, size_t cap);
  * pairs / list-driven sweeps / single sweeps, replayed from a hipGraph or not), the tile plan, task heights, and in multi-device
  * mode the halo depth and the transport of every seam.  Returns the bytes written; 0 without a context or when buf is too small.
  * epic_hip_config_reload: re-reads the environment for this Harmonic's context (a knob that changed is applied; modes set through
- * epic_hip_set_* stay unless their variable changed; the device list only takes effect at the next initialisation) -- for a caller
- * that changes a variable on a live context (tests, bench.py).  NULL: the process-wide knobs the raw operators below go by. */
+ * epic_hip_set_* stay unless their variable changed; EPIC_HIP_DEVICES / EPIC_HIP_HALO are taken over when neither a field nor a
+ * mask is resident, i.e. they shape the NEXT initialisation -- "state" of config_dump shows the slab layout in force) -- for a caller
+ * that changes a variable on a live context (tests, bench.py).  It also refreshes the process-wide knobs: EPIC_HIP_FLAGS and
+ * EPIC_HIP_LIST_WAVES are read by the 2-D launchers from those (speed only, never results), for every context of the process.
+ * NULL: the process-wide knobs only (what the raw operators below go by). */
 int epic_hip_config_dump(EpicHarmonicT *harmonic, char *buf, size_t cap);
 int epic_hip_config_reload(EpicHarmonicT *harmonic);
 

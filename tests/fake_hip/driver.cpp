@@ -123,6 +123,40 @@ static int seq_node(Grid &g)   // src/epic_navigation_node_harmonic.cpp: initAlg
     return harmonic_uninitialize_locked_gpu(&g.h);
 }
 
+// The node's ticks with enough plain updates per tick for whole deferred blocks (driver_loop.hip: harmonic_update_gpu counts): blocks
+// enqueued at the cap, the block enqueued AHEAD of the caller behind a check and adopted, a read-back and an edit in the middle of a
+// block (the block ahead is discarded), a renumbered iteration, and a teardown with iterations pending.
+static int seq_node_ticks(Grid &g)
+{
+    int rc = harmonic_initialize_dimension_size_gpu(&g.h);
+    if (rc) return rc;
+    if ((rc = harmonic_initialize_potential_values_gpu(&g.h))) return rc;
+    if ((rc = harmonic_initialize_locked_gpu(&g.h))) return rc;
+    if ((rc = harmonic_initialize_gpu(&g.h, 1024))) return rc;
+    for (int tick = 0; tick < 4; tick++) {
+        rc = harmonic_update_and_check_gpu(&g.h, 1024);
+        if (rc != EPIC_SUCCESS && rc != EPIC_SUCCESS_AND_CONVERGED) return rc;
+        for (int i = 0; i < (tick == 2 ? 5 : 39); i++)   // (tick 2 stops inside the block that was enqueued ahead)
+            if ((rc = harmonic_update_gpu(&g.h, 1024))) return rc;
+        if (tick == 2) {
+            if ((rc = harmonic_get_potential_values_gpu(&g.h))) return rc;
+            if (g.h.n == 2) {
+                unsigned v[2] = {3, 4}, types[1] = {EPIC_CELL_TYPE_OBSTACLE};
+                if ((rc = harmonic_utilities_set_cells_2d_cpu(&g.h, 1, v, types))) return rc;
+                if ((rc = harmonic_utilities_set_cells_2d_gpu(&g.h, 1024, 1, v, types))) return rc;
+            }
+        }
+    }
+    g.h.currentIteration = 7;   // the caller renumbers with iterations pending
+    for (int i = 0; i < 3; i++)
+        if ((rc = harmonic_update_gpu(&g.h, 1024))) return rc;
+    if ((rc = harmonic_uninitialize_dimension_size_gpu(&g.h))) return rc;   // (the pending iterations surface here)
+    if ((rc = harmonic_get_potential_values_gpu(&g.h))) return rc;
+    if ((rc = harmonic_uninitialize_gpu(&g.h))) return rc;
+    if ((rc = harmonic_uninitialize_potential_values_gpu(&g.h))) return rc;
+    return harmonic_uninitialize_locked_gpu(&g.h);
+}
+
 struct Scenario {
     const char *name;
     std::vector<unsigned> dims;
@@ -135,7 +169,7 @@ struct Scenario {
 static void set_env(const std::map<std::string, std::string> &env, bool on)
 {
     static const char *all[] = {"EPIC_HIP_DEVICES", "EPIC_HIP_THREADS", "EPIC_HIP_NO_PEER", "EPIC_HIP_TRACK", "EPIC_HIP_TILE", "EPIC_HIP_MATH",
-                                "EPIC_HIP_SCHEME", "EPIC_HIP_HALO", "EPIC_HIP_FUSE_MIN_CELLS", "EPIC_HIP_TUNE", "FAKE_NO_PEER_CAPABLE", "FAKE_CURRENT_DEVICE"};
+                                "EPIC_HIP_SCHEME", "EPIC_HIP_HALO", "EPIC_HIP_FUSE_MIN_CELLS", "EPIC_HIP_TUNE", "EPIC_HIP_DEFER", "FAKE_NO_PEER_CAPABLE", "FAKE_CURRENT_DEVICE"};
     for (const char *k : all) unsetenv(k);
     if (on)
         for (auto &kv : env) setenv(kv.first.c_str(), kv.second.c_str(), 1);
@@ -182,6 +216,12 @@ int main(int argc, char **argv)
         {"python solve, 2-D", {12, 40}, 1e-2f, 7, seq_python, {}},
         {"plugin, 3-D", {6, 7, 9}, 1e-3f, 5, seq_plugin, {}},
         {"node, 2-D", {16, 18}, 1e-3f, 4, seq_node, {}},
+        {"node ticks, 2-D, deferred blocks on tiles with run-ahead", {40, 70}, 1e-9f, 100, seq_node_ticks, {}},
+        {"node ticks, 2-D, one launch per call (EPIC_HIP_DEFER=0)", {40, 70}, 1e-9f, 100, seq_node_ticks, {{"EPIC_HIP_DEFER", "0"}}},
+        {"node ticks, 2-D, deferred pairs with work lists", {40, 300}, 1e-9f, 100, seq_node_ticks, {{"EPIC_HIP_TRACK", "1"}, {"EPIC_HIP_FUSE_MIN_CELLS", "0"}}},
+        {"node ticks, 2-D, deferred fused tol pairs", {24, 300}, 1e-9f, 100, seq_node_ticks, {{"EPIC_HIP_MATH", "tol"}, {"EPIC_HIP_SCHEME", "jacobi"}, {"EPIC_HIP_FUSE_MIN_CELLS", "0"}, {"EPIC_HIP_TILE", "0"}}},
+        {"node ticks, 3-D", {5, 6, 7}, 1e-9f, 100, seq_node_ticks, {}},
+        {"node ticks, 2-D, two slabs, deferred stretches", {32, 20}, 1e-9f, 100, seq_node_ticks, {{"EPIC_HIP_DEVICES", "0,0"}, {"EPIC_HIP_THREADS", "0"}}},
         {"node, 3-D", {5, 6, 7}, 1e-3f, 4, seq_node, {}},
         {"plugin, 2-D, work lists", {40, 300}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_TRACK", "1"}}},
         {"plugin, 2-D, tracked pairs of fused passes", {40, 300}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_TRACK", "1"}, {"EPIC_HIP_FUSE_MIN_CELLS", "0"}}},
@@ -290,13 +330,15 @@ int main(int argc, char **argv)
         {"hipMemcpyPeerAsync", {EPIC_ERROR_KERNEL_EXECUTION}},
         {"hipMemsetAsync", {0, EPIC_ERROR_KERNEL_EXECUTION}}, {"hipMemset", {0}},
         {"hipStreamSynchronize", {0, EPIC_ERROR_MEMCPY_TO_HOST, EPIC_ERROR_KERNEL_EXECUTION, EPIC_ERROR_DEVICE_SYNCHRONIZE}},
-        {"hipStreamWaitEvent", {EPIC_ERROR_KERNEL_EXECUTION}}, {"hipEventRecord", {EPIC_ERROR_KERNEL_EXECUTION}},
-        {"hipEventSynchronize", {0, EPIC_ERROR_DEVICE_SYNCHRONIZE}},
+        {"hipStreamWaitEvent", {EPIC_ERROR_KERNEL_EXECUTION}},
+        {"hipEventRecord", {0, EPIC_ERROR_KERNEL_EXECUTION}},   // (0: the event in front of the block enqueued ahead of the caller -- the check goes on without that block)
+        {"hipEventSynchronize", {0, EPIC_ERROR_DEVICE_SYNCHRONIZE}}, {"hipEventQuery", {EPIC_ERROR_DEVICE_SYNCHRONIZE}},
     };
     for (auto &kv : codes) {
         auto it = allowed.find(kv.first);
         for (int c : kv.second) {
             if (kv.first == "launch_fill" && c == 0) continue;   // (seeding the third buffer of the pipelined small-grid loop: the plain loop serves)
+            if (kv.first == "launch_tile_2d" && c == 0) continue;   // (the block enqueued AHEAD of the caller behind a check, Ctx::ahead: the check goes on without it)
             if (kv.first.rfind("launch_", 0) == 0) EXPECT(c == EPIC_ERROR_KERNEL_EXECUTION, "%s failing gave code %d", kv.first.c_str(), c);
             else if (it == allowed.end()) EXPECT(false, "no expectation for %s (code %d)", kv.first.c_str(), c);
             else EXPECT(it->second.count(c) == 1, "%s failing gave code %d", kv.first.c_str(), c);

@@ -324,6 +324,7 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s)
     return hipSuccess;
 }
 hipError_t hipEventSynchronize(hipEvent_t) { return trip("hipEventSynchronize") ? fail(hipErrorUnknown) : hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t) { return trip("hipEventQuery") ? fail(hipErrorUnknown) : hipSuccess; }   // (streams execute at once: never hipErrorNotReady)
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
 {
     *ms = 1.0f;

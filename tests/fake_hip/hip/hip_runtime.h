@@ -18,6 +18,7 @@ typedef enum hipError_t {
     hipErrorInvalidValue = 1,
     hipErrorOutOfMemory = 2,
     hipErrorInvalidDevice = 101,
+    hipErrorNotReady = 600,
     hipErrorPeerAccessAlreadyEnabled = 704,
     hipErrorNotSupported = 801,
     hipErrorUnknown = 999,
@@ -77,6 +78,7 @@ hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned flags);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventQuery(hipEvent_t e);
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
 
 // ---- controls of the fake (tests/fake_hip/fake_hip.cpp) ----

@@ -28,7 +28,7 @@ from epic_amd.harmonic import Harmonic  # noqa: E402
 from epic_amd.synthetic import synthetic_grid  # noqa: E402
 
 E = eh._epic
-KNOBS = ("EPIC_HIP_DEVICES", "EPIC_HIP_HALO", "EPIC_HIP_NO_PEER", "EPIC_HIP_THREADS", "EPIC_HIP_TILE", "EPIC_HIP_TILE_HALO", "EPIC_HIP_TILE_ROWS", "EPIC_HIP_TILE_WIDTH", "EPIC_HIP_TILE_PIPELINE", "EPIC_HIP_FUSE_MIN_CELLS",
+KNOBS = ("EPIC_HIP_DEFER", "EPIC_HIP_DEVICES", "EPIC_HIP_HALO", "EPIC_HIP_NO_PEER", "EPIC_HIP_THREADS", "EPIC_HIP_TILE", "EPIC_HIP_TILE_HALO", "EPIC_HIP_TILE_ROWS", "EPIC_HIP_TILE_WIDTH", "EPIC_HIP_TILE_PIPELINE", "EPIC_HIP_FUSE_MIN_CELLS",
          "EPIC_HIP_NO_FUSE", "EPIC_HIP_NO_GRAPH", "EPIC_HIP_FLAGS", "EPIC_HIP_TRACK", "EPIC_HIP_TRACK_PAIRS", "EPIC_HIP_TRACK_PAIR_ROWS", "EPIC_HIP_FUSED_ROWS",
          "EPIC_HIP_ROWS_PER_TASK", "EPIC_HIP_3D_PAIR", "EPIC_HIP_3D_MARCH", "EPIC_HIP_3D_PAIR_ROWS", "EPIC_HIP_TRACK_SWITCH", "EPIC_HIP_MATH",
          "EPIC_HIP_SCHEME")
@@ -195,6 +195,177 @@ def campaign(cases, seed, verbose=True):
     return bad
 
 
+# ---- the fine-grained API (round 6: harmonic_update_gpu counts, the library enqueues whole blocks) -----------------------------------
+def draw_script(rng, m, big):
+    """A caller's script over the fine-grained entry points, as the navigation node mixes them (src/epic_navigation_node_harmonic.cpp:
+    165-189 ticks, :357-380 setCells, :614-626 the read-back of srvComputePath): 'u' harmonic_update_gpu, 'c' harmonic_update_and_check_gpu,
+    ('n', k, check) epic_hip_update_n_gpu, ('e', v, types) set_cells, 'r' get_potential_values (compared with the checker there and then),
+    ('i', it) the caller sets currentIteration itself."""
+    ops = []
+    budget = int(rng.integers(4, 24 if big else 90))
+    while budget > 0:
+        r = rng.random()
+        if r < 0.45:      # a tick of the node: one check, then steps - 1 plain updates
+            steps = int(rng.integers(1, min(budget, 40) + 1))
+            ops.append("c")
+            ops.extend("u" * (steps - 1))
+            budget -= steps
+        elif r < 0.60:    # plain updates on their own
+            k = int(rng.integers(1, min(budget, 25) + 1))
+            ops.extend("u" * k)
+            budget -= k
+        elif r < 0.70:
+            k = int(rng.integers(1, min(budget, 30) + 1))
+            ops.append(("n", k, int(rng.integers(0, 2))))
+            budget -= k
+        elif r < 0.82 and len(m) == 2:
+            n = int(rng.integers(1, 9))
+            v = np.stack([rng.integers(0, m[1] + 2, n), rng.integers(0, m[0] + 2, n)], axis=1).astype(np.uint32)
+            ops.append(("e", np.ascontiguousarray(v), rng.integers(0, 4, n).astype(np.uint32)))
+        elif r < 0.94:
+            ops.append("r")
+        else:
+            ops.append(("i", int(rng.integers(0, 1000))))
+    ops.append("c")
+    ops.append("r")
+    return ops
+
+
+def node_case(rng):
+    m, u0, locked, mode, k, env, edits = draw_case(rng)
+    big = int(np.prod(m)) > 3000000
+    env["EPIC_HIP_DEFER"] = rng.choice(["0", None, None, None])
+    return m, u0, locked, mode, env, draw_script(rng, m, big)
+
+
+def checker_script(m, u0, locked, mode, ops):
+    """The checker's statement of the script: (field, delta) at every 'r', in order."""
+    p = O.Problem(m, u0, locked)
+    name, math, scheme = mode
+    lib = O.oracle()
+    pending = [0]
+    delta = [0.0]
+
+    def run(ends_with_check):
+        n = pending[0]
+        pending[0] = 0
+        if n == 0:
+            return
+        if math == eh.MATH_TOL:
+            assert lib.oracle_tol_run(ct.byref(p.h), n, 1 if scheme == eh.SCHEME_REDBLACK else 0) == 0
+        elif scheme == eh.SCHEME_JACOBI:
+            assert lib.oracle_jacobi_run(ct.byref(p.h), n) == 0
+        else:
+            for i in range(n):
+                (lib.oracle_update_and_check if ends_with_check and i == n - 1 else lib.oracle_update)(ct.byref(p.h))
+        if ends_with_check:
+            delta[0] = float(p.h.delta)
+
+    shots = []
+    for op in ops:
+        if op == "u":
+            pending[0] += 1
+        elif op == "c":
+            pending[0] += 1
+            run(True)
+        elif op == "r":
+            run(False)
+            shots.append((p.u.copy(), delta[0]))
+        elif op[0] == "n":
+            pending[0] += op[1]
+            run(bool(op[2]))
+        elif op[0] == "e":
+            run(False)
+            assert lib.oracle_set_cells_2d(ct.byref(p.h), len(op[2]), op[1].ctypes.data_as(eh._UP), op[2].ctypes.data_as(eh._UP)) == 0
+        elif op[0] == "i":
+            run(False)
+            p.h.currentIteration = op[1]
+    return shots
+
+
+def library_script(m, u0, locked, mode, env, ops):
+    prev = {a: os.environ.get(a) for a in KNOBS}
+    for a in KNOBS:
+        os.environ.pop(a, None)
+    for a, b in env.items():
+        if b is not None:
+            os.environ[a] = b
+    assert E.epic_hip_config_reload(None) == 0
+    try:
+        h = Harmonic()
+        h.set_grid(m, u0, locked)
+        h.epsilon = 1e-6
+        for fn in (E.harmonic_initialize_dimension_size_gpu, E.harmonic_initialize_potential_values_gpu, E.harmonic_initialize_locked_gpu):
+            assert fn(h) == 0
+        assert E.harmonic_initialize_gpu(h, 1024) == 0
+        assert E.epic_hip_set_math_mode(h, mode[1]) == 0 and E.epic_hip_set_scheme(h, mode[2]) == 0
+        shots = []
+        delta = 0.0
+        for op in ops:
+            if op == "u":
+                assert E.harmonic_update_gpu(h, 1024) == 0
+            elif op == "c":
+                assert E.harmonic_update_and_check_gpu(h, 1024) in (0, 1)
+                delta = float(h.delta)
+            elif op == "r":
+                assert E.harmonic_get_potential_values_gpu(h) == 0
+                shots.append((h.u_array().ravel().copy(), delta))
+            elif op[0] == "n":
+                assert E.epic_hip_update_n_gpu(h, op[1], op[2]) in (0, 1)
+                if op[2]:
+                    delta = float(h.delta)
+            elif op[0] == "e":
+                assert E.harmonic_utilities_set_cells_2d_gpu(h, 1024, len(op[2]), op[1].ctypes.data_as(eh._UP), op[2].ctypes.data_as(eh._UP)) == 0
+            elif op[0] == "i":
+                h.currentIteration = op[1]
+        LAST["dump"] = eh.config_dump(h)
+        for fn in (E.harmonic_uninitialize_gpu, E.harmonic_uninitialize_dimension_size_gpu, E.harmonic_uninitialize_potential_values_gpu,
+                   E.harmonic_uninitialize_locked_gpu):
+            assert fn(h) == 0
+        return shots
+    finally:
+        for a, b in prev.items():
+            os.environ.pop(a, None) if b is None else os.environ.__setitem__(a, b)
+        E.epic_hip_config_reload(None)
+
+
+def script_text(ops):
+    out, run = [], 0
+    for op in list(ops) + [None]:
+        if op == "u":
+            run += 1
+            continue
+        if run:
+            out.append("u*%d" % run)
+            run = 0
+        if op is None:
+            break
+        out.append(op if isinstance(op, str) else "%s%s" % (op[0], "" if op[0] == "e" else op[1]))
+    return " ".join(out)
+
+
+def campaign_node(cases, seed, verbose=True):
+    """Random scripts of single calls, batches, edits, read-backs and caller-set iteration numbers: every read-back must show the checker's
+    field bit for bit, every check its delta -- whatever the library deferred and however it enqueued it."""
+    rng = np.random.default_rng(seed)
+    bad = []
+    for i in range(cases):
+        m, u0, locked, mode, env, ops = node_case(rng)
+        want = checker_script(m, u0, locked, mode, ops)
+        got = library_script(m, u0, locked, mode, env, ops)
+        ok = len(want) == len(got) and all(np.array_equal(g[0], w[0]) and g[1] == w[1] for g, w in zip(got, want))
+        if verbose or not ok:
+            print(f"node {i:4d} {'ok  ' if ok else 'FAIL'} {str(m):18s} {mode[0]:15s} " + " ".join(f"{a[9:]}={b}" for a, b in env.items() if b is not None)
+                  + " | " + script_text(ops), flush=True)
+        if not ok:
+            first = next((j for j, (g, w) in enumerate(zip(got, want)) if not (np.array_equal(g[0], w[0]) and g[1] == w[1])), -1)
+            bad.append(dict(case=i, seed=seed, m=m, mode=mode[0], env=env, script=script_text(ops), first_bad_readback=first,
+                            cells=int((got[first][0] != want[first][0]).sum()) if first >= 0 else -1,
+                            delta=(got[first][1], want[first][1]) if first >= 0 else None, library=LAST["dump"]))
+            print("    the library's account of that context:", json.dumps(LAST["dump"]), flush=True)
+    return bad
+
+
 def draw_complete(rng):
     """A whole relaxation: a small grid (the checker must finish it), a random epsilon and check interval."""
     if rng.random() < 0.25:
@@ -283,8 +454,9 @@ if __name__ == "__main__":
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--complete", action="store_true", help="whole relaxations (harmonic_complete_gpu) instead of fixed iteration counts")
+    ap.add_argument("--node", action="store_true", help="scripts over the fine-grained entry points (single updates, checks, edits, read-backs)")
     a = ap.parse_args()
-    bad = (campaign_complete if a.complete else campaign)(a.cases, a.seed, verbose=not a.quiet)
+    bad = (campaign_node if a.node else campaign_complete if a.complete else campaign)(a.cases, a.seed, verbose=not a.quiet)
     print(f"{a.cases} cases, seed {a.seed}: {len(bad)} mismatches")
     for b in bad:
         print(b)
