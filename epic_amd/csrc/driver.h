@@ -201,7 +201,8 @@ struct Ctx {
         float *h_delta = nullptr;    // pinned
         hipStream_t stream = nullptr, comm = nullptr;   // sweeps / boundary bands + halo copies
         hipEvent_t ev_prev = nullptr, ev_band = nullptr, ev_comm = nullptr, ev_stage = nullptr;
-        Track trk;                   // this slab's work lists
+        Track trk;                   // this slab's work lists (single sweeps)
+        Track trk_f;                 // ... and those of the fused passes' tiling (tracked pairs on slabs: multi_run_pairs; Ctx::last_lists says whose are current)
         bool peer_up = true;         // the seam to the slab above: direct device-to-device copies (else through `bounce`)
         float *bounce[2] = {nullptr, nullptr};   // pinned staging of that seam: [0] downwards (into this slab), [1] upwards
         int first() const { return g_top; }              // first owned local row
@@ -251,7 +252,6 @@ struct Ctx {
 };
 
 constexpr float kTolFinishOptionalBelow = 1e-5f;   // EPIC_HIP_TOL_FINISH=0 is honoured for epsilon <= this (harmonic_execute_gpu)
-constexpr long long kTileMaxCellsDefault = 3ll << 20;   // EPIC_HIP_TILE_MAX_CELLS: grids up to this many cells take the tile path
 constexpr size_t kTileDeltaCap = 4096;   // tiles of a launch whose check may go through Ctx::h_tile_delta
 
 // ---- driver_registry.hip ------------------------------------------------------------------------------------------------
@@ -274,7 +274,9 @@ void apply_config(Ctx *c);                      // the mode fields of a context 
 void resolve_tracking(Ctx *c);
 int auto_rows_per_task(const Ctx *c);
 int fused_rows_per_task(const Ctx *c);
-long long rb_fuse_min_cells(const Ctx *c);
+long long fuse_from_cells(const Ctx *c);       // untracked fused pairs from this many cells (rows x pitch) on
+long long tile_up_to_cells(const Ctx *c);      // LDS tiles up to this many cells (rows x cols)
+long long tracked_pairs_from_cells(const Ctx *c);
 bool fuses_tol(const Ctx *c);
 bool fuses_jacobi(const Ctx *c);
 bool fuses_rb_tol(const Ctx *c);
@@ -284,6 +286,7 @@ void tune_fused_rows(Ctx *c, int kind, unsigned iteration);
 epic_hip::TilePlan tile_plan(const Ctx *c);
 bool tile_checks(const Ctx *c, const epic_hip::TilePlan &tp);
 bool rb_pairs_tracked(const Ctx *c);
+bool rb_pairs_tracked_multi(const Ctx *c);      // the same on the slabs of the multi-device mode (2-D, at least two ghost rows)
 int rb_pairs_rows_per_task(const Ctx *c);
 void rb_pairs_choose_rows(Ctx *c);
 bool bypass_lists_for_batch(Ctx *c, bool pairs = false);
@@ -326,6 +329,7 @@ size_t slab_mask_words(const Ctx *c, const Ctx::Slab &sl);
 bool multi_has_threads(const Ctx *c);
 hipError_t multi_sweep(Ctx *c, bool check, unsigned iteration);
 hipError_t multi_run(Ctx *c, unsigned count, unsigned first, bool check_first);
+hipError_t multi_run_pairs(Ctx *c, unsigned npairs, unsigned first, bool check_last);   // list-driven fused passes on every slab (rb_pairs_tracked_multi)
 int multi_read_delta(Harmonic *h, Ctx *c, const char *fn);
 int multi_upload_u(Harmonic *h, Ctx *c, const char *fn);
 int multi_upload_locked(Harmonic *h, Ctx *c, const char *fn);

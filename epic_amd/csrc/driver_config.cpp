@@ -53,14 +53,14 @@ Config Config::from_env()
     c.no_fuse = given("EPIC_HIP_NO_FUSE");
     c.no_graph = given("EPIC_HIP_NO_GRAPH");
     e = env("EPIC_HIP_FUSE_MIN_CELLS");
-    if (e) c.fuse_min_cells = atoll(e);
+    if (e && atoll(e) >= 0) c.fuse_min_cells = atoll(e);
     e = env("EPIC_HIP_FUSED_ROWS");
     if (e && atoi(e) > 0) c.fused_rows = atoi(e);
     c.tune = !is_zero("EPIC_HIP_TUNE");
     c.tune_debug = given("EPIC_HIP_TUNE_DEBUG");
     c.tile = !is_zero("EPIC_HIP_TILE");
     e = env("EPIC_HIP_TILE_MAX_CELLS");
-    if (e) c.tile_max_cells = atoll(e);
+    if (e && atoll(e) >= 0) c.tile_max_cells = atoll(e);
     c.tile_rows = int_of("EPIC_HIP_TILE_ROWS", 0);
     c.tile_width = int_of("EPIC_HIP_TILE_WIDTH", 0);
     e = env("EPIC_HIP_TILE_HALO");

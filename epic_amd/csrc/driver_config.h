@@ -45,12 +45,12 @@ struct Config {
     // which kernel family runs a batch
     bool no_fuse = false;            // EPIC_HIP_NO_FUSE
     bool no_graph = false;           // EPIC_HIP_NO_GRAPH
-    long long fuse_min_cells = 1ll << 22;   // EPIC_HIP_FUSE_MIN_CELLS
+    long long fuse_min_cells = -1;   // EPIC_HIP_FUSE_MIN_CELLS (-1: by arithmetic and scheme, driver_plan.hip: fuse_from_cells)
     int fused_rows = 0;              // EPIC_HIP_FUSED_ROWS (0: measured / the rule)
     bool tune = true;                // EPIC_HIP_TUNE=0: the rules only
     bool tune_debug = false;         // EPIC_HIP_TUNE_DEBUG
     bool tile = true;                // EPIC_HIP_TILE=0
-    long long tile_max_cells = 3ll << 20;   // EPIC_HIP_TILE_MAX_CELLS
+    long long tile_max_cells = -1;   // EPIC_HIP_TILE_MAX_CELLS (-1: by arithmetic and scheme, driver_plan.hip: tile_up_to_cells)
     int tile_rows = 0, tile_width = 0, tile_halo = 0;   // EPIC_HIP_TILE_ROWS / _WIDTH / _HALO (0: the cost model)
     bool tile_pipeline = true;       // EPIC_HIP_TILE_PIPELINE=0
     bool defer = true;               // EPIC_HIP_DEFER=0: harmonic_update_gpu launches one single iteration per call (as before round 6) instead of counting

@@ -74,7 +74,10 @@ void fold_listed_work(Ctx *c)
     DeviceGuard g;
     const int units = c->n == 2 ? c->rows : c->m[0];
     for (auto &sl : c->slabs)   // a slab's lists cover its ghost rows too: weighted by its share of the grid
-        if (hipSetDevice(sl.dev) == hipSuccess) fold(sl.trk, sl.stream, (double)sl.rows / (double)units);
+        if (hipSetDevice(sl.dev) == hipSuccess) {
+            fold(sl.trk, sl.stream, (double)sl.rows / (double)units);
+            fold(sl.trk_f, sl.stream, 2.0 * (double)sl.rows / (double)units);   // a listed tile of a fused pass is recomputed twice
+        }
 }
 
 void drop_graphs(Ctx *c)
@@ -336,7 +339,10 @@ void force_all(Ctx *c)
     c->trk.force = 2;
     c->trk_f.force = std::max(c->trk_f.force, 1);   // (one pass of two iterations, in -> out, rewrites every tile of the other buffer)
     c->last_lists = 0;
-    for (auto &sl : c->slabs) sl.trk.force = 2;
+    for (auto &sl : c->slabs) {
+        sl.trk.force = 2;
+        sl.trk_f.force = std::max(sl.trk_f.force, 1);
+    }
 }
 
 // tiles listed for the next iteration / tiles in all, summed over the domains (false: no lists in use).  forced_runs_all: a
@@ -361,7 +367,7 @@ bool due_tiles(Ctx *c, unsigned long long *due, unsigned long long *tiles, bool 
     if (!c->multi()) return one(c->last_lists == 2 ? c->trk_f : c->trk);
     DeviceGuard g;
     for (auto &sl : c->slabs)
-        if (hipSetDevice(sl.dev) != hipSuccess || hipStreamSynchronize(sl.stream) != hipSuccess || !one(sl.trk)) return false;
+        if (hipSetDevice(sl.dev) != hipSuccess || hipStreamSynchronize(sl.stream) != hipSuccess || !one(c->last_lists == 2 ? sl.trk_f : sl.trk)) return false;
     return true;
 }
 

@@ -171,6 +171,7 @@ void multi_destroy(Ctx *c)  // the crew, streams, events, pinned words, work lis
     for (auto &sl : c->slabs) {
         (void)hipSetDevice(sl.dev);
         sl.trk.release();
+        sl.trk_f.release();
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
         if (sl.comm) (void)hipStreamDestroy(sl.comm);
         for (hipEvent_t e : {sl.ev_prev, sl.ev_band, sl.ev_comm, sl.ev_stage}) if (e) (void)hipEventDestroy(e);
@@ -314,6 +315,7 @@ int multi_upload_u(Harmonic *h, Ctx *c, const char *fn)
             return EPIC_ERROR_MEMCPY_TO_DEVICE;
         }
         sl.trk.force = 2;
+        sl.trk_f.force = std::max(sl.trk_f.force, 1);
     }
     c->cur = 0;
     c->since = 0;
@@ -356,6 +358,7 @@ int multi_upload_locked(Harmonic *h, Ctx *c, const char *fn)
         (void)hipFree(tmp);
         if (rc != EPIC_SUCCESS) return rc;
         sl.trk.force = 2;
+        sl.trk_f.force = std::max(sl.trk_f.force, 1);
     }
     // (`since` is left alone: the mask does not refresh the ghost units of u -- multi_upload_u does, and resets the countdown)
     return EPIC_SUCCESS;
@@ -413,6 +416,13 @@ hipError_t multi_run(Ctx *c, unsigned count, unsigned first, bool check_first)
     const bool fuse_rb = !tracked && c->redblack && c->n == 2 && c->math != 4 && !c->cfg.no_fuse && (long long)c->rows * c->pitch >= (1ll << 22);
     const bool fuse = !tracked && (fuses_tol(c) || fuse_rb);
     const int rpt_track = c->n == 2 ? auto_rows_per_task(c) : 32;
+    if (tracked) {   // (as enqueue_sweep: fused passes have run since these lists were made -> one iteration over every tile)
+        if (c->last_lists == 2)
+            for (auto &sl : c->slabs) sl.trk.force = std::max(sl.trk.force, 1);
+        c->last_lists = 1;
+    } else {
+        c->last_lists = 0;
+    }
     unsigned done = 0;
     while (done < count) {
         // a stretch without exchange: iterations that keep `since` below G - 1 at their start
@@ -561,6 +571,117 @@ hipError_t multi_run(Ctx *c, unsigned count, unsigned first, bool check_first)
     return hipSuccess;
 }
 
+// Tracked PAIRS on the slabs (round 6): `npairs` pairs of iterations from iteration `first`, every pair ONE list-driven fused pass per
+// slab over its local rows (ghost rows included; rb_fused2d_kernel / tol_fused2d_tracked_kernel with the slab's own lists of that tiling:
+// Slab::trk_f); check_last: the second iteration of the last pair is a check (the slabs' delta words, owned rows only).  A pass makes two
+// more ghost rows stale, so the ghost rows are traded whenever the next pass would run out of exact ones (every halo / 2 passes), as a
+// step of its own behind the passes: the neighbours' outermost owned rows are exact at any time, so an exchange may come early.  After
+// an exchange the tiles that hold or read the rewritten rows -- two rows deep for two iterations -- are woken for the next pass.
+// Until round 6 tracked relaxations on slabs ran single list-driven sweeps: the plugin's default 8192^2 relaxation on two slabs took
+// 17 % longer than on one device.  Same iterations, same bits (tests/test_gpu_multi_device.py).
+hipError_t multi_run_pairs(Ctx *c, unsigned npairs, unsigned first, bool check_last)
+{
+    const int G = c->halo;
+    if (c->n != 2 || G < 2) return hipErrorInvalidValue;
+    const bool tol = c->math == 4;
+    const int rpt = rb_pairs_rows_per_task(c);
+    const int nstrips_f = (c->pitch + 247) / 248;
+    if (c->last_lists != 2)
+        for (auto &sl : c->slabs) sl.trk_f.force = std::max(sl.trk_f.force, 1);   // something else has touched the field since
+    c->last_lists = 2;
+    // every slab's newest rows are in buf[c->cur]; its band event is recorded behind its latest pass
+    auto exchange = [&]() -> hipError_t {
+        const int cur = c->cur;
+        hipError_t e = for_each_slab(c, [&, cur](int k) -> hipError_t {
+            Ctx::Slab &sl = c->slabs[k];
+            hipError_t e = hipStreamWaitEvent(sl.comm, sl.ev_band, 0);
+            if (e == hipSuccess && k > 0) {
+                Ctx::Slab &up = c->slabs[k - 1];
+                e = multi_copy_units(c, sl, sl.buf[cur], 0, up, up.buf[cur], up.last() + 1 - G, G, up.ev_band, sl.peer_up, sl.bounce[0]);
+            }
+            if (e == hipSuccess && k + 1 < (int)c->slabs.size()) {
+                Ctx::Slab &dn = c->slabs[k + 1];
+                e = multi_copy_units(c, sl, sl.buf[cur], sl.rows - G, dn, dn.buf[cur], dn.first(), G, dn.ev_band, dn.peer_up, dn.bounce[1]);
+            }
+            if (e == hipSuccess) e = hipSetDevice(sl.dev);
+            if (e == hipSuccess) e = hipEventRecord(sl.ev_comm, sl.comm);
+            return e;
+        });
+        if (e != hipSuccess) return e;
+        e = for_each_slab(c, [&](int k) -> hipError_t {
+            Ctx::Slab &sl = c->slabs[k];
+            hipError_t e = hipStreamWaitEvent(sl.stream, sl.ev_comm, 0);
+            if (e == hipSuccess && k > 0) e = hipStreamWaitEvent(sl.stream, c->slabs[k - 1].ev_comm, 0);
+            if (e == hipSuccess && k + 1 < (int)c->slabs.size()) e = hipStreamWaitEvent(sl.stream, c->slabs[k + 1].ev_comm, 0);
+            if (e == hipSuccess && sl.trk_f.tiles && sl.trk_f.force == 0) {
+                const epic_hip::Activity next = sl.trk_f.upcoming();
+                auto wake_rows = [&](int lo, int hi) {   // tiles of the fused tiling that hold rows [lo, hi)
+                    lo = std::max(lo, 0);
+                    hi = std::min(hi, sl.rows);
+                    if (hi <= lo) return hipSuccess;
+                    return epic_hip::launch_wake_tile_range(&next, sl.trk_f.tiles, (lo / sl.trk_f.rpt) * nstrips_f, ((hi - 1) / sl.trk_f.rpt + 1) * nstrips_f, sl.stream);
+                };
+                if (sl.g_top) e = wake_rows(0, G + 2);
+                if (e == hipSuccess && sl.g_bot) e = wake_rows(sl.rows - G - 2, sl.rows);
+            }
+            return e;
+        });
+        c->since = 0;
+        return e;
+    };
+    // (an exchange needs every slab's band event behind its latest launch: single sweeps of an earlier call record it only in their
+    //  exchange iteration, so the first exchange of this call records it itself)
+    auto record_bands = [&]() -> hipError_t {
+        return for_each_slab(c, [&](int k) -> hipError_t { return hipEventRecord(c->slabs[k].ev_band, c->slabs[k].stream); });
+    };
+    unsigned p = 0;
+    bool bands_recorded = false;
+    while (p < npairs) {
+        if (c->since + 2 > G) {
+            hipError_t e = bands_recorded ? hipSuccess : record_bands();
+            if (e == hipSuccess) e = exchange();
+            if (e != hipSuccess) return e;
+        }
+        const unsigned n = std::min<unsigned>(npairs - p, (unsigned)((G - c->since) / 2));
+        const unsigned it0 = first + 2 * p;
+        const int cur0 = c->cur;
+        const bool last_stretch = p + n == npairs;
+        hipError_t e = for_each_slab(c, [&, n, it0, cur0, last_stretch](int k) -> hipError_t {
+            Ctx::Slab &sl = c->slabs[k];
+            const size_t tiles = epic_hip::rb_fused_2d_tiles(sl.rows, c->pitch, rpt);
+            int cur = cur0;
+            hipError_t e = hipSuccess;
+            for (unsigned i = 0; i < n && e == hipSuccess; i++) {
+                const bool check = check_last && last_stretch && i + 1 == n;
+                if (check) e = hipMemsetAsync(sl.d_delta, 0, sizeof(unsigned), sl.stream);
+                if (e != hipSuccess) break;
+                epic_hip::Activity act = sl.trk_f.next(tiles, rpt, sl.stream, nullptr);
+                const int parity = (int)((it0 + 2 * i + (unsigned)sl.top()) & 1u);
+                e = tol ? epic_hip::launch_jacobi_fused_2d(sl.buf[cur], sl.buf[cur ^ 1], sl.maskw, sl.rows, c->pitch, rpt, c->math, sl.stream,
+                                                           c->redblack ? parity : -1, c->maskf(sl), act.list_out ? &act : nullptr,
+                                                           check ? sl.d_delta : nullptr, sl.first(), sl.last() + 1)
+                        : epic_hip::launch_rb_fused_2d(sl.buf[cur], sl.buf[cur ^ 1], sl.maskw, sl.rows, c->pitch, rpt, c->math, parity, sl.stream,
+                                                       c->maskf(sl), act.list_out ? &act : nullptr, check ? sl.d_delta : nullptr, sl.first(), sl.last() + 1);
+                if (e == hipSuccess && act.list_out) sl.trk_f.advance();
+                cur ^= 1;
+            }
+            if (e == hipSuccess) e = hipEventRecord(sl.ev_band, sl.stream);   // (what the next exchange waits for)
+            return e;
+        });
+        if (e != hipSuccess) return e;
+        bands_recorded = true;
+        if (n & 1u) c->cur ^= 1;
+        c->since += 2 * (int)n;
+        p += n;
+    }
+    // multi_run's invariant -- at least one exact ghost row at the start of every iteration, since <= G - 1 -- holds on return: whatever
+    // comes next may be a single sweep (an odd count, a check of its own, a batch without the lists).  (First version of round 6 returned
+    // with since == G after G / 2 passes: the next single sweep then read ghost rows that were all stale -- found by
+    // tests/test_gpu_multi_device.py::test_tracked_pairs_on_slabs_maps_equal_the_reference, umass at eps = 1e-3 on three slabs.)
+    if (c->since >= G) return exchange();
+    return hipSuccess;
+}
+
 hipError_t multi_sweep(Ctx *c, bool check, unsigned iteration) { return multi_run(c, 1, iteration, check); }
 
 int multi_read_delta(Harmonic *h, Ctx *c, const char *fn)
@@ -612,6 +733,7 @@ int multi_set_cells(Ctx *c, unsigned k, const unsigned *v, const unsigned *types
     for (auto &sl : c->slabs) {
         unsigned *d_v = nullptr, *d_types = nullptr;
         sl.trk.force = 2;
+        sl.trk_f.force = std::max(sl.trk_f.force, 1);
         if (hipSetDevice(sl.dev) != hipSuccess || hipMalloc((void **)&d_v, 2 * (size_t)k * sizeof(unsigned)) != hipSuccess ||
             hipMalloc((void **)&d_types, (size_t)k * sizeof(unsigned)) != hipSuccess) {
             (void)hipGetLastError();

@@ -53,23 +53,47 @@ int fused_rows_per_task(const Ctx *c)
     return (int)std::min<long long>(64, std::max<long long>(16, r));
 }
 
-// Red-black with the precise / fast math: from how many cells (rows x pitch) on two plain iterations run as one fused pass
-// (rb_fused2d_kernel).  EPIC_HIP_FUSE_MIN_CELLS overrides (the tests set 0).
-long long rb_fuse_min_cells(const Ctx *c) { return c->cfg.fuse_min_cells; }   // (default 4 Mcell)
+// Which kernel family serves a 2-D grid WITHOUT work lists is a matter of its size, and the sizes at which the families cross differ
+// by arithmetic and scheme.  Measured in round 6 (tools/size_curve.py, profiles/r06_size_curve.txt: us per iteration of a block of
+// harmonic_execute_gpu's loop, every family forced on every size):
+//                              LDS tiles win up to         single sweeps in between        fused pairs win from
+//   precise / fast, red-black        ~3 Mcell            3 - 5.5 Mcell (2048^2: 10.1 us           ~5.5 Mcell
+//                                                         against the pass's 12.1)
+//   precise / fast, Jacobi          ~0.6 Mcell           everything above (no fused pass)             --
+//   tol, red-black                  ~2 Mcell                        --                             ~2 Mcell   (1900^2: 5.9 us against 10.5)
+//   tol, Jacobi                     ~1.5 Mcell                      --                             ~1.5 Mcell (1419 x 1735: 6.4 against 10.3)
+// Until round 6 one pair of numbers served all four (tiles <= 3 Mcell, fused >= 4 Mcell), which left 3-4 Mcell on single sweeps for the
+// tol arithmetic (1.8 x slower than its fused pass there) and put 1.5-3 Mcell tol grids on tiles that the fused pass beats by 1.4-1.6 x.
+// EPIC_HIP_FUSE_MIN_CELLS / EPIC_HIP_TILE_MAX_CELLS override (the tests set 0 / huge values).
+long long fuse_from_cells(const Ctx *c)
+{
+    if (c->cfg.fuse_min_cells >= 0) return c->cfg.fuse_min_cells;
+    if (c->math == 4) return c->redblack ? (2ll << 20) : (3ll << 19);
+    return 11ll << 19;   // 5.5 Mcell
+}
+long long tile_up_to_cells(const Ctx *c)
+{
+    if (c->cfg.tile_max_cells >= 0) return c->cfg.tile_max_cells;
+    if (c->math != 4 && !c->redblack) return 5ll << 17;   // 0.625 Mcell
+    return 3ll << 20;   // (the tol grids above fuse_from_cells never get here: tile_plan asks fuses_tol first)
+}
+// Tracked pairs: wherever the work lists are on by themselves (grids above 4 Mcell) -- list-driven single sweeps are the alternative there,
+// not untracked ones.
+long long tracked_pairs_from_cells(const Ctx *c) { return c->cfg.fuse_min_cells >= 0 ? c->cfg.fuse_min_cells : (1ll << 22); }
 
 // Whether two consecutive plain Jacobi iterations run as one fused pass in the context's current configuration.
-// EPIC_HIP_FUSE_MIN_CELLS: grids below it keep the single sweeps (default 4 Mcell: below, a sweep is launch-bound and the
+// EPIC_HIP_FUSE_MIN_CELLS: grids below it keep the single sweeps (default: fuse_from_cells above; below, a sweep is launch-bound and the
 // fused pass's extra rows cost more than the second launch; read per batch, not cached -- the tests switch it).
 bool fuses_tol(const Ctx *c)   // either scheme
 {
     if (c->cfg.no_fuse) return false;
-    return c->n == 2 && !c->track && c->math == 4 && (long long)c->rows * c->pitch >= c->cfg.fuse_min_cells;
+    return c->n == 2 && !c->track && c->math == 4 && (long long)c->rows * c->pitch >= fuse_from_cells(c);
 }
 bool fuses_jacobi(const Ctx *c) { return !c->redblack && fuses_tol(c); }
 // red-black with the precise / fast math: two plain iterations as one rb_fused2d_kernel pass (no work lists; from fuse_min_cells up)
 bool fuses_rb_precise(const Ctx *c)
 {
-    return c->redblack && c->n == 2 && !c->cfg.no_fuse && !c->track && c->math != 4 && (long long)c->rows * c->pitch >= rb_fuse_min_cells(c);
+    return c->redblack && c->n == 2 && !c->cfg.no_fuse && !c->track && c->math != 4 && (long long)c->rows * c->pitch >= fuse_from_cells(c);
 }
 // red-black, tol math: both colours in one pass (rb_tol_fused2d_kernel); one device only
 bool fuses_rb_tol(const Ctx *c) { return c->redblack && fuses_tol(c); }
@@ -158,7 +182,7 @@ void tune_fused_rows(Ctx *c, int kind, unsigned iteration)
 // stay in LDS (kernels_tile2d.hip) -- the reference's maps are launch-bound, 2.5-3 us per half-sweep whatever it computes.
 // halo == 0: not for this context.  Knobs (read per batch; the tests switch them): EPIC_HIP_TILE=0 off; EPIC_HIP_TILE_HALO = ghost
 // rings = iterations per launch, EPIC_HIP_TILE_WIDTH = 64 | 128 (default for both: a cost model of the launch, below);
-// EPIC_HIP_TILE_ROWS = owned rows per tile; EPIC_HIP_TILE_MAX_CELLS (default 3 Mcell; from 4 Mcell up the fused passes take over).
+// EPIC_HIP_TILE_ROWS = owned rows per tile; EPIC_HIP_TILE_MAX_CELLS (default: tile_up_to_cells above).
 // Where it pays (tools/tile_probe.py, tools/time_maps.py; profiles/r04_experiments.txt items 1f, 1i): 2.0-2.4 x on the maps up to
 // 0.3 Mcell (one narrow tile per CU), 1.1-1.3 x on the 1-2.5 Mcell fixtures (wide tiles).
 epic_hip::TilePlan tile_plan(const Ctx *c)
@@ -167,7 +191,7 @@ epic_hip::TilePlan tile_plan(const Ctx *c)
     if (c->n != 2 || c->multi() || c->track || c->math == 2) return none;
     if (fuses_tol(c)) return none;   // (a fused pass asked for on a small grid: EPIC_HIP_FUSE_MIN_CELLS, the tests)
     if (!c->cfg.tile) return none;
-    if ((long long)c->rows * c->cols > c->cfg.tile_max_cells) return none;
+    if ((long long)c->rows * c->cols > tile_up_to_cells(c)) return none;
     const int want_rows = c->cfg.tile_rows;
     const int only_width = c->cfg.tile_width;   // 64 | 128: one width only (experiments, tests)
     const int only_halo = c->cfg.tile_halo;
@@ -218,7 +242,17 @@ bool rb_pairs_tracked(const Ctx *c)   // (the name is round 4's first form: red-
     if (!c->track || c->n != 2 || c->multi() || c->math == 2) return false;
     if (!c->redblack && c->math != 4) return false;   // precise Jacobi has no fused pass
     if (c->cfg.no_fuse || !c->cfg.track_pairs) return false;
-    return (long long)c->rows * c->pitch >= c->cfg.fuse_min_cells;
+    return (long long)c->rows * c->pitch >= tracked_pairs_from_cells(c);
+}
+
+// The same on the slabs of the multi-device mode (round 6; driver_multi.hip: multi_run_pairs): every slab runs the pass over its local
+// rows with lists of its own, the ghost rows are traded after every halo / 2 passes.  A pass makes two ghost rows stale: at least two.
+bool rb_pairs_tracked_multi(const Ctx *c)
+{
+    if (!c->track || c->n != 2 || !c->multi() || c->halo < 2 || c->math == 2) return false;
+    if (!c->redblack && c->math != 4) return false;
+    if (c->cfg.no_fuse || !c->cfg.track_pairs) return false;
+    return (long long)c->rows * c->pitch >= tracked_pairs_from_cells(c);
 }
 
 // rows per task of the tracked pass: the unit of skipping, and every task recomputes the first colour of one row above and one
@@ -278,6 +312,7 @@ const char *plain_batch_path(const Ctx *c)
 {
     if (c->n == 4) return "none (n = 4: a counting no-op)";
     if (c->multi()) {
+        if (rb_pairs_tracked_multi(c)) return c->math == 4 ? "slabs: tracked pairs of list-driven fused tol passes per slab" : "slabs: tracked pairs of list-driven fused red-black passes per slab";
         if (c->track) return "slabs: list-driven single sweeps per slab";
         if (fuses_tol(c)) return c->redblack ? "slabs: fused tol red-black pairs between exchanges" : "slabs: fused tol Jacobi pairs between exchanges";
         if (c->redblack && c->n == 2 && c->math != 4 && !c->cfg.no_fuse && (long long)c->rows * c->pitch >= (1ll << 22)) return "slabs: fused red-black pairs between exchanges";

@@ -58,7 +58,7 @@ hipError_t launch_wake_tile_range(const Activity *next_as_out, size_t tiles, int
 // of the two iterations (zero it first).
 hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
                               int math, int parity, hipStream_t stream, const uint32_t *maskf = nullptr, const Activity *act = nullptr,
-                              unsigned *delta_bits = nullptr);
+                              unsigned *delta_bits = nullptr, int check_begin = -1, int check_end = -1);   // check_*: as launch_sweep_2d (slabs)
 inline size_t rb_fused_2d_tiles(int rows, int pitch, int rows_per_task)
 {
     return (size_t)((pitch + 247) / 248) * (size_t)((rows + rows_per_task - 1) / rows_per_task);
@@ -70,7 +70,7 @@ inline size_t rb_fused_2d_tiles(int rows, int pitch, int rows_per_task)
 // the second of the two iterations (zero it first; needs maskf).
 hipError_t launch_jacobi_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
                                   int math, hipStream_t stream, int parity = -1, const uint32_t *maskf = nullptr,
-                                  const Activity *act = nullptr, unsigned *delta_bits = nullptr);
+                                  const Activity *act = nullptr, unsigned *delta_bits = nullptr, int check_begin = -1, int check_end = -1);
 // Fused layout: a fused pass cuts a row into strips of 248 columns, lane L of strip S holding columns 248 S - 4 + 4 L .. + 3
 // (lanes 0 and 63 are halo lanes); per row and such strip four 64-bit words as in the standard layout (bit L of word j =
 // cell 4 L + j of that mapping).  Derived from the standard masks after every upload and every edit.

@@ -559,6 +559,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
     auto stage = [&](int r, bool second, bool owned, const float4 &up, const float4 &c, const float4 &dn, const RowMask &k) -> float4 {
         float4 o = c;
         const bool odd_cols = ((((r + it) & 1) == 0) != second);  // scalar
+        const bool counts = CHECK && r >= a.check_lo && r < a.check_hi;   // scalar: a slab's ghost rows are swept but kept out of max |du|
         lmask e0 = 0, e1 = 0;   // lanes whose first / second recomputed cell changed its bits
         if (odd_cols) {
             const float rt = wave_from_right(c.x, 0.0f);
@@ -567,7 +568,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
             o.y = sel(k.m1, c.y, ny);
             o.w = sel(k.m3, c.w, nw);
             if (TRACK) { e0 = lanes_ne(o.y, c.y); e1 = lanes_ne(o.w, c.w); }
-            if (CHECK && second) dmax = max2(dmax, sel(owners, max2(fabsf(c.y - o.y), fabsf(c.w - o.w)), 0.0f));
+            if (CHECK && second && counts) dmax = max2(dmax, sel(owners, max2(fabsf(c.y - o.y), fabsf(c.w - o.w)), 0.0f));
         } else {
             const float lf = wave_from_left(c.w, 0.0f);
             const float nx = cell_update_2d<MATH>(up.x, dn.x, lf, c.y, lds);
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void rb_fused2d_kernel(Swee
             o.x = sel(k.m0, c.x, nx);
             o.z = sel(k.m2, c.z, nz);
             if (TRACK) { e0 = lanes_ne(o.x, c.x); e1 = lanes_ne(o.z, c.z); }
-            if (CHECK && second) dmax = max2(dmax, sel(owners, max2(fabsf(c.x - o.x), fabsf(c.z - o.z)), 0.0f));
+            if (CHECK && second && counts) dmax = max2(dmax, sel(owners, max2(fabsf(c.x - o.x), fabsf(c.z - o.z)), 0.0f));
         }
         if (TRACK && owned) {   // (scalar throughout)
             const lmask rc = (e0 | e1) & owners;
@@ -815,7 +816,7 @@ __device__ __forceinline__ void tol_fused_pass(const Sweep2dArgs &a, TolLnEntry 
             o.y = sel(k.m1, c.y, ny);
             o.w = sel(k.m3, c.w, nw);
         }
-        if (CHECK && second) {
+        if (CHECK && second && row >= a.check_lo && row < a.check_hi) {   // (scalar; a slab's ghost rows do not count)
             const float d = max2(max2(fabsf(c.x - o.x), fabsf(c.y - o.y)), max2(fabsf(c.z - o.z), fabsf(c.w - o.w)));
             dmax = max2(dmax, sel(owners, d, 0.0f));
         }
@@ -1204,7 +1205,8 @@ void launch_rb_fused_2d_math(const Sweep2dArgs &a, bool fmask, hipStream_t strea
 }  // namespace
 
 hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
-                              int math, int parity, hipStream_t stream, const uint32_t *maskf, const Activity *act, unsigned *delta_bits)
+                              int math, int parity, hipStream_t stream, const uint32_t *maskf, const Activity *act, unsigned *delta_bits,
+                              int check_begin, int check_end)
 {
     if (pitch <= 0 || (pitch % 256) != 0 || rows <= 0 || rows_per_task <= 0 || in == out) return hipErrorInvalidValue;
     if (math != kMathPrecise && math != kMathFast && math != kMathTraffic) return hipErrorInvalidValue;  // (tol: in-place half-sweeps)
@@ -1218,7 +1220,8 @@ hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw
     a.out = out;
     a.maskw = maskw;
     a.maskf = maskf;
-    a.check_lo = a.check_hi = 0;
+    a.check_lo = check_begin < 0 ? 0 : check_begin;
+    a.check_hi = check_begin < 0 ? rows : check_end;
     a.delta_bits = delta_bits;
     a.rows = rows;
     a.pitch = pitch;
@@ -1268,7 +1271,8 @@ hipError_t launch_fuse_masks_2d(const uint32_t *maskw, int rows, int pitch, uint
 }
 
 hipError_t launch_jacobi_fused_2d(const float *in, float *out, const uint32_t *maskw, int rows, int pitch, int rows_per_task,
-                                  int math, hipStream_t stream, int parity, const uint32_t *maskf, const Activity *act, unsigned *delta_bits)
+                                  int math, hipStream_t stream, int parity, const uint32_t *maskf, const Activity *act, unsigned *delta_bits,
+                                  int check_begin, int check_end)
 {
     if (pitch <= 0 || (pitch % 256) != 0 || rows <= 0 || rows_per_task <= 0 || in == out) return hipErrorInvalidValue;
     if (math != kMathTol) return hipErrorInvalidValue;
@@ -1282,7 +1286,8 @@ hipError_t launch_jacobi_fused_2d(const float *in, float *out, const uint32_t *m
     a.out = out;
     a.maskw = maskw;
     a.maskf = nullptr;
-    a.check_lo = a.check_hi = 0;
+    a.check_lo = check_begin < 0 ? 0 : check_begin;
+    a.check_hi = check_begin < 0 ? rows : check_end;
     a.delta_bits = delta_bits;
     a.rows = rows;
     a.pitch = pitch;

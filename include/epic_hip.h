@@ -44,12 +44,12 @@ int epic_hip_timed_sweeps_gpu(EpicHarmonicT *harmonic, unsigned int sweeps, unsi
 
 /* How many iterations one kernel launch of a batch of PLAIN (unchecked) iterations advances in the current configuration:
  * 2 where pairs of iterations run as one fused pass over the data -- Jacobi with the tol math (two sweeps, 4 B of HBM
- * traffic per cell-update instead of 8) and red-black with any math (both colours), 2-D grids of at least
- * 4 Mcell with activity tracking off (per device in multi-device mode, between exchanges); results are bit-identical to single iterations, an odd iteration and
+ * traffic per cell-update instead of 8) and red-black with any math (both colours), 2-D grids from the size at which the pass beats
+ * the other kernel families (tol Jacobi 1.5 Mcell, tol red-black 2 Mcell, precise red-black 5.5 Mcell; EPIC_HIP_FUSE_MIN_CELLS) with activity tracking off (per device in multi-device mode, between exchanges); results are bit-identical to single iterations, an odd iteration and
  * every check iteration run singly -- 1 otherwise, 0 without device state.  EPIC_HIP_NO_FUSE=1 switches the fusion off. */
 int epic_hip_iterations_per_pass(EpicHarmonicT *harmonic);
 
-/* Small 2-D grids (at most 3 Mcell, one device, activity tracking off -- the maps the reference's callers relax): the plain
+/* Small 2-D grids (at most 3 Mcell -- less where another family is faster: EPIC_HIP_TILE_MAX_CELLS --, one device, activity tracking off -- the maps the reference's callers relax): the plain
  * iterations between two checks run SEVERAL PER LAUNCH on tiles that stay in LDS with that many ghost rings
  * (epic_amd/csrc/kernels_tile2d.hip); bit-identical to single iterations.  Returns the iterations one such launch advances
  * (8, 10, 12, 14 or 16, chosen per grid by a cost model of the launch; 1 to 27 when EPIC_HIP_TILE_HALO fixes it), 0 where the path

@@ -208,6 +208,7 @@ int main(int argc, char **argv)
          {{"EPIC_HIP_DEVICES", "0,1,2,3"}, {"EPIC_HIP_THREADS", "0"}, {"EPIC_HIP_HALO", "2"}, {"FAKE_NO_PEER_CAPABLE", "1"}}},
         {"plugin, 2-D, devices 0,2 with staging forced, issuing threads", {64, 40}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_DEVICES", "0,2"}, {"EPIC_HIP_NO_PEER", "1"}}},
         {"plugin, 2-D, ONE device, the caller's current device is 2", {20, 30}, 1e-3f, 10, seq_plugin, {{"FAKE_CURRENT_DEVICE", "2"}}},
+        {"plugin, 2-D, devices 1,3, tracked pairs per slab", {60, 300}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_DEVICES", "1,3"}, {"EPIC_HIP_TRACK", "1"}, {"EPIC_HIP_FUSE_MIN_CELLS", "0"}, {"EPIC_HIP_HALO", "4"}}},
         {"node, 2-D, slabs on 0,1 while the caller's current device is 3", {32, 20}, 1e-3f, 4, seq_node, {{"EPIC_HIP_DEVICES", "0,1"}, {"FAKE_CURRENT_DEVICE", "3"}}},
     };
     std::vector<Scenario> scenarios = {
@@ -236,6 +237,9 @@ int main(int argc, char **argv)
         {"plugin, 3-D, two slabs of planes", {12, 6, 7}, 1e-3f, 5, seq_plugin, {{"EPIC_HIP_DEVICES", "0,0"}, {"EPIC_HIP_THREADS", "0"}}},
         {"plugin, 2-D, four slabs, issuing threads", {64, 40}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_DEVICES", "0,0,0,0"}, {"EPIC_HIP_HALO", "4"}}},
         {"node, 2-D, three slabs, issuing threads, work lists", {48, 300}, 1e-3f, 4, seq_node, {{"EPIC_HIP_DEVICES", "0,0,0"}, {"EPIC_HIP_TRACK", "1"}}},
+        {"plugin, 2-D, three slabs, tracked pairs per slab, caller's thread", {60, 300}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_DEVICES", "0,0,0"}, {"EPIC_HIP_THREADS", "0"}, {"EPIC_HIP_TRACK", "1"}, {"EPIC_HIP_FUSE_MIN_CELLS", "0"}, {"EPIC_HIP_HALO", "4"}}},
+        {"plugin, 2-D, two slabs, tracked tol pairs, staged halos, odd count", {40, 300}, 1e-3f, 7, seq_plugin, {{"EPIC_HIP_DEVICES", "0,0"}, {"EPIC_HIP_THREADS", "0"}, {"EPIC_HIP_TRACK", "1"}, {"EPIC_HIP_FUSE_MIN_CELLS", "0"}, {"EPIC_HIP_MATH", "tol"}, {"EPIC_HIP_NO_PEER", "1"}, {"EPIC_HIP_HALO", "3"}}},
+        {"node ticks, 2-D, two slabs, tracked pairs, issuing threads", {48, 300}, 1e-9f, 100, seq_node_ticks, {{"EPIC_HIP_DEVICES", "0,0"}, {"EPIC_HIP_TRACK", "1"}, {"EPIC_HIP_FUSE_MIN_CELLS", "0"}, {"EPIC_HIP_HALO", "4"}}},
     };
     // host logic of the small-grid path: whatever the grid and the ring depth, the tiles cover the grid, fit the LDS tile and
     // leave at least two owned rows and columns; a plan that cannot be made says so (halo == 0)

@@ -355,14 +355,14 @@ hipError_t launch_wake_tile_range(const Activity *next, size_t, int, int, hipStr
     return hipSuccess;
 }
 hipError_t launch_rb_fused_2d(const float *in, float *out, const uint32_t *maskw, int, int, int, int, int, hipStream_t s, const uint32_t *maskf, const Activity *act,
-                              unsigned *delta)
+                              unsigned *delta, int, int)
 {
     FAKE_LAUNCH("launch_rb_fused_2d");
     check_launch("launch_rb_fused_2d", s, {in, out, maskw, maskf, delta, act ? act->list_out : nullptr});
     return hipSuccess;
 }
 hipError_t launch_jacobi_fused_2d(const float *in, float *out, const uint32_t *maskw, int, int, int, int, hipStream_t s, int, const uint32_t *maskf, const Activity *act,
-                                  unsigned *delta)
+                                  unsigned *delta, int, int)
 {
     FAKE_LAUNCH("launch_jacobi_fused_2d");
     check_launch("launch_jacobi_fused_2d", s, {in, out, maskw, maskf, delta, act ? act->list_out : nullptr});

@@ -37,6 +37,30 @@ def test_every_declared_symbol_is_exported():
     assert not missing, missing
 
 
+def test_only_the_boundary_is_exported():
+    """`nm -D --defined-only libepic.so` lists the declared harmonic_* / epic_hip_* entry points and NOTHING else (round 6:
+    epic_amd/csrc/libepic.map) -- no mangled C++ of the host driver, no kernel launchers, no template instances of the standard library
+    in a library that is loaded into other people's processes -- under the reference's soname."""
+    import shutil
+    import subprocess
+
+    if shutil.which("nm") is None or shutil.which("readelf") is None:
+        pytest.skip("needs binutils")
+    out = subprocess.run(["nm", "-D", "--defined-only", eh.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = [line.split()[-1] for line in out.splitlines() if line.strip()]
+    stray = [n for n in names if not (n.startswith("harmonic_") or n.startswith("epic_hip_"))]
+    assert not stray, stray[:10]
+    assert len([n for n in names if n.startswith("harmonic_")]) == 30
+    declared = set()
+    for path in glob.glob(os.path.join(ROOT, "include", "**", "*.h"), recursive=True):
+        text = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        declared |= set(re.findall(r"\b((?:harmonic|epic_hip)_\w+)\s*\(", text))
+    assert sorted(names) == sorted(declared), sorted(set(names) ^ declared)
+    dyn = subprocess.run(["readelf", "-d", eh.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "soname: [libepic.so]" in dyn
+
+
 def test_reference_abi_symbols_present():
     """The hot-path subset of `nm -D libepic/lib/libepic.so`."""
     names = """harmonic_complete_cpu harmonic_update_cpu harmonic_update_and_check_cpu harmonic_complete_gpu

@@ -618,10 +618,17 @@ def test_redblack_fused_pairs_equal_the_checker(m, rpt):
         locked[idx] = 1
     lib = O.oracle()
     for k in (13, 14):
-        h = make(m, u0, locked)
-        gpu_init(h)
+        # (since round 6 the precise pass takes over from 5.5 Mcell, where it beats the single sweeps: asked for explicitly on these sizes)
+        saved = os.environ.get("EPIC_HIP_FUSE_MIN_CELLS")
+        os.environ["EPIC_HIP_FUSE_MIN_CELLS"] = "0"
+        try:
+            h = make(m, u0, locked)
+            gpu_init(h)
+        finally:
+            os.environ.pop("EPIC_HIP_FUSE_MIN_CELLS", None) if saved is None else os.environ.__setitem__("EPIC_HIP_FUSE_MIN_CELLS", saved)
         assert E.epic_hip_set_scheme(h, 1) == 0
         assert E.epic_hip_set_activity_tracking(h, 0) == 0   # the fused pass is the tracking-off path
+        assert E.epic_hip_iterations_per_pass(h) == 2
         if rpt:
             assert E.epic_hip_set_rows_per_task(h, rpt) == 0
         assert E.harmonic_update_and_check_gpu(h, NT) in (0, 1)

@@ -147,9 +147,9 @@ def test_measured_task_height_of_the_fused_passes_changes_nothing_but_time(math,
     pair of plain iterations is enqueued past the first min(rows, cols) / 2 iterations (driver_plan.hip: tune_fused_rows):
     every candidate runs from the current buffer into the other one.  The field, the delta and the iteration count must be
     what the rule's height (EPIC_HIP_TUNE=0) gives, and the height in use afterwards is the rule's or one of the candidates."""
-    m = [2048, 2100]
+    m = [2600, 2300]                                    # 6 Mcell: above the size from which every arithmetic takes its fused pass (precise: 5.5 Mcell)
     u0, locked = with_extra_goals(m, 31, 0.05)
-    k = 1400                                            # the tuner runs at the first batch that starts past iteration 1024
+    k = 1400                                            # the tuner runs at the first batch that starts past iteration 1150
 
     def run(tune):
         if tune:
@@ -413,6 +413,38 @@ def test_tol_complete_gpu_equals_the_checkers_loop_bit_for_bit(goldens, name, sc
         assert np.array_equal(h.u_array().ravel(), p.u)
     finally:
         lib.oracle_tol_set_finish(1)
+
+
+CAMPAIGN_SAMPLE = [("dense", 1407), ("dense", 1400), ("maze", 1103), ("rooms", 1004), ("corridor", 1206), ("labyrinth", 1600), ("office", 1506),
+                   ("sparse", 1300)]
+
+
+@pytest.mark.parametrize("family,seed", CAMPAIGN_SAMPLE)
+@pytest.mark.parametrize("devices", [None, "0,0,0"])
+def test_the_campaigns_maps_on_the_device_equal_the_checkers_loop(family, seed, devices, tol_env, monkeypatch):
+    """tests/tol_campaign.py puts a miss rate behind the tol mode's parity with the CHECKER's statement of the loop (CPU: the tol
+    iteration, the hand-over, the reference's own finishing iterations) against harmonic_complete_cpu.  That is a statement about the
+    device only because the device's loop IS the checker's: a sample of the campaign's generated maps -- among them the ones that
+    changed the hand-over rule in round 6 (a check that is already clearly below epsilon ends the loop itself) -- through
+    harmonic_complete_gpu at the campaign's three epsilons and both schemes, on one device and on three slabs: field, iteration count,
+    delta and the iteration of the hand-over at tolerance 0."""
+    import tol_campaign as TC
+    from conftest import scheme_env
+
+    m, u0, locked = TC.make_case(family, seed)
+    if devices:
+        monkeypatch.setenv("EPIC_HIP_DEVICES", devices)
+    lib = O.oracle()
+    lib.oracle_tol_last_finish_from.restype = ct.c_uint
+    for eps in TC.EPSILONS:
+        for scheme in TC.SCHEMES:
+            p = O.Problem(m, u0, locked, eps, 100)
+            assert lib.oracle_tol_complete(ct.byref(p.h), 0 if scheme == "jacobi" else 1) == 0
+            with scheme_env(scheme):
+                h = make(m, u0, locked, eps, 100)
+                assert E.harmonic_complete_gpu(h, NT) == 0
+            assert h.currentIteration == p.h.currentIteration and np.float32(h.delta) == np.float32(p.h.delta), (eps, scheme)
+            assert np.array_equal(h.u_array().ravel(), p.u), (eps, scheme)
 
 
 def _tol_map_run(goldens, name, record_property, iteration_slack=0.02):

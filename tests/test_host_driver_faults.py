@@ -88,7 +88,7 @@ def test_distinct_devices_keep_the_runtimes_device_rules(tmp_path):
     assert "fault driver: ok" in run.stdout
     for bad in ("AddressSanitizer", "LeakSanitizer", "runtime error", "EXPECT failed"):
         assert bad not in run.stderr, tail
-    assert run.stdout.count("fallible runtime calls") == 10, tail          # ten device scenarios ran
+    assert run.stdout.count("fallible runtime calls") == 11, tail          # eleven device scenarios ran
 
 
 def test_the_device_model_catches_a_driver_that_forgets_a_device(tmp_path):
