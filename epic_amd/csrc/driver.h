@@ -179,6 +179,13 @@ struct Ctx {
     // 2 the fused pass's.
     Track trk_f;
     int last_lists = 0;
+    // The work lists of a red-black run say which tiles the NEXT colour has to recompute.  A caller may renumber its iterations
+    // (currentIteration is its field): if the iteration about to run has the colour of the one that ran last, those lists are for
+    // the wrong colour -- that iteration changes nothing, lists nothing, and its successor would find every tile at rest although the
+    // cells it reads have moved.  seq_next = the iteration number the lists in force expect next (note_iterations, driver_enqueue.hip);
+    // found by the script fuzz of round 6 (caller-set iteration numbers under EPIC_HIP_TRACK=1).
+    unsigned seq_next = 0;
+    bool seq_valid = false;
     int pair_rows = 0;             // task height of the tracked pass in use (0: not chosen yet); see rb_pairs_choose_rows
     static constexpr size_t kL = Track::kL, kCS = Track::kCS;
     // Work accounting (epic_hip_work_done): whole-grid iterations' worth of cells recomputed since the last reset.  Launches
@@ -293,6 +300,7 @@ bool bypass_lists_for_batch(Ctx *c, bool pairs = false);
 const char *plain_batch_path(const Ctx *c);     // the kernel family a batch of plain iterations takes now (epic_hip_config_dump)
 
 // ---- driver_enqueue.hip -------------------------------------------------------------------------------------------------
+void note_iterations(Ctx *c, unsigned first, unsigned count);   // iterations [first, first + count) are about to be enqueued (see Ctx::seq_next)
 hipError_t enqueue_sweep(Ctx *c, bool check, unsigned iteration);
 void fold_listed_work(Ctx *c);
 void drop_graphs(Ctx *c);  // captured launch sequences hold the buffer addresses: drop them whenever a buffer goes away

@@ -4,10 +4,27 @@
 
 namespace epic_drv {
 
+// Iterations [first, first + count) are about to be enqueued.  With work lists and the red-black scheme the lists in force were made for
+// the colour of iteration seq_next; another colour (the caller has renumbered its iterations) makes them void: every tile runs.
+static void expect_iteration(Ctx *c, unsigned first)
+{
+    if (c->track && c->redblack && c->seq_valid && ((first ^ c->seq_next) & 1u)) {
+        force_all(c);
+        c->seq_valid = false;
+    }
+}
+void note_iterations(Ctx *c, unsigned first, unsigned count)
+{
+    expect_iteration(c, first);
+    c->seq_next = first + count;
+    c->seq_valid = true;
+}
+
 hipError_t enqueue_sweep(Ctx *c, bool check, unsigned iteration)
 {
     if (c->n == 4) return hipSuccess;   // the reference's empty n == 4 branch: nothing is swept, the caller counts
     if (c->multi()) return multi_sweep(c, check, iteration);
+    note_iterations(c, iteration, 1);
     hipError_t e;
     if (check) {
         e = hipMemsetAsync(c->d_delta, 0, sizeof(unsigned), c->stream);
@@ -165,6 +182,7 @@ hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first, bool check_
 // device delta word is zeroed and filled).  bypass: without the lists (every tile; the untracked pass's own task height).
 hipError_t enqueue_rb_pairs_tracked(Ctx *c, unsigned npairs, unsigned first, bool check_last, bool bypass)
 {
+    note_iterations(c, first, 2 * npairs);
     const bool tol = c->math == 4;
     const int rpt = !bypass ? rb_pairs_rows_per_task(c) : tol ? jacobi_fused_rows_per_task(c) : fused_rows_per_task(c);
     const size_t tiles = epic_hip::rb_fused_2d_tiles(c->rows, c->pitch, rpt);
@@ -195,6 +213,7 @@ hipError_t enqueue_rb_pairs_tracked(Ctx *c, unsigned npairs, unsigned first, boo
 hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first, bool check_last)
 {
     if (c->n == 4) return enqueue_plain_run(c, count, first, check_last);
+    expect_iteration(c, first);   // (before the decision to replay a captured sequence: a forced iteration is never replayed)
     const bool small = (long long)c->rows * c->pitch <= (1ll << 22);
     const bool no_graph = c->cfg.no_graph;
     // a captured sequence bakes in the work-list buffers and list mode: run eagerly until the forced iterations are over
@@ -244,6 +263,8 @@ hipError_t enqueue_plain_batch(Ctx *c, unsigned count, unsigned first, bool chec
         c->graphs_broken = true;
         return enqueue_plain_run(c, count, first, check_last);
     }
+    c->seq_next = first + count + (check_last ? 1u : 0u);   // (the replayed launches did not pass through note_iterations)
+    c->seq_valid = true;
     c->cur ^= it->second.cur_flip;
     c->work_full += it->second.work;
     if (check_last) c->tile_delta_n = it->second.tile_delta_n;

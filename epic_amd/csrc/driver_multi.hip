@@ -416,6 +416,7 @@ hipError_t multi_run(Ctx *c, unsigned count, unsigned first, bool check_first)
     const bool fuse_rb = !tracked && c->redblack && c->n == 2 && c->math != 4 && !c->cfg.no_fuse && (long long)c->rows * c->pitch >= (1ll << 22);
     const bool fuse = !tracked && (fuses_tol(c) || fuse_rb);
     const int rpt_track = c->n == 2 ? auto_rows_per_task(c) : 32;
+    note_iterations(c, first, count);
     if (tracked) {   // (as enqueue_sweep: fused passes have run since these lists were made -> one iteration over every tile)
         if (c->last_lists == 2)
             for (auto &sl : c->slabs) sl.trk.force = std::max(sl.trk.force, 1);
@@ -583,6 +584,7 @@ hipError_t multi_run_pairs(Ctx *c, unsigned npairs, unsigned first, bool check_l
 {
     const int G = c->halo;
     if (c->n != 2 || G < 2) return hipErrorInvalidValue;
+    note_iterations(c, first, 2 * npairs);
     const bool tol = c->math == 4;
     const int rpt = rb_pairs_rows_per_task(c);
     const int nstrips_f = (c->pitch + 247) / 248;

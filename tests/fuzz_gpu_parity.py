@@ -221,7 +221,12 @@ def draw_script(rng, m, big):
         elif r < 0.82 and len(m) == 2:
             n = int(rng.integers(1, 9))
             v = np.stack([rng.integers(0, m[1] + 2, n), rng.integers(0, m[0] + 2, n)], axis=1).astype(np.uint32)
-            ops.append(("e", np.ascontiguousarray(v), rng.integers(0, 4, n).astype(np.uint32)))
+            t = rng.integers(0, 4, n).astype(np.uint32)
+            # (one edit per cell and call: the reference's device scatter is one thread per edit -- harmonic_utilities_gpu.cu:38-64 --, two
+            #  edits of one cell in one call race there as here; its CPU form applies them in order)
+            _, keep = np.unique(v[:, 1].astype(np.int64) * (m[1] + 2) + v[:, 0], return_index=True)
+            keep.sort()
+            ops.append(("e", np.ascontiguousarray(v[keep]), np.ascontiguousarray(t[keep])))
         elif r < 0.94:
             ops.append("r")
         else:

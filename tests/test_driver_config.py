@@ -44,8 +44,8 @@ def test_defaults_are_the_librarys(harness):
     c, k = run(harness)
     assert c["math"] == 0 and c["scheme"] == "redblack" and c["track_mode"] == 2 and c["rows_per_task"] == 0      # the reference's iteration, bit-exact
     assert c["devices"] == "" and c["halo"] == 0 and c["threads"] is True and c["spin_us"] == 20 and c["no_peer"] is False
-    assert c["no_fuse"] is False and c["no_graph"] is False and c["fuse_min_cells"] == 1 << 22 and c["tune"] is True
-    assert c["tile"] is True and c["tile_max_cells"] == 3 << 20 and c["tile_pipeline"] is True and c["track_pairs"] is True
+    assert c["no_fuse"] is False and c["no_graph"] is False and c["fuse_min_cells"] == -1 and c["tune"] is True      # -1: by arithmetic and scheme (driver_plan.hip)
+    assert c["tile"] is True and c["tile_max_cells"] == -1 and c["tile_pipeline"] is True and c["track_pairs"] is True and c["defer"] is True
     assert c["track_switch"] == -1 and c["tol_finish"] == -1 and c["tol_finish_factor"] == 0
     assert k == {"flags": 7, "list_waves": 0, "pair3d": 1, "pair3d_rows": 0, "march_x0": 0}
 
@@ -54,14 +54,14 @@ def test_every_knob_is_parsed(harness):
     c, k = run(harness, EPIC_HIP_MATH="tol", EPIC_HIP_SCHEME="jacobi", EPIC_HIP_TRACK="1", EPIC_HIP_ROWS_PER_TASK="12", EPIC_HIP_DEVICES="0,1,1,3",
                EPIC_HIP_HALO="5", EPIC_HIP_NO_PEER="1", EPIC_HIP_THREADS="0", EPIC_HIP_SPIN_US="0", EPIC_HIP_NO_FUSE="1", EPIC_HIP_NO_GRAPH="1",
                EPIC_HIP_FUSE_MIN_CELLS="0", EPIC_HIP_FUSED_ROWS="33", EPIC_HIP_TUNE="0", EPIC_HIP_TILE="0", EPIC_HIP_TILE_MAX_CELLS="1000",
-               EPIC_HIP_TILE_ROWS="7", EPIC_HIP_TILE_WIDTH="128", EPIC_HIP_TILE_HALO="9", EPIC_HIP_TILE_PIPELINE="0", EPIC_HIP_TRACK_PAIRS="0",
+               EPIC_HIP_TILE_ROWS="7", EPIC_HIP_TILE_WIDTH="128", EPIC_HIP_TILE_HALO="9", EPIC_HIP_TILE_PIPELINE="0", EPIC_HIP_DEFER="0", EPIC_HIP_TRACK_PAIRS="0",
                EPIC_HIP_TRACK_PAIR_ROWS="6", EPIC_HIP_TRACK_SWITCH="0.5", EPIC_HIP_TOL_FINISH="0", EPIC_HIP_TOL_FINISH_FACTOR="30",
                EPIC_HIP_FLAGS="2", EPIC_HIP_LIST_WAVES="512", EPIC_HIP_3D_PAIR="0", EPIC_HIP_3D_PAIR_ROWS="20", EPIC_HIP_3D_MARCH="x0")
     assert c["math"] == 4 and c["scheme"] == "jacobi" and c["track_mode"] == 1 and c["rows_per_task"] == 12 and c["devices"] == "0,1,1,3"
     assert c["halo"] == 5 and c["no_peer"] is True and c["threads"] is False and c["spin_us"] == 0 and c["no_fuse"] is True and c["no_graph"] is True
     assert c["fuse_min_cells"] == 0 and c["fused_rows"] == 33 and c["tune"] is False and c["tile"] is False and c["tile_max_cells"] == 1000
     assert (c["tile_rows"], c["tile_width"], c["tile_halo"]) == (7, 128, 9) and c["tile_pipeline"] is False and c["track_pairs"] is False
-    assert c["track_pair_rows"] == 6 and c["track_switch"] == 0.5 and c["tol_finish"] == 0 and c["tol_finish_factor"] == 30
+    assert c["track_pair_rows"] == 6 and c["track_switch"] == 0.5 and c["tol_finish"] == 0 and c["tol_finish_factor"] == 30 and c["defer"] is False
     assert k == {"flags": 2, "list_waves": 512, "pair3d": 0, "pair3d_rows": 20, "march_x0": 1}
     assert (c["flags"], c["list_waves"], c["pair3d"], c["pair3d_rows"], c["march_x0"]) == (2, 512, False, 20, True)
 
@@ -75,3 +75,12 @@ def test_values_out_of_range_fall_back(harness):
     assert c["devices"] == "0,x"
     c, _ = run(harness, EPIC_HIP_SPIN_US="99999999")   # ... and a spin is never longer than 0.1 s
     assert c["spin_us"] == 100000
+
+
+def test_whatever_the_environment_holds_the_dump_stays_one_json_object(harness):
+    """EPIC_HIP_DEVICES is the caller's text and is echoed in the dump: quotes and backslashes are escaped, control characters blanked, a
+    very long value clipped (round 6; until then a fixed buffer truncated the object and a quote broke it -- bench.py parses this)."""
+    nasty = '0,"1\\' + "\t" + "x" * 5000
+    c, _ = run(harness, EPIC_HIP_DEVICES=nasty)
+    assert c["devices"].startswith('0,"1\\ x') and len(c["devices"]) == 256
+    assert c["math"] == 0 and c["march_x0"] is False       # the fields behind the text are all there

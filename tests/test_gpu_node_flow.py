@@ -218,6 +218,44 @@ def test_teardown_in_every_order_with_iterations_pending(env):
         assert not h.d_m and not h.d_u and not h.d_locked and not h.d_delta
 
 
+@pytest.mark.parametrize("m,pairs", [([337, 299], "0"), ([337, 299], None), ([16, 24, 121], None)])
+@pytest.mark.parametrize("math", [eh.MATH_PRECISE, eh.MATH_TOL])
+def test_a_caller_that_renumbers_its_iterations_with_work_lists_on(m, pairs, math, env):
+    """currentIteration is the caller's field, and the colour of a red-black iteration is its number's parity.  With work lists the lists
+    in force were made for the colour that was to come next; a caller that renumbers so that one colour runs twice in a row used to get an
+    empty list for the iteration after (nothing had changed in the repeated colour) and a field that stood still -- found by the script
+    fuzz of round 6 (seed 61, cases 373, 564, 572, 591), fixed by epic_amd/csrc/driver_enqueue.hip: note_iterations.  Checked against
+    the checker here, which takes the parity from the number like the reference (harmonic_cpu.cpp:46-51)."""
+    env(EPIC_HIP_TRACK="1", EPIC_HIP_FUSE_MIN_CELLS="0", EPIC_HIP_TILE="0", EPIC_HIP_TRACK_PAIRS=pairs, EPIC_HIP_TRACK_SWITCH="2")
+    u0, locked = synthetic_grid(m, 17, 0.05)
+    h = make(m, u0, locked)
+    gpu_init(h)
+    assert E.epic_hip_set_math_mode(h, math) == 0 and E.epic_hip_set_scheme(h, eh.SCHEME_REDBLACK) == 0
+    p = O.Problem(m, u0, locked)
+    lib = O.oracle()
+
+    def steps(n, check):
+        for i in range(n):
+            last = check and i == n - 1
+            assert (E.harmonic_update_and_check_gpu if last else E.harmonic_update_gpu)(h, NT) in (0, 1)
+        if math == eh.MATH_TOL:
+            assert lib.oracle_tol_run(ct.byref(p.h), n, 1) == 0
+        else:
+            for i in range(n):
+                (lib.oracle_update_and_check if check and i == n - 1 else lib.oracle_update)(ct.byref(p.h))
+
+    steps(21, True)
+    for renumber in (70, 71, 1000, 3):        # same colour again, the other colour, and back
+        h.currentIteration = renumber
+        p.h.currentIteration = renumber
+        steps(2, True)
+        assert float(h.delta) == float(p.h.delta), renumber
+        steps(5, False)
+        assert E.harmonic_get_potential_values_gpu(h) == 0
+        assert np.array_equal(h.u_array().ravel(), p.u), renumber
+    gpu_fini(h)
+
+
 def test_update_without_state_is_refused_and_counts_nothing():
     m = [16, 16]
     u0, locked = synthetic_grid(m, 1, 0.0)

@@ -40,6 +40,8 @@ struct Args {
     float *sink;
     int steps;
     int mode;              // 0 grid, 1 neighbour, 2 no synchronisation (the work alone)
+    int lean;              // 1: rings and flags live in UNCACHED device memory (hipDeviceMallocUncached): no L2 write-back / invalidate around the
+                           //    exchange -- the stores are waited for (s_waitcnt) and the flag is a relaxed store; the consumer's loads bypass the caches
 };
 
 __global__ __launch_bounds__(kThreads) void persistent_kernel(Args a)
@@ -55,21 +57,27 @@ __global__ __launch_bounds__(kThreads) void persistent_kernel(Args a)
     for (int s = 1; s <= a.steps; s++) {
         // publish this step's ring (what a tile's owned boundary cells would be)
         float *mine = a.rings + ((size_t)b * 2 + (s & 1)) * kRingWords;
-        for (int i = t; i < kRingWords; i += kThreads) mine[i] = acc + (float)(s + i);
-        __threadfence();
+        if (a.lean) {
+            for (int i = t; i < kRingWords; i += kThreads) __builtin_nontemporal_store(acc + (float)(s + i), mine + i);
+            __builtin_amdgcn_s_waitcnt(0);   // this thread's stores have left for the fabric
+        } else {
+            for (int i = t; i < kRingWords; i += kThreads) mine[i] = acc + (float)(s + i);
+            __threadfence();
+        }
         __syncthreads();
         if (t == 0 && a.mode != 2) {
             unsigned polls = 0;
+            const int order_ld = a.lean ? __ATOMIC_RELAXED : __ATOMIC_ACQUIRE;
             if (a.mode == 0) {
-                atomicAdd(a.counter, 1u);
+                __hip_atomic_fetch_add(a.counter, 1u, a.lean ? __ATOMIC_RELAXED : __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned want = (unsigned)s * kBlocks;
-                while (__hip_atomic_load(a.counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                while (__hip_atomic_load(a.counter, order_ld, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     if (++polls > kMaxPolls || __hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { bail = 1; break; }
                 }
             } else {
-                __hip_atomic_store(a.flags + b * 16, (unsigned)s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.flags + b * 16, (unsigned)s, a.lean ? __ATOMIC_RELAXED : __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 for (int k = 0; k < 4 && !bail; k++)
-                    while (__hip_atomic_load(a.flags + nb[k] * 16, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)s) {
+                    while (__hip_atomic_load(a.flags + nb[k] * 16, order_ld, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)s) {
                         if (++polls > kMaxPolls || __hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { bail = 1; break; }
                     }
             }
@@ -119,9 +127,20 @@ int main()
     printf("%d CUs; %d workgroups x %d threads, %d B of ring data per workgroup and step\n", cus, kBlocks, kThreads, kRingWords * 4);
     const int steps = 4000;
     a.steps = steps;
+    a.lean = 0;
+    // the lean variant's memory: uncached (fine-grained) device memory
+    unsigned *u_counter = nullptr, *u_flags = nullptr;
+    float *u_rings = nullptr;
+    const bool have_uncached = hipExtMallocWithFlags((void **)&u_counter, 256, hipDeviceMallocUncached) == hipSuccess &&
+                               hipExtMallocWithFlags((void **)&u_flags, kBlocks * 64, hipDeviceMallocUncached) == hipSuccess &&
+                               hipExtMallocWithFlags((void **)&u_rings, (size_t)kBlocks * 2 * kRingWords * sizeof(float), hipDeviceMallocUncached) == hipSuccess;
+    if (!have_uncached) { (void)hipGetLastError(); printf("(no uncached device memory here: the lean variant is skipped)\n"); }
     const char *names[3] = {"persistent kernel, grid-wide barrier (one counter)", "persistent kernel, four neighbour flags", "persistent kernel, no synchronisation (work only)"};
-    for (int mode : {2, 0, 1, 0, 1}) {
+    for (int run = 0; run < (have_uncached ? 10 : 5); run++) {
+        const int mode = (const int[]){2, 0, 1, 0, 1}[run % 5];
         a.mode = mode;
+        a.lean = run >= 5;
+        if (run == 5) { a.counter = u_counter; a.flags = u_flags; a.rings = u_rings; }
         CHECK(hipMemsetAsync(a.counter, 0, 256, st));
         CHECK(hipMemsetAsync(a.flags, 0, kBlocks * 64, st));
         CHECK(hipMemsetAsync(a.error, 0, 256, st));
@@ -134,7 +153,8 @@ int main()
         unsigned err = 0;
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         CHECK(hipMemcpy(&err, a.error, 4, hipMemcpyDeviceToHost));
-        printf("%-58s %8.3f us per step%s\n", names[mode], ms * 1e3 / steps, err ? "   (BAILED OUT: a spin ran into its bound)" : "");
+        printf("%-58s %s %8.3f us per step%s\n", names[mode], a.lean ? "[uncached memory, relaxed flags]" : "[release / acquire]            ", ms * 1e3 / steps,
+               err ? "   (BAILED OUT: a spin ran into its bound)" : "");
     }
     // the launch boundary it would replace: one kernel per step, eagerly and from a captured graph
     for (int graph = 0; graph < 2; graph++) {
