@@ -340,7 +340,7 @@ def live_traffic(args):
     child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "1", "--develop", "5000",
              "--size", str(args.size), "--stagger", str(args.stagger), "--math", args.math, "--scheme", args.scheme,
              "--rows-per-task", str(args.rows_per_task), "--no-cpu", "--no-relax", "--no-extra-legs", "--no-parity",
-             "--no-live-traffic"] + (["--track"] if args.track else [])
+             "--no-maps", "--no-node-flow", "--no-live-traffic"] + (["--track"] if args.track else [])
     env = dict(os.environ, TMPDIR="/tmp")
     try:
         # The library measures that height by timing, which a counter pass distorts.  So one plain child first, to learn the
@@ -511,6 +511,18 @@ def self_launch(args):
     return rc
 
 
+T_START = time.perf_counter()
+LEG_SECONDS = {}   # wall seconds per leg of this run, reported in the line (`leg_seconds`): where a default run's minutes go
+
+
+def timed_leg(name, fn, *a, **kw):
+    t0 = time.perf_counter()
+    try:
+        return fn(*a, **kw)
+    finally:
+        LEG_SECONDS[name] = round(time.perf_counter() - t0, 1)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.in_library_child:
@@ -520,7 +532,9 @@ def main():
     live, live_note = {}, "not measured in this run"
     if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and not args.no_live_traffic and not args.in_library_child
             and not args.slab):
+        _t_live = time.perf_counter()
         live, live_note = live_traffic(args)   # child processes, before anything here initialises the GPU
+        LEG_SECONDS["live_traffic (rocprofv3 --pmc child passes)"] = round(time.perf_counter() - _t_live, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1077,6 +1091,8 @@ def main():
                 "frac": round(BYTES_PER_CELL_SWEEP * cells_per_launch / (single_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
                 "note": "sweep2d_kernel, one iteration per launch (EPIC_HIP_NO_FUSE=1), same arithmetic, same field, same run"}
         assert E.harmonic_uninitialize_gpu(h) == 0
+        LEG_SECONDS["imports, grid, develop, timed steps, kernel batches"] = round(time.perf_counter() - T_START - sum(LEG_SECONDS.values()), 1)
+        _t_relax = time.perf_counter()
         relaxed = {}   # converged 8192^2 fields of this run, for the parity object
         if not args.no_relax:
             # the complete relaxation, exactly as the plugin runs it (harmonic_execute_gpu), from the initial state: the
@@ -1132,6 +1148,7 @@ def main():
                     relaxed[key] = h.u_array().ravel().copy()
             assert E.epic_hip_set_math_mode(h, MODES[args.math]) == 0
         abi_release(h)
+        LEG_SECONDS["relax legs (whole 8192^2 relaxations)"] = round(time.perf_counter() - _t_relax, 1)
         if not args.no_extra_legs and args.math != "precise":
             # the bit-exact mode on the same workload, same box, same run: what the tol arithmetic buys
             hp, _ = abi_setup(grid, u0, locked, "precise", args.scheme, args.track)
@@ -1141,17 +1158,19 @@ def main():
             out.setdefault("kernels", {})["precise"] = {"launch_us": round(pl, 3), "frac": round(BYTES_PER_CELL_SWEEP * cells_per_launch / (pl * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
                                           "note": "default math mode of the library: expf/logf bit-identical to glibc, f64; same grid, scheme and run"}
         if not args.no_extra_legs:
-            out["config5"] = config5_leg()
+            out["config5"] = timed_leg("config5", config5_leg)
         if not args.no_extra_legs and not args.no_config4:
-            out["config4"] = config4_leg()
+            out["config4"] = timed_leg("config4", config4_leg)
         if not args.no_maps:
-            out["maps"] = maps_leg()
+            out["maps"] = timed_leg("maps", maps_leg)
         if not args.no_node_flow:
-            out["node_flow"] = node_flow_leg(("8192^2" if n == 8192 else "%d^2" % n, grid, u0, locked))
+            out["node_flow"] = timed_leg("node_flow", node_flow_leg, ("8192^2" if n == 8192 else "%d^2" % n, grid, u0, locked))
         if not args.no_parity:
-            out["parity"] = parity_object(args, E, MODES, relaxed, locked)
+            out["parity"] = timed_leg("parity", parity_object, args, E, MODES, relaxed, locked)
         if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(grid, u0, locked, args.cpu_half_sweeps, free_by_colour)
+            out["cpu_baseline"] = timed_leg("cpu_baseline", cpu_baseline, grid, u0, locked, args.cpu_half_sweeps, free_by_colour)
+        LEG_SECONDS["whole run"] = round(time.perf_counter() - T_START, 1)
+        out["leg_seconds"] = dict(LEG_SECONDS)
         summarise_into_config(out)
         print(json.dumps(out), flush=True)
         return

@@ -354,7 +354,10 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
     result = EPIC_SUCCESS;
     // what follows every check iteration (result and harmonic->delta are the check's)
     auto after_check = [&] {
-        if (finish_wanted && !finish.on && harmonic->delta < finish_below) {
+        // (not at the FIRST check of a run that has not moved yet: a red-black iteration 0 whose colour has no cell next to a goal reports
+        //  delta = 0 exactly -- the 512^3 benchmark grid does --, and handing over there ran the whole relaxation in the reference's
+        //  arithmetic: correct, and not what the mode is for; round 6)
+        if (finish_wanted && !finish.on && harmonic->delta < finish_below && !(harmonic->delta == 0.0f && handover.seen == 0)) {
             // A delta that has fallen by less than 0.3 % per check over the last 32 checks is a plateau on which the stop is decided
             // by single ulps of single cells: maps/trivial.png falls 0.12-0.4 % per 100 iterations, in steps of one ulp of |u| < 8
             // (at delta = 1e-5 = 21 ulp one step is 5 %, once in ~40 checks -- hence a window, not two successive checks).  There

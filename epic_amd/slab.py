@@ -543,7 +543,8 @@ class SlabSolver:
                 _, check = self.advance(2 if max_sweeps is None else max_sweeps - self.iteration)
                 result = (self.reduce_delta() < self.epsilon) if check else False
                 if check:
-                    if finish_wanted and not finishing and self.delta < finish_below:
+                    # (not at the first check of a run that has not moved yet: delta == 0 exactly -- harmonic_execute_gpu's rule, round 6)
+                    if finish_wanted and not finishing and self.delta < finish_below and not (self.delta == 0.0 and last_check < 0.0):
                         # (at the callers' epsilons this check keeps its verdict: harmonic_execute_gpu's rule, round 6)
                         finishing, result = True, bool(result and np.float32(self.epsilon) > np.float32(1e-5))
                         be.math = 0

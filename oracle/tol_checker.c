@@ -277,7 +277,10 @@ int oracle_tol_complete(TolHarmonic *h, int scheme)
         if (check) {
             h->delta = d;
             converged = d < h->epsilon;
-            if (finish_on && d < finish_below) {   /* from here on: the reference's iteration, and only it may end the loop */
+            /* (not at the FIRST check of a run that has not moved yet: a red-black iteration 0 whose colour has no cell next to a goal
+             *  -- the 512^3 benchmark grid, 36 of the campaign's 315 red-black cases -- reports delta = 0 exactly, and handing over there ran
+             *  the whole relaxation in the reference's arithmetic: correct, and not what the mode is for.  Round 6.) */
+            if (finish_on && d < finish_below && !(d == 0.0f && seen == 0)) {   /* from here on: the reference's iteration, and only it may end the loop */
                 const float ago = seen >= kWindow ? recent[seen % kWindow] : -1.0f;
                 g_last_plateau = ago > 0.0f && d > 0.908f * ago;
                 g_last_finish_from = h->currentIteration;

@@ -10,16 +10,16 @@
 #   4. --kernel-trace --stats of whole relaxations with activity tracking (tools/time_relax.py): tol Jacobi, and the library
 #      default (precise, red-black) -- the list-driven kernels and the bypassed batches
 #   bash tools/profile_round.sh r03 3d      only the passes whose name contains "3d" (after a change to the 3-D kernel)
-TAG=${1:-r05}
+TAG=${1:-r06}
 ONLY=${2:-}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="$ROOT/bench.py --no-cpu --no-relax --no-extra-legs --no-parity --no-live-traffic"
+B="$ROOT/bench.py --no-cpu --no-relax --no-extra-legs --no-parity --no-live-traffic --no-node-flow"
 C="$ROOT/tools/bench_config.py --grid 512 512 512 --develop 1500"
 SQ="SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE"
-run() { name=$1; shift; case "$name" in *"$ONLY"*) ;; *) return 0;; esac; "$@" > "$OUT/$name.log" 2>&1; echo "[$name] rc=$?"; }
+run() { name=$1; shift; if [ -n "$ONLY" ] && ! [[ "$name" =~ $ONLY ]]; then return 0; fi; "$@" > "$OUT/$name.log" 2>&1; echo "[$name] rc=$?"; }   # ONLY: a regex over the pass names
 # the library measures the task height of its fused passes by timing, which counter passes distort: learn it from a plain run
 # and fix it for every 2-D tol pass of this script
 ROWS=$(python3 $B --steps 1 --warmup 1 --develop 5000 2>/dev/null | python3 -c 'import sys,json; print(json.loads(sys.stdin.read().strip().splitlines()[-1])["config"].get("fused_rows_per_task", 0))' 2>/dev/null)
@@ -35,6 +35,11 @@ run stats_relax_default  rocprofv3 --kernel-trace --stats --output-format csv -d
 #   5. (round 4) the reference's maps through harmonic_complete_gpu with the library's defaults: tile2d_kernel (several iterations per
 #      launch on LDS tiles) -- kernel stats, and the SQ counters of the same command
 M="$ROOT/tools/time_maps.py --modes default --tile 1 --repeat 1"
+#   6. (round 6) the navigation node's call loop on maze.png (tools/time_node_flow.py): the kernels the fine-grained API reaches with the
+#      deferred blocks, and with one launch per call (EPIC_HIP_DEFER=0)
+N="$ROOT/tools/time_node_flow.py --map maze --iterations 20000 --steps 50"
+run stats_node_flow  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_node_flow" -- python3 $N
+EPIC_HIP_DEFER=0 run stats_node_flow_undeferred  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_node_flow_undeferred" -- python3 $N
 run stats_maps  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_maps" -- python3 $M
 run sq_maps     rocprofv3 --pmc $SQ --output-format csv -d "$OUT/sq_maps" -- python3 $M --maps maze
 run fetch_tol   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_tol_jacobi" -- python3 $B --steps 1 --warmup 1 --develop 5000
@@ -59,6 +64,8 @@ $S stats "$OUT/stats_relax_tol" > "$OUT/${TAG}_kernel_stats_relax_tol_tracked.tx
 $S stats "$OUT/stats_relax_default" > "$OUT/${TAG}_kernel_stats_relax_default.txt"
 $S stats "$OUT/stats_relax_tol_rb" > "$OUT/${TAG}_kernel_stats_relax_tol_redblack.txt"
 $S stats "$OUT/stats_maps" > "$OUT/${TAG}_kernel_stats_maps_tiles.txt"
+$S stats "$OUT/stats_node_flow" > "$OUT/${TAG}_kernel_stats_node_flow_maze.txt"
+$S stats "$OUT/stats_node_flow_undeferred" > "$OUT/${TAG}_kernel_stats_node_flow_maze_undeferred.txt"
 PROFILE_KERNEL=tile2d $S sq "$OUT/sq_maps" 232324 > "$OUT/${TAG}_sq_counters_maze_tiles.txt" 2>&1
 PROFILE_LAST=90 PROFILE_KERNEL=jacobi_fused2d $S pmc "$OUT/fetch_tol_jacobi" "$OUT/write_tol_jacobi" > "$OUT/${TAG}_hbm_traffic_tol_jacobi_fused.txt"
 PROFILE_KERNEL=sweep2d $S pmc "$OUT/fetch_tol_jacobi" "$OUT/write_tol_jacobi" > "$OUT/${TAG}_hbm_traffic_tol_jacobi.txt"
