@@ -27,7 +27,8 @@ def test_the_scheme_dependent_files_pass_with_the_library_default_as_session_sch
     env = {k: v for k, v in os.environ.items() if k not in ("EPIC_HIP_SCHEME", "PYTEST_CURRENT_TEST")}
     env["EPIC_TEST_SCHEME"] = "default"
     r = subprocess.run([sys.executable, "-m", "pytest", *FILES, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
-                        "-k", "not 8192_tracking and not relax_8192 and not 32768"],   # (the three longest: run in the outer session, scheme set explicitly)
+                        "-k", "not 8192_tracking and not relax_8192 and not 32768 and not campaigns_maps and not tracked_pairs_on_slabs and not tracked_tol_pairs_on_slabs"],
+                       # (the longest ones and round 6's slab-pair / campaign tests: run in the outer session, their schemes set explicitly)
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=840)
     tail = r.stdout[-3000:] + r.stderr[-1500:]
     assert r.returncode == 0, tail
