@@ -7,7 +7,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = ["profiles/r05_bench_line_n1.json", "profiles/r05_bench_line_n2_gloo_one_gpu.json"]
+LINES = ["profiles/r06_bench_line_n1.json", "profiles/r06_bench_line_n2_gloo_one_gpu.json"]
 
 
 def load(rel):
@@ -192,6 +192,41 @@ def test_round_5_the_keys_the_driver_keeps_carry_relax_to_eps_parity_and_the_oth
     # the N > 1 line came out of the PLAIN command (no launcher in front): the parent started its own ranks
     d2 = load(LINES[1])
     assert d2["n_gpus"] == 2 and d2["ranks"]["ranks_seen"] == 2 and "in_library" in d2 and "error" not in d2["in_library"]
+
+
+def test_round_6_what_the_driver_keeps_is_scalars_and_the_node_flow_leg_is_in_the_line():
+    """The driver's record keeps the SCALARS of `config` (round 5's nested objects were dropped from BENCH_r05.parsed): BASELINE's metric -- relax to
+    eps = 1e-6 --, the parity verdict, the maps, the measured HBM fraction, the navigation node's call loop and the tol campaign are repeated flat."""
+    d = load(LINES[0])
+    c = d["config"]
+    scalars = ("relax_default_seconds", "relax_default_iterations", "relax_fastest_seconds", "relax_fastest_mode", "relax_fastest_iterations",
+               "relax_finishing_iterations", "parity_miss_count", "maze_seconds", "umass_seconds", "hbm_frac_measured", "valu_issue_frac",
+               "config5_frac", "config5_relax_seconds_default", "config5_relax_seconds_tol_jacobi", "config5_relax_seconds_tol_redblack",
+               "node_flow_maze_us_per_iteration", "node_flow_maze_ratio_to_execute", "node_flow_maze_undeferred_us_per_iteration",
+               "node_flow_umass_us_per_iteration", "node_flow_umass_ratio_to_execute", "node_flow_8192_us_per_iteration",
+               "node_flow_8192_ratio_to_execute", "node_flow_bit_identical", "tol_campaign_cases", "tol_campaign_misses", "tol_campaign_worst_rel")
+    for k in scalars:
+        assert k in c and isinstance(c[k], (int, float, str, bool)) and not isinstance(c[k], (dict, list)), k
+    assert c["relax_default_seconds"] == d["relax_default"]["seconds"] and c["relax_default_iterations"] == 45001
+    assert c["relax_fastest_seconds"] == d["relax"]["seconds"] and c["relax_finishing_iterations"] == d["relax"]["finishing_iterations"]
+    assert c["parity_miss_count"] == 0 and c["hbm_frac_measured"] == d["roofline"]["hbm_frac_measured"] < d["roofline"]["frac"]
+    assert c["maze_seconds"] == d["maps"]["maze default eps 1e-06"]["seconds"]
+    # the navigation node's literal call loop (1 check + 49 single updates per tick): within 1.25 x the execute loop on all three grids
+    # (VERDICT r05 item 1), the same field bit for bit, and clearly faster than one launch per call
+    nf = d["node_flow"]
+    for name, key in (("maze", "maze"), ("umass", "umass"), ("8192^2", "8192")):
+        e = nf[name]
+        assert e["execute"]["iterations"] > 40000 and all(x["bit_identical"] for x in e["node_flow"] + e["undeferred"]), name
+        assert [x["steps_per_tick"] for x in e["node_flow"]] == [50, 100]
+        assert c["node_flow_%s_ratio_to_execute" % key] == e["node_flow"][0]["ratio_to_execute"] <= 1.25, name
+        assert e["undeferred"][0]["us_per_iteration"] > 1.2 * e["node_flow"][0]["us_per_iteration"], name
+    assert c["node_flow_bit_identical"] is True
+    # the campaign's record as committed (tests/golden/tol_campaign.json)
+    camp = json.load(open(os.path.join(ROOT, "tests", "golden", "tol_campaign.json")))["summary"]
+    assert (c["tol_campaign_cases"], c["tol_campaign_misses"]) == (camp["cases"], camp["misses"]) and c["tol_campaign_cases"] >= 300
+    # 3-D: three whole relaxations; where the default run's minutes go
+    assert len(d["config5"]["relax_seconds"]) == 3
+    assert d["leg_seconds"]["whole run"] < 420 and d["leg_seconds"]["whole run"] >= sum(v for k, v in d["leg_seconds"].items() if k != "whole run") - 1.0
 
 
 def test_plain_multi_gpu_command_starts_its_own_ranks_as_a_child():
