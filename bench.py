@@ -513,6 +513,9 @@ def self_launch(args):
 
 
 T_START = time.perf_counter()
+# The A/B legs of this script switch kernel families with STUDY knobs (EPIC_HIP_NO_FUSE, EPIC_HIP_FUSED_ROWS in the counter passes): the library reads those
+# only when EPIC_HIP_STUDY=1 says the caller means them (epic_amd/csrc/driver_config.cpp).  With none of them set a context is the library's default.
+os.environ.setdefault("EPIC_HIP_STUDY", "1")
 LEG_SECONDS = {}   # wall seconds per leg of this run, reported in the line (`leg_seconds`): where a default run's minutes go
 
 

@@ -11,15 +11,43 @@
 namespace epic_drv {
 
 namespace {
+// Two classes of variables.  PRODUCT knobs -- arithmetic, scheme, work lists, the device list and its transport,
+// the tol mode's finishing iterations, deferred updates -- are always honoured.  STUDY knobs -- everything that only selects a code path or
+// a tiling and never changes a result: thresholds, task heights, tile plans, launch flags, the tuner -- are what the tests, the fuzz
+// campaigns, bench.py's A/B legs and tools/ steer the library with; a drop-in library loaded into somebody else's process should not change
+// its kernel plan because a variable of that name happens to be set, so they are read only when EPIC_HIP_STUDY=1 says the caller means
+// it.  A study knob that is set without it is ignored, and the library says so once on stderr.
+bool g_study = false;
+std::mutex g_ignored_mu;
+bool g_ignored_said = false;
 const char *env(const char *name) { return getenv(name); }
+const char *senv(const char *name)
+{
+    const char *v = getenv(name);
+    if (v && !g_study) {
+        std::lock_guard<std::mutex> lk(g_ignored_mu);
+        if (!g_ignored_said) {
+            g_ignored_said = true;
+            fprintf(stderr, "Warning[epic_hip]: %s is a study knob and is ignored without EPIC_HIP_STUDY=1 (INTEGRATION.md section 6); further ones are not reported.\n", name);
+        }
+        return nullptr;
+    }
+    return v;
+}
 bool given(const char *name) { return env(name) != nullptr; }
+bool sgiven(const char *name) { return senv(name) != nullptr; }
 bool is_zero(const char *name) { const char *e = env(name); return e && e[0] == '0'; }   // "=0" switches a default-on feature off
-int int_of(const char *name, int dflt) { const char *e = env(name); return e ? atoi(e) : dflt; }
+bool sis_zero(const char *name) { const char *e = senv(name); return e && e[0] == '0'; }
+int sint_of(const char *name, int dflt) { const char *e = senv(name); return e ? atoi(e) : dflt; }
 }  // namespace
 
 Config Config::from_env()
 {
     Config c;
+    {
+        const char *st = env("EPIC_HIP_STUDY");
+        c.study = g_study = st != nullptr && st[0] != '0';
+    }
     const char *e = env("EPIC_HIP_MATH");
     if (e && strcmp(e, "fast") == 0) c.math = 1;
     if (e && strcmp(e, "tol") == 0) c.math = 4;
@@ -28,7 +56,7 @@ Config Config::from_env()
     if (e && strcmp(e, "jacobi") == 0) c.redblack = false;
     e = env("EPIC_HIP_TRACK");
     if (e && (strcmp(e, "0") == 0 || strcmp(e, "1") == 0)) c.track_mode = atoi(e);
-    c.rows_per_task = int_of("EPIC_HIP_ROWS_PER_TASK", 0);
+    c.rows_per_task = sint_of("EPIC_HIP_ROWS_PER_TASK", 0);
     e = env("EPIC_HIP_HALO");
     if (e && atoi(e) >= 1) c.halo = atoi(e);
     e = env("EPIC_HIP_DEVICES");
@@ -50,42 +78,42 @@ Config Config::from_env()
     c.threads = !(e && atoi(e) == 0);
     e = env("EPIC_HIP_SPIN_US");
     if (e && atoi(e) >= 0) c.spin_us = atoi(e) > 100000 ? 100000 : atoi(e);
-    c.no_fuse = given("EPIC_HIP_NO_FUSE");
-    c.no_graph = given("EPIC_HIP_NO_GRAPH");
-    e = env("EPIC_HIP_FUSE_MIN_CELLS");
+    c.no_fuse = sgiven("EPIC_HIP_NO_FUSE");
+    c.no_graph = sgiven("EPIC_HIP_NO_GRAPH");
+    e = senv("EPIC_HIP_FUSE_MIN_CELLS");
     if (e && atoll(e) >= 0) c.fuse_min_cells = atoll(e);
-    e = env("EPIC_HIP_FUSED_ROWS");
+    e = senv("EPIC_HIP_FUSED_ROWS");
     if (e && atoi(e) > 0) c.fused_rows = atoi(e);
-    c.tune = !is_zero("EPIC_HIP_TUNE");
-    c.tune_debug = given("EPIC_HIP_TUNE_DEBUG");
-    c.tile = !is_zero("EPIC_HIP_TILE");
-    e = env("EPIC_HIP_TILE_MAX_CELLS");
+    c.tune = !sis_zero("EPIC_HIP_TUNE");
+    c.tune_debug = sgiven("EPIC_HIP_TUNE_DEBUG");
+    c.tile = !sis_zero("EPIC_HIP_TILE");
+    e = senv("EPIC_HIP_TILE_MAX_CELLS");
     if (e && atoll(e) >= 0) c.tile_max_cells = atoll(e);
-    c.tile_rows = int_of("EPIC_HIP_TILE_ROWS", 0);
-    c.tile_width = int_of("EPIC_HIP_TILE_WIDTH", 0);
-    e = env("EPIC_HIP_TILE_HALO");
+    c.tile_rows = sint_of("EPIC_HIP_TILE_ROWS", 0);
+    c.tile_width = sint_of("EPIC_HIP_TILE_WIDTH", 0);
+    e = senv("EPIC_HIP_TILE_HALO");
     if (e && atoi(e) > 0) c.tile_halo = atoi(e);
-    c.tile_pipeline = !is_zero("EPIC_HIP_TILE_PIPELINE");
+    c.tile_pipeline = !sis_zero("EPIC_HIP_TILE_PIPELINE");
     c.defer = !is_zero("EPIC_HIP_DEFER");
-    c.track_pairs = !is_zero("EPIC_HIP_TRACK_PAIRS");
-    e = env("EPIC_HIP_TRACK_PAIR_ROWS");
+    c.track_pairs = !sis_zero("EPIC_HIP_TRACK_PAIRS");
+    e = senv("EPIC_HIP_TRACK_PAIR_ROWS");
     if (e && atoi(e) > 0) c.track_pair_rows = atoi(e);
-    e = env("EPIC_HIP_TRACK_SWITCH");
+    e = senv("EPIC_HIP_TRACK_SWITCH");
     if (e) c.track_switch = atof(e);
     e = env("EPIC_HIP_TOL_FINISH");
     if (e) c.tol_finish = e[0] == '0' ? 0 : 1;
-    e = env("EPIC_HIP_TOL_FINISH_FACTOR");
+    e = senv("EPIC_HIP_TOL_FINISH_FACTOR");
     if (e) {
         const float v = (float)atof(e);
         if (v >= 1.0f && v <= 1e9f) c.tol_finish_factor = v;
     }
-    c.launch.flags = int_of("EPIC_HIP_FLAGS", 7);
-    e = env("EPIC_HIP_LIST_WAVES");
+    c.launch.flags = sint_of("EPIC_HIP_FLAGS", 7);
+    e = senv("EPIC_HIP_LIST_WAVES");
     if (e && atol(e) >= 4) c.launch.list_waves = (size_t)atol(e);
-    c.launch.pair3d = !is_zero("EPIC_HIP_3D_PAIR");
-    e = env("EPIC_HIP_3D_PAIR_ROWS");
+    c.launch.pair3d = !sis_zero("EPIC_HIP_3D_PAIR");
+    e = senv("EPIC_HIP_3D_PAIR_ROWS");
     if (e && atoi(e) > 0) c.launch.pair3d_rows = atoi(e);
-    e = env("EPIC_HIP_3D_MARCH");
+    e = senv("EPIC_HIP_3D_MARCH");
     c.launch.march_x0 = e && e[0] == 'x' && e[1] == '0';
     return c;
 }
@@ -101,7 +129,7 @@ std::string Config::json() const
     }
     char t[1536];
     std::string out = "{";
-    snprintf(t, sizeof t, "\"math\": %d, \"scheme\": \"%s\", \"track_mode\": %d, \"rows_per_task\": %d, \"devices\": \"", math,
+    snprintf(t, sizeof t, "\"study\": %s, \"math\": %d, \"scheme\": \"%s\", \"track_mode\": %d, \"rows_per_task\": %d, \"devices\": \"", study ? "true" : "false", math,
              redblack ? "redblack" : "jacobi", track_mode, rows_per_task);
     out += t;
     out += dev;

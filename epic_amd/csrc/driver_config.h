@@ -29,6 +29,8 @@ const LaunchKnobs &process_launch_knobs();
 namespace epic_drv {
 
 struct Config {
+    bool study = false;              // EPIC_HIP_STUDY=1: the STUDY knobs below are read at all (driver_config.cpp: two classes of variables)
+    // ---- product knobs: always honoured ----
     // mode of a new context (also settable per context: epic_hip_set_*)
     int math = 0;                    // EPIC_HIP_MATH: 0 precise (default), 1 fast, 4 tol
     bool redblack = true;            // EPIC_HIP_SCHEME: redblack (default) | jacobi

@@ -8,6 +8,10 @@ import pytest
 # a 16-CPU share of a much larger machine, where such a team spends its time in barriers.  Set before libgomp is loaded.
 os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
 
+# The tests steer the library's kernel plan with STUDY knobs (thresholds, task heights, tile plans: epic_amd/csrc/driver_config.cpp), which the
+# library reads only when the caller says it means them.
+os.environ.setdefault("EPIC_HIP_STUDY", "1")
+
 # The library's default iteration is the reference's red-black half-sweep (bit-identical to harmonic_complete_cpu with the
 # default precise math); BASELINE.json's metric names the Jacobi scheme, which is what bench.py times.  The suite runs under
 # EITHER for the session, selected the way a user would select it -- the environment the library reads:

@@ -171,6 +171,7 @@ static void set_env(const std::map<std::string, std::string> &env, bool on)
     static const char *all[] = {"EPIC_HIP_DEVICES", "EPIC_HIP_THREADS", "EPIC_HIP_NO_PEER", "EPIC_HIP_TRACK", "EPIC_HIP_TILE", "EPIC_HIP_MATH",
                                 "EPIC_HIP_SCHEME", "EPIC_HIP_HALO", "EPIC_HIP_FUSE_MIN_CELLS", "EPIC_HIP_TUNE", "EPIC_HIP_DEFER", "FAKE_NO_PEER_CAPABLE", "FAKE_CURRENT_DEVICE"};
     for (const char *k : all) unsetenv(k);
+    setenv("EPIC_HIP_STUDY", "1", 1);   // the scenarios steer the kernel plan with study knobs (epic_amd/csrc/driver_config.cpp)
     if (on)
         for (auto &kv : env) setenv(kv.first.c_str(), kv.second.c_str(), 1);
 }

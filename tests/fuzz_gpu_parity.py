@@ -18,7 +18,8 @@ import sys
 
 import numpy as np
 
-os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))   # (the checker's OpenMP: the GPU box shows 256 cores and grants 16)
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+os.environ.setdefault("EPIC_HIP_STUDY", "1")   # the knobs drawn below are study knobs: read only when asked for (epic_amd/csrc/driver_config.cpp)   # (the checker's OpenMP: the GPU box shows 256 cores and grants 16)
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))

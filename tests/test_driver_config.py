@@ -42,6 +42,7 @@ def run(exe, **env):
 
 def test_defaults_are_the_librarys(harness):
     c, k = run(harness)
+    assert c["study"] is False
     assert c["math"] == 0 and c["scheme"] == "redblack" and c["track_mode"] == 2 and c["rows_per_task"] == 0      # the reference's iteration, bit-exact
     assert c["devices"] == "" and c["halo"] == 0 and c["threads"] is True and c["spin_us"] == 20 and c["no_peer"] is False
     assert c["no_fuse"] is False and c["no_graph"] is False and c["fuse_min_cells"] == -1 and c["tune"] is True      # -1: by arithmetic and scheme (driver_plan.hip)
@@ -51,7 +52,7 @@ def test_defaults_are_the_librarys(harness):
 
 
 def test_every_knob_is_parsed(harness):
-    c, k = run(harness, EPIC_HIP_MATH="tol", EPIC_HIP_SCHEME="jacobi", EPIC_HIP_TRACK="1", EPIC_HIP_ROWS_PER_TASK="12", EPIC_HIP_DEVICES="0,1,1,3",
+    c, k = run(harness, EPIC_HIP_STUDY="1", EPIC_HIP_MATH="tol", EPIC_HIP_SCHEME="jacobi", EPIC_HIP_TRACK="1", EPIC_HIP_ROWS_PER_TASK="12", EPIC_HIP_DEVICES="0,1,1,3",
                EPIC_HIP_HALO="5", EPIC_HIP_NO_PEER="1", EPIC_HIP_THREADS="0", EPIC_HIP_SPIN_US="0", EPIC_HIP_NO_FUSE="1", EPIC_HIP_NO_GRAPH="1",
                EPIC_HIP_FUSE_MIN_CELLS="0", EPIC_HIP_FUSED_ROWS="33", EPIC_HIP_TUNE="0", EPIC_HIP_TILE="0", EPIC_HIP_TILE_MAX_CELLS="1000",
                EPIC_HIP_TILE_ROWS="7", EPIC_HIP_TILE_WIDTH="128", EPIC_HIP_TILE_HALO="9", EPIC_HIP_TILE_PIPELINE="0", EPIC_HIP_DEFER="0", EPIC_HIP_TRACK_PAIRS="0",
@@ -67,7 +68,7 @@ def test_every_knob_is_parsed(harness):
 
 
 def test_values_out_of_range_fall_back(harness):
-    c, _ = run(harness, EPIC_HIP_MATH="double", EPIC_HIP_SCHEME="sor", EPIC_HIP_TRACK="7", EPIC_HIP_HALO="0", EPIC_HIP_SPIN_US="-3",
+    c, _ = run(harness, EPIC_HIP_STUDY="1", EPIC_HIP_MATH="double", EPIC_HIP_SCHEME="sor", EPIC_HIP_TRACK="7", EPIC_HIP_HALO="0", EPIC_HIP_SPIN_US="-3",
                EPIC_HIP_TOL_FINISH_FACTOR="0.5", EPIC_HIP_LIST_WAVES="2", EPIC_HIP_TILE_HALO="-1", EPIC_HIP_FUSED_ROWS="0")
     assert c["math"] == 0 and c["scheme"] == "redblack" and c["track_mode"] == 2 and c["halo"] == 0 and c["spin_us"] == 20
     assert c["tol_finish_factor"] == 0 and c["list_waves"] == 0 and c["tile_halo"] == 0 and c["fused_rows"] == 0
@@ -84,3 +85,35 @@ def test_whatever_the_environment_holds_the_dump_stays_one_json_object(harness):
     c, _ = run(harness, EPIC_HIP_DEVICES=nasty)
     assert c["devices"].startswith('0,"1\\ x') and len(c["devices"]) == 256
     assert c["math"] == 0 and c["march_x0"] is False       # the fields behind the text are all there
+
+
+def test_study_knobs_are_read_only_when_asked_for(harness):
+    """Two classes of variables (round 6, driver_config.cpp).  PRODUCT knobs -- arithmetic, scheme, work lists, devices and their transport, the
+    tol mode's finishing iterations, deferred updates -- are always honoured.  STUDY knobs -- thresholds, task heights, tile plans, launch flags,
+    the tuner: they select a code path, never a result -- are what tests, fuzz campaigns and bench.py's A/B legs steer the library with; a drop-in
+    library in somebody else's process reads them only under EPIC_HIP_STUDY=1, and says once on stderr that it ignored one otherwise."""
+    study = dict(EPIC_HIP_ROWS_PER_TASK="12", EPIC_HIP_NO_FUSE="1", EPIC_HIP_NO_GRAPH="1", EPIC_HIP_FUSE_MIN_CELLS="0", EPIC_HIP_FUSED_ROWS="33",
+                 EPIC_HIP_TUNE="0", EPIC_HIP_TILE="0", EPIC_HIP_TILE_MAX_CELLS="1000", EPIC_HIP_TILE_ROWS="7", EPIC_HIP_TILE_WIDTH="128",
+                 EPIC_HIP_TILE_HALO="9", EPIC_HIP_TILE_PIPELINE="0", EPIC_HIP_TRACK_PAIRS="0", EPIC_HIP_TRACK_PAIR_ROWS="6", EPIC_HIP_TRACK_SWITCH="0.5",
+                 EPIC_HIP_TOL_FINISH_FACTOR="30", EPIC_HIP_FLAGS="2", EPIC_HIP_LIST_WAVES="512", EPIC_HIP_3D_PAIR="0", EPIC_HIP_3D_PAIR_ROWS="20",
+                 EPIC_HIP_3D_MARCH="x0")
+    product = dict(EPIC_HIP_MATH="tol", EPIC_HIP_SCHEME="jacobi", EPIC_HIP_TRACK="1", EPIC_HIP_DEVICES="0,1", EPIC_HIP_HALO="5", EPIC_HIP_NO_PEER="1",
+                   EPIC_HIP_THREADS="0", EPIC_HIP_SPIN_US="7", EPIC_HIP_TOL_FINISH="0", EPIC_HIP_DEFER="0")
+    defaults, k0 = run(harness)
+    e = {k: v for k, v in os.environ.items() if not k.startswith("EPIC_HIP_")}
+    e.update(study)
+    e.update(product)
+    r = subprocess.run([harness], env=e, capture_output=True, text=True, check=True)
+    c, k = json.loads(r.stdout.splitlines()[0]), json.loads(r.stdout.splitlines()[1])
+    assert c["study"] is False and k == k0
+    for key in ("rows_per_task", "no_fuse", "no_graph", "fuse_min_cells", "fused_rows", "tune", "tile", "tile_max_cells", "tile_rows", "tile_width",
+                "tile_halo", "tile_pipeline", "track_pairs", "track_pair_rows", "track_switch", "tol_finish_factor", "flags", "list_waves", "pair3d",
+                "pair3d_rows", "march_x0"):
+        assert c[key] == defaults[key], key
+    assert (c["math"], c["scheme"], c["track_mode"], c["devices"], c["halo"], c["no_peer"], c["threads"], c["spin_us"], c["tol_finish"], c["defer"]) == \
+        (4, "jacobi", 1, "0,1", 5, True, False, 7, 0, False)
+    assert r.stderr.count("is a study knob and is ignored without EPIC_HIP_STUDY=1") == 1
+    c2, _ = run(harness, EPIC_HIP_STUDY="1", **study)
+    assert c2["study"] is True and c2["no_fuse"] is True and c2["tile_rows"] == 7 and c2["flags"] == 2
+    c3, _ = run(harness, EPIC_HIP_STUDY="0", **study)
+    assert c3["study"] is False and c3["no_fuse"] is False

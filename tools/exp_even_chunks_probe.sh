@@ -1,4 +1,5 @@
 #!/bin/bash
+export EPIC_HIP_STUDY=1   # the knobs below are study knobs: read only when asked for (epic_amd/csrc/driver_config.cpp)
 # does a task height that fills the last round exactly pay?  8190 rows = 210 chunks of 39 (6.97 blocks per CU) against 205 chunks of 40 (6.81)
 for spec in "8190 39" "8190 40" "8190 39" "8190 40" "8188 46" "8188 45"; do
   set -- $spec

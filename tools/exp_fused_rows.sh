@@ -1,4 +1,5 @@
 #!/bin/bash
+export EPIC_HIP_STUDY=1   # the knobs below are study knobs: read only when asked for (epic_amd/csrc/driver_config.cpp)
 # Experiment: task height of the fused tol pass (EPIC_HIP_FUSED_ROWS) on the bench workload; one gpurun call, same box.
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/exp_fused_rows.txt

@@ -1,4 +1,5 @@
 #!/bin/bash
+export EPIC_HIP_STUDY=1   # the knobs below are study knobs: read only when asked for (epic_amd/csrc/driver_config.cpp)
 # LDS counters of the fused tol pass (8192^2, developed field) for the shipped library and a variant (gpurun_alt/<name>): item 11 of
 # profiles/r05_experiments.txt.   bash tools/exp_lds_reads.sh k2d_b96
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}

@@ -1,4 +1,5 @@
 #!/bin/bash
+export EPIC_HIP_STUDY=1   # the knobs below are study knobs: read only when asked for (epic_amd/csrc/driver_config.cpp)
 # Tracked red-black pairs (round 4): whole 8192^2 default relaxations side by side in ONE gpurun call.
 #   bash tools/exp_pairs.sh   -> seconds for: half-sweeps (round 3's path), pairs at several task heights and bypass thresholds
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}

@@ -1,4 +1,5 @@
 #!/bin/bash
+export EPIC_HIP_STUDY=1   # the knobs below are study knobs: read only when asked for (epic_amd/csrc/driver_config.cpp)
 # Tracked pairs with the tol passes: whole 8192^2 relaxations, pairs against list-driven single sweeps, ONE gpurun call.
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"

@@ -1,6 +1,8 @@
 """8192^2 default relaxation (precise, red-black, work lists) on one device and on in-library slabs of the same GPU, with the work lists
 always bypassed (EPIC_HIP_TRACK_SWITCH=0), never (2) and by the rule: where do the slabs lose time?  (round 6)"""
 import os
+
+os.environ.setdefault("EPIC_HIP_STUDY", "1")   # this tool steers the kernel plan with study knobs (epic_amd/csrc/driver_config.cpp)
 import sys
 import time
 

@@ -1,4 +1,5 @@
 #!/bin/bash
+export EPIC_HIP_STUDY=1   # the knobs below are study knobs: read only when asked for (epic_amd/csrc/driver_config.cpp)
 # Experiment: the share of due tiles above which harmonic_execute_gpu runs a batch without the work lists (EPIC_HIP_TRACK_SWITCH),
 # whole 8192^2 relaxations, same box.  --track 2 = automatic (the library's default).
 #   CONFIGS="tol:jacobi:0.6,0.7 precise:redblack:0.5" bash tools/exp_track_switch.sh

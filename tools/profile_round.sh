@@ -1,4 +1,5 @@
 #!/bin/bash
+export EPIC_HIP_STUDY=1   # the knobs below are study knobs: read only when asked for (epic_amd/csrc/driver_config.cpp)
 # Profiles kept under profiles/ for a round (run on the GPU box through gpurun; TAG = r01, r02, ...):
 #   bash tools/profile_round.sh r05
 # rocprofv3 passes, each with the program itself after `--` (python3 <script>), counters in their own runs:

@@ -10,6 +10,8 @@ iterations with one check (what harmonic_execute_gpu's loop runs), on a develope
 """
 import ctypes as ct
 import os
+
+os.environ.setdefault("EPIC_HIP_STUDY", "1")   # this tool steers the kernel plan with study knobs (epic_amd/csrc/driver_config.cpp)
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

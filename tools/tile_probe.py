@@ -8,6 +8,8 @@ outlasts the host's launch rate (~4 us).
 import argparse
 import ctypes as ct
 import os
+
+os.environ.setdefault("EPIC_HIP_STUDY", "1")   # this tool steers the kernel plan with study knobs (epic_amd/csrc/driver_config.cpp)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

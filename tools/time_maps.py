@@ -8,6 +8,8 @@ Prints one line per configuration and a JSON summary on the last line.
 import argparse
 import json
 import os
+
+os.environ.setdefault("EPIC_HIP_STUDY", "1")   # this tool steers the kernel plan with study knobs (epic_amd/csrc/driver_config.cpp)
 import sys
 import time
 

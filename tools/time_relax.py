@@ -6,6 +6,8 @@ import argparse
 import ctypes as ct
 import json
 import os
+
+os.environ.setdefault("EPIC_HIP_STUDY", "1")   # this tool steers the kernel plan with study knobs (epic_amd/csrc/driver_config.cpp)
 import sys
 import time
 
