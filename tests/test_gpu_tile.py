@@ -153,6 +153,37 @@ def test_tiles_against_the_checker(m, seed, dens):
         assert np.array_equal(got, p.u) and gdelta == float(p.h.delta)
 
 
+@pytest.mark.parametrize("m,math,scheme,expect", [
+    ([1700, 1700], eh.MATH_PRECISE, eh.SCHEME_REDBLACK, "tiles"),      # 2.9 Mcell: the default arithmetic stays on tiles up to 3 Mcell
+    ([1900, 1900], eh.MATH_PRECISE, eh.SCHEME_REDBLACK, "sweeps"),     # 3.6 Mcell, the former gap: single sweeps ARE the fastest family here
+    ([2048, 2048], eh.MATH_PRECISE, eh.SCHEME_REDBLACK, "sweeps"),     # 4.2 Mcell: the precise pass takes over from 5.5 Mcell
+    ([1024, 1024], eh.MATH_PRECISE, eh.SCHEME_JACOBI, "sweeps"),       # precise Jacobi has no wide tile: sweeps from 0.6 Mcell
+    ([700, 800], eh.MATH_PRECISE, eh.SCHEME_JACOBI, "tiles"),
+    ([1024, 1024], eh.MATH_TOL, eh.SCHEME_REDBLACK, "tiles"),
+])
+def test_the_family_a_size_takes_by_default_and_its_bits(m, math, scheme, expect):
+    """The measured crossovers of round 6 (driver_plan.hip: fuse_from_cells / tile_up_to_cells; profiles/r06_size_curve.txt) with NO knob set:
+    which family serves the size, and that a block of iterations through it equals the same block through single sweeps bit for bit."""
+    u0, locked = seeded(m, 13, 0.05)
+    with env(EPIC_HIP_TILE_MAX_CELLS=None, EPIC_HIP_FUSE_MIN_CELLS=None, EPIC_HIP_TILE=None):
+        h = Harmonic()
+        h.set_grid(m, u0, locked)
+        h.epsilon = 1e-6
+        for fn in (E.harmonic_initialize_dimension_size_gpu, E.harmonic_initialize_potential_values_gpu, E.harmonic_initialize_locked_gpu):
+            assert fn(h) == 0
+        assert E.harmonic_initialize_gpu(h, NT) == 0
+        assert E.epic_hip_set_math_mode(h, math) == 0 and E.epic_hip_set_scheme(h, scheme) == 0 and E.epic_hip_set_activity_tracking(h, 0) == 0
+        path = eh.config_dump(h)["path"]["plain_batch"]
+        assert ("LDS tiles" in path) == (expect == "tiles") and ("single sweeps" in path) == (expect == "sweeps"), path
+        for fn in (E.harmonic_uninitialize_gpu, E.harmonic_uninitialize_dimension_size_gpu, E.harmonic_uninitialize_potential_values_gpu,
+                   E.harmonic_uninitialize_locked_gpu):
+            assert fn(h) == 0
+        got, gdelta = run_gpu(m, u0, locked, 23, math, scheme)
+    with env(EPIC_HIP_TILE="0", EPIC_HIP_NO_FUSE="1", EPIC_HIP_NO_GRAPH="1"):
+        want, wdelta = run_gpu(m, u0, locked, 23, math, scheme)
+    assert np.array_equal(got, want) and gdelta == wdelta
+
+
 def test_reference_half_sweeps_through_tiles(goldens):
     """rb10 of every 2-D golden grid: ten of the reference's own half-sweeps (harmonic_update_cpu x 9 + _and_check_cpu)."""
     small = goldens["small"]

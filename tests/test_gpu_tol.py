@@ -258,6 +258,27 @@ def test_tol_fused_double_sweeps_equal_the_checker_bit_for_bit(m, seed, dens, ro
 
 
 @pytest.mark.parametrize("scheme", [eh.SCHEME_JACOBI, eh.SCHEME_REDBLACK], ids=["jacobi", "redblack"])
+@pytest.mark.parametrize("m", [[1900, 1900], [1735, 2100], [1419, 1735]])
+def test_sizes_of_the_former_gap_take_the_fused_passes_by_default(m, scheme):
+    """Until round 6 grids of 3-4 Mcell fell between the LDS tiles (<= 3 Mcell) and the fused passes (>= 4 Mcell) onto single sweeps, and
+    1.5-3 Mcell tol grids ran on tiles that the fused pass beats by 1.4-1.6 x (profiles/r06_size_curve.txt).  With NO knob set the tol
+    arithmetic now takes its fused pass from 1.5 (Jacobi) / 2 Mcell (red-black) on: two sizes inside the former gap and one below it, against
+    the checker bit for bit -- an odd and an even count, the check included."""
+    u0, locked = with_extra_goals(m, 11, 0.05)
+    for k in (7, 12):
+        h = make(m, u0, locked)
+        gpu_init(h)
+        assert E.epic_hip_set_scheme(h, scheme) == 0 and E.epic_hip_set_activity_tracking(h, 0) == 0
+        assert E.epic_hip_iterations_per_pass(h) == 2 and E.epic_hip_tile_iterations(h) == 0, eh.config_dump(h)["path"]
+        assert E.epic_hip_update_n_gpu(h, k, 1) in (0, 1)
+        assert E.harmonic_get_potential_values_gpu(h) == 0
+        got, gdelta = h.u_array().ravel().copy(), float(h.delta)
+        gpu_fini(h)
+        want, wdelta = checker_iterations(m, u0, locked, k, scheme)
+        assert np.array_equal(got, want) and gdelta == wdelta, (m, k)
+
+
+@pytest.mark.parametrize("scheme", [eh.SCHEME_JACOBI, eh.SCHEME_REDBLACK], ids=["jacobi", "redblack"])
 @pytest.mark.parametrize("m,rows", [([1237, 1500], 40), ([1237, 1500], 100), ([1237, 1500], 17), ([2051, 520], 64), ([999, 8200], 46)])
 def test_fused_passes_cut_into_as_many_chunks_as_fit_the_last_round_change_nothing(m, rows, scheme, monkeypatch):
     """kernels_2d.hip: tighten_chunks -- a fused pass without work lists cuts its rows into the most chunks that still make the same
