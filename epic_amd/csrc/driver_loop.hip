@@ -229,7 +229,7 @@ static int update_and_check(Harmonic *harmonic, bool decide)
     const int rc = run_block(harmonic, c, plain, first, true, fn, c->defer_bypass ? 1 : 0, run_ahead);
     if (rc != EPIC_SUCCESS) return rc;
     harmonic->currentIteration++;
-    if (decide) c->defer_bypass = c->cfg.defer && bypass_lists_for_batch(c, rb_pairs_tracked(c));
+    if (decide) c->defer_bypass = c->cfg.defer && bypass_lists_for_batch(c, rb_pairs_tracked(c) || rb_pairs_tracked_multi(c));
     return harmonic->delta < harmonic->epsilon ? EPIC_SUCCESS_AND_CONVERGED : EPIC_SUCCESS;
 }
 
