@@ -276,6 +276,16 @@ def parity_object(args, E, MODES, relaxed, locked_8192):
             if key in relaxed and "relax_default" in relaxed:
                 e = dist(relaxed[key], relaxed["relax_default"], locked_8192)
                 e.update(against="this run's relax_default (precise + red-black, the reference's iteration bit for bit)")
+                # round 6: that field is no longer only the library's word -- the reference's loop was run on the CPU at this size once
+                # (tests/golden/generate_8192_golden.py, half-sweeps dealt to threads: the sequential result bit for bit) and its sha256 committed
+                try:
+                    import hashlib
+
+                    g8 = json.load(open(os.path.join(gdir, "synthetic_8192.json")))
+                    e["relax_default_equals_cpu_statement_of_the_reference"] = bool(hashlib.sha256(np.ascontiguousarray(relaxed["relax_default"]).tobytes()).hexdigest() == g8["sha_u"])
+                    e["cpu_statement"] = "tests/golden/synthetic_8192.json: %d iterations, delta %.3e, %d threads, %.0f s" % (g8["iterations"], g8["delta"], g8["threads"], g8["seconds"])
+                except (OSError, ValueError, KeyError):
+                    e["relax_default_equals_cpu_statement_of_the_reference"] = None
                 out["configs"][label] = e
         out["configs"]["configs[3] 32768x32768 on 4 / 8 GPUs"] = {"max_rel": None, "note": "not relaxed at N = 1; same arithmetic and kernels, bit-identical across slab counts (tests/test_gpu_multi_device.py)"}
         if not args.no_extra_legs:
@@ -454,6 +464,10 @@ def summarise_into_config(out):
         cfg["relax_finishing_iterations"] = rte["fastest_parity_clean"]["finishing_iterations"]
     if "parity" in out:
         cfg["parity_miss_count"] = len(out["parity"].get("misses") or [])
+        e8 = (out["parity"].get("configs") or {}).get("configs[2] 8192x8192 (the timed grid)") or {}
+        if e8.get("relax_default_equals_cpu_statement_of_the_reference") is not None:
+            cfg["default_field_8192_equals_cpu_reference"] = e8["relax_default_equals_cpu_statement_of_the_reference"]
+            cfg["timed_mode_8192_max_rel_vs_reference"] = e8.get("max_rel")
     for name, secs in (cfg.get("maps_seconds") or {}).items():
         cfg["%s_seconds" % name] = secs
     roof = out.get("roofline") or {}

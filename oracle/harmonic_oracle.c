@@ -19,6 +19,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -118,6 +119,60 @@ int oracle_update_parallel_2d(OracleHarmonic *h, int threads)
         }
     }
     h->currentIteration++;
+    return ORACLE_SUCCESS;
+}
+
+/* ... and the check form (harmonic_cpu.cpp:203-220): max |du| over the cells the half-sweep recomputes.  A maximum does not depend on the
+ * order it is taken in, so delta is the sequential one bit for bit as well. */
+int oracle_update_and_check_parallel_2d(OracleHarmonic *h, int threads)
+{
+    if (h == NULL || h->n != 2 || h->m == NULL || h->u == NULL || h->locked == NULL || threads < 1)
+        return ORACLE_ERROR_INVALID_DATA;
+    const unsigned int m0 = h->m[0], m1 = h->m[1];
+    const unsigned int it = h->currentIteration;
+    float *u = h->u;
+    const unsigned int *locked = h->locked;
+    float delta = 0.0f;
+#pragma omp parallel for num_threads(threads) schedule(static) reduction(max : delta)
+    for (long long x0 = 1; x0 < (long long)m0 - 1; x0++) {
+        unsigned int offset = (unsigned int)((it % 2) != ((unsigned int)x0 % 2));
+        for (unsigned int x1 = 1 + offset; x1 + 1 < m1; x1 += 2) {
+            size_t c = (size_t)x0 * m1 + x1;
+            if (locked[c]) continue;
+            const float prev = u[c];
+            const float v = cell_update_2d(u[c - m1], u[c + m1], u[c - 1], u[c + 1]);
+            u[c] = v;
+            delta = fmax2(delta, (float)fabs(prev - v));
+        }
+    }
+    h->delta = delta;
+    h->currentIteration++;
+    return (h->delta < h->epsilon) ? ORACLE_SUCCESS_AND_CONVERGED : ORACLE_SUCCESS;
+}
+
+/* harmonic_complete_cpu's loop (harmonic_cpu.cpp:136-184; oracle_complete below) with the half-sweeps dealt to threads: the reference's field,
+ * iteration count and delta bit for bit, in 1 / threads of the time -- what makes a CPU-side statement of the reference's converged field
+ * possible at the benchmark's own size (8192^2: 45 001 half-sweeps, ~15 h on one core; tests/golden/generate_8192_golden.py).  progress_every > 0:
+ * a line on stderr every so many iterations. */
+int oracle_complete_parallel_2d(OracleHarmonic *h, int threads, unsigned int progress_every)
+{
+    if (h == NULL || h->n != 2 || h->m == NULL || h->u == NULL || h->locked == NULL || h->epsilon <= 0.0 || threads < 1 ||
+        h->numIterationsToStaggerCheck == 0)
+        return ORACLE_ERROR_INVALID_DATA;
+    unsigned int mMax = h->m[0] > h->m[1] ? h->m[0] : h->m[1];
+    h->currentIteration = 0;
+    h->delta = h->epsilon + 1.0;
+    int result = ORACLE_SUCCESS;
+    while (result != ORACLE_SUCCESS_AND_CONVERGED || h->currentIteration < mMax) {
+        if (h->currentIteration % h->numIterationsToStaggerCheck == 0) {
+            result = oracle_update_and_check_parallel_2d(h, threads);
+            if (progress_every && (h->currentIteration - 1) % progress_every == 0)
+                fprintf(stderr, "[oracle_complete_parallel_2d] iteration %u delta %.6e\n", h->currentIteration, (double)h->delta);
+        } else {
+            result = oracle_update_parallel_2d(h, threads);
+        }
+        if (result != ORACLE_SUCCESS && result != ORACLE_SUCCESS_AND_CONVERGED) return result;
+    }
     return ORACLE_SUCCESS;
 }
 

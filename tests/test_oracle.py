@@ -149,3 +149,28 @@ def test_parallel_half_sweeps_equal_the_sequential_ones():
         for _ in range(31):
             assert lib.oracle_update_parallel_2d(ct.byref(par.h), threads) == 0
         assert par.h.currentIteration == 31 and np.array_equal(par.u, seq.u)
+
+
+def test_parallel_complete_is_the_reference_loop_bit_for_bit(goldens):
+    """oracle_complete_parallel_2d -- harmonic_complete_cpu's loop with the half-sweeps dealt to OpenMP threads, what states the reference's
+    converged field at the benchmark's own size (tests/golden/generate_8192_golden.py) -- against a field the REFERENCE itself converged: the
+    benchmark's grid family at 512^2 (tests/golden/generate_synthetic_goldens.py): iteration count, delta, sha256 of the field; and against the
+    sequential checker on a ragged grid with another check interval."""
+    import ctypes as ct
+    import hashlib
+
+    from epic_amd.synthetic import synthetic_grid
+
+    lib = O.oracle()
+    lib.oracle_complete_parallel_2d.argtypes = (ct.POINTER(O.CHarmonic), ct.c_int, ct.c_uint)
+    lib.oracle_complete_parallel_2d.restype = ct.c_int
+    info = goldens["manifest"]["synthetic"]["grids"]["512"]
+    u0, locked = synthetic_grid([512, 512])
+    p = O.Problem([512, 512], u0, locked, info["epsilon"], info["stagger"])
+    assert lib.oracle_complete_parallel_2d(ct.byref(p.h), 4, 0) == 0
+    assert p.h.currentIteration == info["iterations"] and float(p.h.delta) == info["delta"]
+    assert hashlib.sha256(p.u.tobytes()).hexdigest() == info["sha_u"]
+    u0, locked = synthetic_grid([97, 211], 5, 0.1)
+    a, b = O.Problem([97, 211], u0, locked, 1e-4, 7), O.Problem([97, 211], u0, locked, 1e-4, 7)
+    assert lib.oracle_complete_parallel_2d(ct.byref(a.h), 3, 0) == 0 and lib.oracle_complete(ct.byref(b.h)) == 0
+    assert a.h.currentIteration == b.h.currentIteration and float(a.h.delta) == float(b.h.delta) and np.array_equal(a.u, b.u)
