@@ -1302,18 +1302,23 @@ def main():
             from epic_amd.synthetic import RAMP_RATE
 
             st4 = max(2, args.steps // 5)
-            r4 = slab_run([n4, n4], st4, 1, develop=200, ramp=RAMP_RATE)
+            try:
+                r4 = slab_run([n4, n4], st4, 1, develop=200, ramp=RAMP_RATE)
+            except BaseException as exc:   # an evidence leg: never lose the headline line (a failure on one rank only surfaces on the others as a collective's timeout)
+                r4 = None
+                out["config4"] = {"error": repr(exc)}
             sw4 = st4 * args.stagger
-            l4 = r4["dev_ms"] * 1e3 / sw4
-            out["config4"] = {
-                "workload": "synthetic 32768x32768 (BASELINE configs[3]) cut into %d row slabs, one process per GPU, %s %s" % (world, args.math, "jacobi"),
-                "grid": [n4, n4], "value": round(r4["free"] * sw4 / r4["wall"] / 1e6, 1), "unit": "Mcell-updates/s", "steps": st4,
-                "us_per_iteration": round(l4, 2), "halo": r4["halo"], "rows_per_gpu": r4["rows_local"],
-                "frac_per_gpu": round(BYTES_PER_CELL_SWEEP * r4["rows_local"] * n4 / (l4 * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
-                "start": "ramp: u = -%.1f x Manhattan distance to the goal on unlocked cells + 200 untimed iterations (epic_amd/synthetic.py: ramp_rows)" % RAMP_RATE,
-                "exchange_probe": r4["probe"],
-                "note": "frac_per_gpu as roofline.frac: 8 B x this rank's owned cells per iteration / mean device time per iteration (checks, "
-                        "exchange waits included) / 8 TB/s; value = unlocked cells of the whole grid x iterations / max-over-ranks wall time"}
+            l4 = r4["dev_ms"] * 1e3 / sw4 if r4 else 0.0
+            if r4:
+              out["config4"] = {
+                  "workload": "synthetic 32768x32768 (BASELINE configs[3]) cut into %d row slabs, one process per GPU, %s %s" % (world, args.math, "jacobi"),
+                  "grid": [n4, n4], "value": round(r4["free"] * sw4 / r4["wall"] / 1e6, 1), "unit": "Mcell-updates/s", "steps": st4,
+                  "us_per_iteration": round(l4, 2), "halo": r4["halo"], "rows_per_gpu": r4["rows_local"],
+                  "frac_per_gpu": round(BYTES_PER_CELL_SWEEP * r4["rows_local"] * n4 / (l4 * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                  "start": "ramp: u = -%.1f x Manhattan distance to the goal on unlocked cells + 200 untimed iterations (epic_amd/synthetic.py: ramp_rows)" % RAMP_RATE,
+                  "exchange_probe": r4["probe"],
+                  "note": "frac_per_gpu as roofline.frac: 8 B x this rank's owned cells per iteration / mean device time per iteration (checks, "
+                          "exchange waits included) / 8 TB/s; value = unlocked cells of the whole grid x iterations / max-over-ranks wall time"}
     if in_library is not None:
         out["in_library"] = in_library
     if rank == 0:
