@@ -178,7 +178,9 @@ int epic_hip_multi_report(EpicHarmonicT *harmonic, char *buf, size_t cap);
 /* ---- configuration ---------------------------------------------------------------------------------------------------
  * The library reads its environment (the EPIC_HIP_* knobs of INTEGRATION.md section 6) ONCE per Harmonic, when the library-side
  * context of that Harmonic is created (the first harmonic_initialize_*_gpu), into one struct (epic_amd/csrc/driver_config.h);
- * nothing is read again behind the caller's back.
+ * nothing is read again behind the caller's back.  Two classes: PRODUCT knobs (EPIC_HIP_MATH, _SCHEME, _TRACK, _DEVICES with _HALO / _NO_PEER /
+ * _THREADS / _SPIN_US, _TOL_FINISH, _DEFER) are always honoured; STUDY knobs (thresholds, task heights, tile plans, launch flags, the tuner: they
+ * select a code path, never a result) are read only under EPIC_HIP_STUDY=1 -- one that is set without it is ignored and named once on stderr.
  * epic_hip_config_dump: one JSON object in buf -- "config": every knob as read then; "state": dimensions and the modes in force now
  * (epic_hip_set_* change them); "path": the kernel family a batch of plain iterations takes (LDS tiles / fused pairs / tracked
  * pairs / list-driven sweeps / single sweeps, replayed from a hipGraph or not), the tile plan, task heights, and in multi-device
