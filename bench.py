@@ -305,6 +305,15 @@ def parity_object(args, E, MODES, relaxed, locked_8192):
                                     "precise redblack (library default)": fields[("precise", "redblack", "s")][0]},
                      iterations={"%s jacobi" % args.math: fields[(args.math, "jacobi", "s")][1],
                                  "precise redblack (library default)": fields[("precise", "redblack", "s")][1]})
+            try:   # round 6: the reference's loop run on the CPU at this size once (tests/golden/generate_8192_golden.py --cube 512)
+                import hashlib
+
+                g5 = json.load(open(os.path.join(gdir, "synthetic_512cubed.json")))
+                e["relax_default_equals_cpu_statement_of_the_reference"] = bool(
+                    hashlib.sha256(np.ascontiguousarray(fields[("precise", "redblack")]).tobytes()).hexdigest() == g5["sha_u"])
+                e["cpu_statement"] = "tests/golden/synthetic_512cubed.json: %d iterations, delta %.3e, %d threads, %.0f s" % (g5["iterations"], g5["delta"], g5["threads"], g5["seconds"])
+            except (OSError, ValueError, KeyError):
+                e["relax_default_equals_cpu_statement_of_the_reference"] = None
             out["configs"]["configs[4] 512x512x512"] = e
         missed = [k for k, v in out["configs"].items() if v.get("within_bar") is False]
         out["misses"] = missed
@@ -468,6 +477,10 @@ def summarise_into_config(out):
         if e8.get("relax_default_equals_cpu_statement_of_the_reference") is not None:
             cfg["default_field_8192_equals_cpu_reference"] = e8["relax_default_equals_cpu_statement_of_the_reference"]
             cfg["timed_mode_8192_max_rel_vs_reference"] = e8.get("max_rel")
+        e5 = (out["parity"].get("configs") or {}).get("configs[4] 512x512x512") or {}
+        if e5.get("relax_default_equals_cpu_statement_of_the_reference") is not None:
+            cfg["default_field_512cubed_equals_cpu_reference"] = e5["relax_default_equals_cpu_statement_of_the_reference"]
+            cfg["timed_mode_512cubed_max_rel_vs_reference"] = e5.get("max_rel")
     for name, secs in (cfg.get("maps_seconds") or {}).items():
         cfg["%s_seconds" % name] = secs
     roof = out.get("roofline") or {}

@@ -202,6 +202,58 @@ static uint64_t rb_update_3d(OracleHarmonic *h, int check)
     return updates;
 }
 
+/* The 3-D half-sweep (harmonic_cpu.cpp:81-133, rb_update_3d above) with its planes dealt to OpenMP threads: every updated cell reads only cells of
+ * the other colour, so planes are independent and field and max |du| are the sequential ones bit for bit.  check: also h->delta. */
+static int rb_update_3d_parallel(OracleHarmonic *h, int check, int threads)
+{
+    const unsigned int m0 = h->m[0], m1 = h->m[1], m2 = h->m[2];
+    const size_t s0 = (size_t)m1 * m2, s1 = m2;
+    const unsigned int it = h->currentIteration;
+    float *u = h->u;
+    const unsigned int *locked = h->locked;
+    float delta = 0.0f;
+#pragma omp parallel for num_threads(threads) schedule(static) reduction(max : delta)
+    for (long long x0 = 1; x0 < (long long)m0 - 1; x0++) {
+        for (unsigned int x1 = 1; x1 + 1 < m1; x1++) {
+            unsigned int offset = (unsigned int)((it % 2) != ((unsigned int)x0 % 2));
+            if (x1 % 2 == 0) offset = !offset;
+            for (unsigned int x2 = 1 + offset; x2 + 1 < m2; x2 += 2) {
+                size_t c = (size_t)x0 * s0 + x1 * s1 + x2;
+                if (locked[c]) continue;
+                const float prev = u[c];
+                const float v = cell_update_3d(u[c - s0], u[c + s0], u[c - s1], u[c + s1], u[c - 1], u[c + 1]);
+                u[c] = v;
+                if (check) delta = fmax2(delta, (float)fabs(prev - v));
+            }
+        }
+    }
+    if (check) h->delta = delta;
+    h->currentIteration++;
+    return ORACLE_SUCCESS;
+}
+
+/* harmonic_complete_cpu's loop for n = 3 with the half-sweeps dealt to threads (as oracle_complete_parallel_2d): the reference's converged 512^3
+ * field of BASELINE configs[4] on the CPU (tests/golden/generate_8192_golden.py --cube 512). */
+int oracle_complete_parallel_3d(OracleHarmonic *h, int threads, unsigned int progress_every)
+{
+    if (h == NULL || h->n != 3 || h->m == NULL || h->u == NULL || h->locked == NULL || h->epsilon <= 0.0 || threads < 1 ||
+        h->numIterationsToStaggerCheck == 0)
+        return ORACLE_ERROR_INVALID_DATA;
+    unsigned int mMax = 0;
+    for (unsigned int i = 0; i < 3; i++) mMax = h->m[i] > mMax ? h->m[i] : mMax;
+    h->currentIteration = 0;
+    h->delta = h->epsilon + 1.0;
+    int converged = 0;
+    while (!converged || h->currentIteration < mMax) {
+        const int check = (h->currentIteration % h->numIterationsToStaggerCheck) == 0;
+        rb_update_3d_parallel(h, check, threads);
+        converged = check && h->delta < h->epsilon;
+        if (check && progress_every && (h->currentIteration - 1) % progress_every == 0)
+            fprintf(stderr, "[oracle_complete_parallel_3d] iteration %u delta %.6e\n", h->currentIteration, (double)h->delta);
+    }
+    return ORACLE_SUCCESS;
+}
+
 static uint64_t g_updates; /* cells recomputed since oracle_reset_counters() */
 
 void oracle_reset_counters(void) { g_updates = 0; }

@@ -10,6 +10,7 @@ max, and 16 384 seeded samples.  tests/test_gpu_bench_parity.py then holds the l
 device) to it, sha256 included.
 
     python tests/golden/generate_8192_golden.py [--threads 8]        (~2 h on 8 cores of the build container; progress on stderr)
+    python tests/golden/generate_8192_golden.py --cube 512           (BASELINE configs[4]: 512^3, 3 801 half-sweeps of the 7-point stencil)
 """
 import argparse
 import ctypes as ct
@@ -32,25 +33,27 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
     ap.add_argument("--size", type=int, default=8192)
+    ap.add_argument("--cube", type=int, default=0, help="N: the N x N x N grid of BASELINE configs[4] (512) instead of the 2-D one")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
-    n = a.size
-    m = [n, n]
+    n = a.cube or a.size
+    m = [n, n, n] if a.cube else [n, n]
     u0, locked = synthetic_grid(m)
     lib = O.oracle()
-    lib.oracle_complete_parallel_2d.argtypes = (ct.POINTER(O.CHarmonic), ct.c_int, ct.c_uint)
-    lib.oracle_complete_parallel_2d.restype = ct.c_int
+    loop = lib.oracle_complete_parallel_3d if a.cube else lib.oracle_complete_parallel_2d
+    loop.argtypes = (ct.POINTER(O.CHarmonic), ct.c_int, ct.c_uint)
+    loop.restype = ct.c_int
     p = O.Problem(m, u0, locked, 1e-6, 100)
     t0 = time.time()
-    rc = lib.oracle_complete_parallel_2d(ct.byref(p.h), a.threads, 1000)
+    rc = loop(ct.byref(p.h), a.threads, 100 if a.cube else 1000)
     secs = time.time() - t0
     assert rc == 0, rc
     rng = np.random.default_rng(20240601)
-    idx = np.sort(rng.choice(n * n, size=16384, replace=False)).astype(np.int64)
+    idx = np.sort(rng.choice(int(np.prod(m)), size=16384, replace=False)).astype(np.int64)
     reached = (p.u > -9e5) & (locked == 0)
     doc = {
-        "generator": "tests/golden/generate_8192_golden.py --threads %d" % a.threads,
-        "what": "harmonic_complete_cpu's loop on the benchmark's grid with its half-sweeps dealt to threads (oracle_complete_parallel_2d: the sequential result bit for bit)",
+        "generator": "tests/golden/generate_8192_golden.py --threads %d%s" % (a.threads, " --cube %d" % a.cube if a.cube else ""),
+        "what": "harmonic_complete_cpu's loop on the benchmark's grid with its half-sweeps dealt to threads (oracle_complete_parallel_%dd: the sequential result bit for bit)" % len(m),
         "m": m, "seed": DEFAULT_SEED, "density": 0.05, "epsilon": 1e-6, "stagger": 100,
         "iterations": int(p.h.currentIteration), "delta": float(p.h.delta), "seconds": round(secs, 1), "threads": a.threads,
         "sha_u0": hashlib.sha256(u0.tobytes()).hexdigest(), "sha_locked": hashlib.sha256(locked.tobytes()).hexdigest(),
@@ -59,7 +62,7 @@ def main():
         "min": float(p.u[reached].min()), "max": float(p.u[reached].max()),
         "sample_index": idx.tolist(), "sample_u": [float(x) for x in p.u[idx]],
     }
-    out = a.out or os.path.join(HERE, "synthetic_%d.json" % n)
+    out = a.out or os.path.join(HERE, "synthetic_%dcubed.json" % n if a.cube else "synthetic_%d.json" % n)
     with open(out, "w") as f:
         json.dump(doc, f, separators=(",", ":"))
     print("wrote %s: %d iterations, delta %.3e, %.0f s" % (out, doc["iterations"], doc["delta"], secs))

@@ -116,6 +116,33 @@ def test_8192_squared_tol_jacobi_against_the_reference_identical_mode(record_pro
     assert abs(its - rits) <= 0.25 * rits
 
 
+def test_512_cubed_default_relaxation_equals_the_cpu_statement_of_the_reference(record_property):
+    """BASELINE configs[4] at full size: the library's defaults (precise arithmetic, the reference's red-black half-sweeps of the 7-point stencil)
+    relaxed to eps = 1e-6 on the device against the reference's loop run on the CPU at this size (round 6: tests/golden/generate_8192_golden.py
+    --cube 512 -- harmonic_complete_cpu's loop with the half-sweeps dealt to threads, the sequential result bit for bit, pinned against the reference's
+    own 3-D goldens by tests/test_oracle.py): iteration count, delta, 16 384 samples and the sha256 of all 134 217 728 cells.  And the timed tol
+    arithmetic's converged field against that same field."""
+    import hashlib
+    import json
+
+    golden = os.path.join(O.ROOT, "tests", "golden", "synthetic_512cubed.json")
+    if not os.path.exists(golden):
+        pytest.skip("tests/golden/synthetic_512cubed.json not generated")
+    g = json.load(open(golden))
+    m = [512, 512, 512]
+    u0, locked = synthetic_grid(m)
+    assert g["sha_u0"] == hashlib.sha256(u0.tobytes()).hexdigest() and g["sha_locked"] == hashlib.sha256(locked.tobytes()).hexdigest()
+    ref, rits, rdelta = relax(m, u0, locked, eh.MATH_PRECISE, eh.SCHEME_REDBLACK)
+    ref = ref.copy()
+    assert (rits, rdelta) == (g["iterations"], g["delta"])
+    assert np.array_equal(ref[np.asarray(g["sample_index"])], np.asarray(g["sample_u"], dtype=np.float32))
+    assert hashlib.sha256(ref.tobytes()).hexdigest() == g["sha_u"], "the device's converged 512^3 field differs from the CPU statement of the reference's"
+    got, its, delta = relax(m, u0, locked, eh.MATH_TOL, eh.SCHEME_JACOBI)
+    rel, ab = distance(got, ref, locked)
+    record_property("max_rel", rel)
+    assert delta < 1e-6 and rel <= BAR
+
+
 @pytest.mark.parametrize("name", ["g2d_64", "g2d_70x66_dense", "g2d_8x300", "g3d_16", "g3d_20x12x34"])
 def test_empty_environment_runs_the_reference_iteration(goldens, name):
     """No EPIC_HIP_* variable at all (what the ROS plugin's process looks like): harmonic_complete_gpu must produce the

@@ -174,3 +174,19 @@ def test_parallel_complete_is_the_reference_loop_bit_for_bit(goldens):
     a, b = O.Problem([97, 211], u0, locked, 1e-4, 7), O.Problem([97, 211], u0, locked, 1e-4, 7)
     assert lib.oracle_complete_parallel_2d(ct.byref(a.h), 3, 0) == 0 and lib.oracle_complete(ct.byref(b.h)) == 0
     assert a.h.currentIteration == b.h.currentIteration and float(a.h.delta) == float(b.h.delta) and np.array_equal(a.u, b.u)
+
+
+@pytest.mark.parametrize("name", ["g3d_8", "g3d_16", "g3d_7x9x11", "g3d_20x12x34"])
+def test_parallel_complete_3d_is_the_reference_loop_bit_for_bit(goldens, name):
+    """oracle_complete_parallel_3d (the 7-point half-sweeps dealt to threads; what states the reference's converged 512^3 field of BASELINE
+    configs[4], tests/golden/synthetic_512cubed.json) against the fields the REFERENCE converged: iteration count, delta, every cell."""
+    import ctypes as ct
+
+    lib = O.oracle()
+    lib.oracle_complete_parallel_3d.argtypes = (ct.POINTER(O.CHarmonic), ct.c_int, ct.c_uint)
+    lib.oracle_complete_parallel_3d.restype = ct.c_int
+    g, info = goldens["small"], goldens["manifest"]["small"][name]
+    p = O.Problem([int(x) for x in g[name + "/m"]], g[name + "/u0"], g[name + "/locked"], info["epsilon"], info["stagger"])
+    assert lib.oracle_complete_parallel_3d(ct.byref(p.h), 3, 0) == 0
+    assert p.h.currentIteration == info["iterations"] and float(p.h.delta) == info["delta"]
+    assert np.array_equal(p.u, np.ravel(g[name + "/converged"]))
