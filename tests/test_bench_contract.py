@@ -224,6 +224,9 @@ def test_round_6_what_the_driver_keeps_is_scalars_and_the_node_flow_leg_is_in_th
     # the campaign's record as committed (tests/golden/tol_campaign.json)
     camp = json.load(open(os.path.join(ROOT, "tests", "golden", "tol_campaign.json")))["summary"]
     assert (c["tol_campaign_cases"], c["tol_campaign_misses"]) == (camp["cases"], camp["misses"]) and c["tol_campaign_cases"] >= 300
+    # the converged fields of both timed grids against the CPU statements of the reference's loop (tests/golden/synthetic_8192.json, _512cubed.json)
+    assert c["default_field_8192_equals_cpu_reference"] is True and c["timed_mode_8192_max_rel_vs_reference"] < 2e-6
+    assert c["default_field_512cubed_equals_cpu_reference"] is True and c["timed_mode_512cubed_max_rel_vs_reference"] < 2e-6
     # 3-D: three whole relaxations; where the default run's minutes go
     assert len(d["config5"]["relax_seconds"]) == 3
     assert d["leg_seconds"]["whole run"] < 420 and d["leg_seconds"]["whole run"] >= sum(v for k, v in d["leg_seconds"].items() if k != "whole run") - 1.0
