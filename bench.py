@@ -200,7 +200,7 @@ def parity_object(args, E, MODES, relaxed, locked_8192):
 
     out = {"mode": {"math": args.math, "scheme": args.scheme}, "bar": "|du| <= 1e-5 max(1, |u|) over reached free cells",
            "finish": ("tol relaxations leave the tol arithmetic at the first check with delta < 10 eps (100 eps for eps <= 1e-5) and finish with the reference's own "
-                      "iteration (precise red-black); at eps > 1e-5 that check keeps its own verdict (round 6: tests/tol_campaign.py, 630 generated cases against the "
+                      "iteration (precise red-black); at eps > 1e-5 that check keeps its own verdict (round 6: tests/tol_campaign.py, 720 generated cases against the "
                       "reference -- config.tol_campaign_*): the library's default for harmonic_execute_gpu / harmonic_complete_gpu; "
                       "`tol_iteration_alone` repeats a config with EPIC_HIP_TOL_FINISH=0") if args.math == "tol" else None,
            "configs": {}}

@@ -68,7 +68,7 @@ int epic_hip_fused_rows_per_task(EpicHarmonicT *harmonic);
  * reference's iteration from a state within a few 1e-5 of it: maps/umass.png 1.4e-6 from harmonic_complete_cpu's field instead of 1.6e-5.  At the
  * callers' epsilons (> 1e-5) the hand-over check keeps its own verdict (round 6: on maps that converge within a few checks the reference stops at that
  * very check), and a first check that reports delta = 0 exactly (a run that has not moved yet) does not hand over.  Measured against the reference on
- * 630 generated cases: tests/tol_campaign.py, DESIGN.md section 2.
+ * 720 generated cases (2-D and 3-D): tests/tol_campaign.py, DESIGN.md section 2.
  * EPIC_HIP_TOL_FINISH=0 in the environment keeps the tol iteration to the end (honoured for epsilon <= 1e-5 only: above, the
  * finishing phase is what makes the stop the reference's).  EPIC_HIP_TOL_FINISH_FACTOR=f replaces the 10 / 100 (a study knob:
  * tools/finish_study_gpu.py swept it over every map of the reference).

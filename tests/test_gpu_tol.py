@@ -437,7 +437,7 @@ def test_tol_complete_gpu_equals_the_checkers_loop_bit_for_bit(goldens, name, sc
 
 
 CAMPAIGN_SAMPLE = [("dense", 1407), ("dense", 1400), ("maze", 1103), ("rooms", 1004), ("corridor", 1206), ("labyrinth", 1600), ("office", 1506),
-                   ("sparse", 1301)]
+                   ("sparse", 1301), ("cube", 1708), ("cube", 1700)]
 
 
 @pytest.mark.parametrize("family,seed", CAMPAIGN_SAMPLE)

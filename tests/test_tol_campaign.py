@@ -50,10 +50,10 @@ def test_what_the_record_says(record):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("family,seed", [("dense", 1407), ("labyrinth", 1600), ("maze", 1103)])
+@pytest.mark.parametrize("family,seed", [("dense", 1407), ("labyrinth", 1600), ("maze", 1103), ("cube", 1708)])
 def test_a_sample_re_run_today_gives_the_recorded_numbers(record, family, seed):
     """Generator and checker are pinned by the record: the same map (sha of its mask), the same iteration counts, hand-over iteration and
-    distance, for all six (epsilon, scheme) runs of the map -- one of them a recorded miss (dense 1407, Jacobi, 1e-2)."""
+    distance, for all six (epsilon, scheme) runs of the map -- two of them recorded misses (dense 1407 and the 3-D cube 1708, Jacobi, 1e-2)."""
     want = [c for c in record["cases"] if c["family"] == family and c["seed"] == seed]
     assert len(want) == 6
     got = T.run_map((family, seed))
@@ -77,6 +77,7 @@ def test_the_generated_maps_are_the_same_everywhere():
 
 
 EXPECTED_MAPS = {'corridor': ([156, 135], '8b09be044d741990', 1),
+ 'cube': ([16, 20, 64], '1b857df62d86812d', 3),
  'dense': ([62, 102], 'dc3779361d686ce5', 4),
  'labyrinth': ([43, 109], '0262ee41a91d1218', 1),
  'maze': ([118, 77], '4137f1bdd2a2e35e', 3),

@@ -13,7 +13,8 @@ exists -- the build container --, else the checker's bit-identical restatement o
   sparse     2-6 % random obstacle cells
   dense      20-38 % random obstacle cells (close to the percolation threshold: crooked, narrow ways)
   office     rooms with clutter inside
-  labyrinth  a spanning-tree maze without loops, ONE goal in a corner: the longest ways round, tens of thousands of iterations
+  labyrinth  a spanning-tree maze without loops, ONE goal in a corner: the longest ways round
+  cube       3-D (n = 3, the 7-point stencil of BASELINE configs[4]): 16-72 cells per side, 3-25 % random obstacle cells, a few slabs with holes
 with 1-5 goals, 48-384 cells per side, eps in {1e-2, 1e-3, 1e-6} (python default, ROS callers, the benchmark), both schemes.
 
 Per case: the reference's iterations, the tol loop's (tol phase + finishing phase), the largest |du| / max(1, |u|) over the cells the
@@ -39,7 +40,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 
-FAMILIES = ("rooms", "maze", "corridor", "sparse", "dense", "office", "labyrinth")
+FAMILIES = ("rooms", "maze", "corridor", "sparse", "dense", "office", "labyrinth", "cube")
 EPSILONS = (1e-2, 1e-3, 1e-6)
 SCHEMES = ("redblack", "jacobi")
 BAR = 1e-5
@@ -130,9 +131,37 @@ def gen_random(rng, rows, cols, lo, hi):
     return _border(rng.random((rows, cols)) < float(rng.uniform(lo, hi)))
 
 
+def make_cube(rng):
+    d = [int(rng.integers(16, 73)) for _ in range(3)]
+    occ = rng.random(d) < float(rng.uniform(0.03, 0.25))
+    for _ in range(int(rng.integers(0, 4))):      # walls across the volume with a hole: rooms in 3-D
+        ax = int(rng.integers(0, 3))
+        pos = int(rng.integers(3, d[ax] - 3))
+        wall = [slice(None)] * 3
+        wall[ax] = pos
+        occ[tuple(wall)] = True
+        hole = [slice(int(rng.integers(1, max(2, d[i] - 4))), None) for i in range(3)]
+        hole = [slice(h.start, h.start + int(rng.integers(1, 4))) for h in hole]
+        hole[ax] = pos
+        occ[tuple(hole)] = False
+    occ[0], occ[-1] = True, True
+    occ[:, 0], occ[:, -1] = True, True
+    occ[:, :, 0], occ[:, :, -1] = True, True
+    free = np.argwhere(~occ)
+    goals = free[rng.choice(len(free), size=min(len(free), int(rng.integers(1, 4))), replace=False)]
+    u0 = np.full(d, -1e6, dtype=np.float32)
+    locked = occ.astype(np.uint32)
+    for g in goals:
+        u0[tuple(g)] = 0.0
+        locked[tuple(g)] = 1
+    return d, u0.ravel(), locked.ravel()
+
+
 def make_case(family, seed):
     """-> (m, u0, locked): obstacles locked at -1e6, goals locked at 0, free cells at -1e6 (the loaders' convention)."""
     rng = np.random.default_rng(seed)
+    if family == "cube":
+        return make_cube(rng)
     big = family in ("sparse", "rooms", "office")
     rows = int(rng.integers(48, 385 if big else 200))
     cols = int(rng.integers(48, 385 if big else 200))
