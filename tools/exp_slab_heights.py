@@ -2,6 +2,8 @@
 """us per iteration of the fused tol Jacobi pass on slab-shaped grids (rows x 8192: what one GPU of 8, 4, 2 holds) against the task
 height (EPIC_HIP_FUSED_ROWS; 0 = the rule): python tools/exp_slab_heights.py   (one process per point: the knob is read per context)"""
 import json, os, subprocess, sys
+
+os.environ.setdefault("EPIC_HIP_STUDY", "1")   # EPIC_HIP_FUSED_ROWS is a study knob (epic_amd/csrc/driver_config.cpp); the children inherit it
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
 import sys, ctypes as ct, os
