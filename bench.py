@@ -447,9 +447,12 @@ def summarise_into_config(out):
             "timed_scheme": legs["relax_jacobi"],
             "note": "harmonic_execute_gpu from the initial field to the reference's stop, final D2H included; library_default = no "
                     "environment (bit-identical to harmonic_complete_cpu); full objects: the line's relax* keys"}
-    if "parity" in out:
+    if "parity" in out and "error" not in out["parity"]:
         cfg["parity_misses"] = out["parity"].get("misses")
-    if "config5" in out:
+    for key in ("config5", "config4", "maps", "node_flow", "parity", "cpu_baseline"):
+        if isinstance(out.get(key), dict) and set(out[key]) == {"error"}:
+            cfg["%s_error" % key] = out[key]["error"]
+    if "config5" in out and "frac" in out["config5"]:
         cfg["config5_frac"] = out["config5"]["frac"]
         for key, leg3 in (out["config5"].get("relax_seconds") or {}).items():
             cfg["config5_relax_seconds_%s" % key.split(" (")[0].replace(" ", "_").replace("-", "")] = leg3["seconds"]
@@ -457,7 +460,7 @@ def summarise_into_config(out):
             cfg["config5_frac_default_math"] = out["config5"]["precise"]["frac"]
     if "kernels" in out and "precise" in out["kernels"]:
         cfg["default_math_frac"] = out["kernels"]["precise"]["frac"]   # the bit-exact sweep an unchanged caller's kernels run at
-    if "maps" in out:
+    if "maps" in out and "error" not in out["maps"]:
         cfg["maps_seconds"] = {name: out["maps"]["%s default eps 1e-06" % name]["seconds"] for name in ("maze", "umass")
                                if "%s default eps 1e-06" % name in out["maps"]}
     # The driver's record keeps SCALARS of `config` only (round 5's nested relax_to_eps / parity_misses / maps_seconds were dropped from
@@ -471,7 +474,7 @@ def summarise_into_config(out):
         cfg["relax_fastest_mode"] = rte["fastest_parity_clean"]["mode"]
         cfg["relax_fastest_iterations"] = rte["fastest_parity_clean"]["iterations"]
         cfg["relax_finishing_iterations"] = rte["fastest_parity_clean"]["finishing_iterations"]
-    if "parity" in out:
+    if "parity" in out and "error" not in out["parity"]:
         cfg["parity_miss_count"] = len(out["parity"].get("misses") or [])
         e8 = (out["parity"].get("configs") or {}).get("configs[2] 8192x8192 (the timed grid)") or {}
         if e8.get("relax_default_equals_cpu_statement_of_the_reference") is not None:
@@ -488,6 +491,8 @@ def summarise_into_config(out):
         if roof.get(src) is not None:
             cfg[dst] = roof[src]
     nf = out.get("node_flow") or {}
+    if "error" in nf:
+        nf = {}
     for name, key in (("maze", "maze"), ("umass", "umass"), ("8192^2", "8192")):
         e = nf.get(name)
         if e and e.get("node_flow"):
@@ -547,9 +552,16 @@ LEG_SECONDS = {}   # wall seconds per leg of this run, reported in the line (`le
 
 
 def timed_leg(name, fn, *a, **kw):
+    """An evidence leg beside the headline: timed, and never allowed to take the line with it -- a leg that raises is reported as
+    {"error": ...} under its key (and on stderr), the keys derived from it are simply absent."""
     t0 = time.perf_counter()
     try:
         return fn(*a, **kw)
+    except Exception as exc:   # noqa: BLE001
+        import traceback
+
+        traceback.print_exc()
+        return {"error": "%s leg failed: %r" % (name, exc)}
     finally:
         LEG_SECONDS[name] = round(time.perf_counter() - t0, 1)
 
