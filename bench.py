@@ -600,13 +600,14 @@ def main():
             r2 = subprocess.run([sys.executable, os.path.abspath(__file__), "--in-library-child", str(world), "--steps", str(args.steps),
                                  "--math", args.math, "--size", str(args.size), "--develop", str(min(args.develop, 6000)),
                                  "--stagger", str(args.stagger), "--no-live-traffic"],
-                                env=env, capture_output=True, text=True, timeout=900 if world >= 4 else 300)
+                                env=env, capture_output=True, text=True, timeout=600 if world >= 4 else 300)   # (well inside the other ranks' wait below)
             lines = [l for l in r2.stdout.splitlines() if l.startswith("{")]
             in_library = json.loads(lines[-1]) if lines else {"error": "rc %d: %s" % (r2.returncode, r2.stderr[-400:])}
             if in_library is not None and r2.stderr:
                 in_library["stderr_tail"] = r2.stderr[-600:]   # the library reports refused peer access here
         except BaseException as exc:   # evidence leg only: never lose the headline line
             in_library = {"error": repr(exc)}
+        LEG_SECONDS["in_library child (one process, all devices)"] = round(time.perf_counter() - T_START, 1)
     import torch  # first: one HIP runtime per process (epic_amd/epic_harmonic.py)
 
     if world != args.gpus:
@@ -627,7 +628,7 @@ def main():
 
         import torch.distributed as dist
 
-        wait = datetime.timedelta(minutes=15)   # the other ranks wait here while rank 0 runs the in-library leg
+        wait = datetime.timedelta(minutes=20)   # the other ranks wait here while rank 0 runs the in-library leg (at most 10 minutes: above)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=wait)
         else:
@@ -1012,6 +1013,7 @@ def main():
         finally:
             if h is not None:
                 abi_release(h)
+        LEG_SECONDS["imports, grid, report, timed steps, default relaxation"] = round(time.perf_counter() - T_START, 1)
         from epic_amd.synthetic import RAMP_RATE, ramp_rows
 
         def slabs_timed(grid3, label, steps3, dev_sweeps):
@@ -1041,12 +1043,15 @@ def main():
                     abi_release(hg)
 
         if not args.no_extra_legs:
+            _t5 = time.perf_counter()
             try:   # BASELINE configs[4] on slabs of PLANES (the 3-D form of the same decomposition)
                 res["config5"] = slabs_timed([512, 512, 512], "synthetic 512^3 (BASELINE configs[4]) cut into plane slabs, %s Jacobi" % args.math,
                                              max(2, args.steps // 4), 100)
             except BaseException as exc:   # evidence legs: never lose the line
                 res["config5"] = {"error": repr(exc)}
+            LEG_SECONDS["config5"] = round(time.perf_counter() - _t5, 1)
         if not args.no_extra_legs and not args.no_config4 and nd >= 4:
+            _t4 = time.perf_counter()
             try:   # BASELINE configs[3] through the unchanged ABI: 8.6 GB of host arrays, ~1 minute of host-side generation
                 import psutil
 
@@ -1057,6 +1062,9 @@ def main():
                                                  max(2, args.steps // 5), 200)
             except BaseException as exc:
                 res["config4"] = {"error": repr(exc)}
+            LEG_SECONDS["config4"] = round(time.perf_counter() - _t4, 1)
+        LEG_SECONDS["whole run"] = round(time.perf_counter() - T_START, 1)
+        res["leg_seconds"] = dict(LEG_SECONDS)
         res["note"] = ("harmonic_*_gpu on one Harmonic in ONE process, EPIC_HIP_DEVICES=0..N-1 (one issuing thread per device, halo rows by "
                        "hipMemcpyPeerAsync); host-clocked.  relax_default: harmonic_execute_gpu to eps = 1e-6 with the library defaults "
                        "(precise, red-black, work lists per slab), incl. the final D2H")
@@ -1258,7 +1266,9 @@ def main():
 
     weak_first = args.weak and world > 1
     main_grid = [n * world, n] if weak_first else [n, n]
+    _t_leg = time.perf_counter()
     r = slab_run(main_grid, args.steps, args.warmup)
+    LEG_SECONDS["headline: develop, tune, probe, timed steps"] = round(time.perf_counter() - _t_leg, 1)
     launch_us = r["dev_ms"] * 1e3 / sweeps
     actual_backend = dist.get_backend() if world > 1 else "none"
     transport = {"nccl": "RCCL send/recv of device rows (xGMI)", "gloo": "gloo, rows staged through host memory",
@@ -1304,7 +1314,9 @@ def main():
         out["ranks"] = {"ranks_seen": dist.get_world_size(), "backend": actual_backend, "per_rank": seen}
         if not args.no_extra_legs:
             other_grid = [n, n] if weak_first else [n * world, n]
+            _t_leg = time.perf_counter()
             w = slab_run(other_grid, max(2, args.steps // 2), 1)
+            LEG_SECONDS["the other scaling mode"] = round(time.perf_counter() - _t_leg, 1)
             wsweeps = max(2, args.steps // 2) * args.stagger
             wl = w["dev_ms"] * 1e3 / wsweeps
             out["strong" if weak_first else "weak"] = {
@@ -1327,11 +1339,13 @@ def main():
             from epic_amd.synthetic import RAMP_RATE
 
             st4 = max(2, args.steps // 5)
+            _t_leg = time.perf_counter()
             try:
                 r4 = slab_run([n4, n4], st4, 1, develop=200, ramp=RAMP_RATE)
             except BaseException as exc:   # an evidence leg: never lose the headline line (a failure on one rank only surfaces on the others as a collective's timeout)
                 r4 = None
                 out["config4"] = {"error": repr(exc)}
+            LEG_SECONDS["config4"] = round(time.perf_counter() - _t_leg, 1)
             sw4 = st4 * args.stagger
             l4 = r4["dev_ms"] * 1e3 / sw4 if r4 else 0.0
             if r4:
@@ -1346,6 +1360,9 @@ def main():
                           "exchange waits included) / 8 TB/s; value = unlocked cells of the whole grid x iterations / max-over-ranks wall time"}
     if in_library is not None:
         out["in_library"] = in_library
+    if world > 1:
+        LEG_SECONDS["whole run (rank 0)"] = round(time.perf_counter() - T_START, 1)
+        out["leg_seconds"] = dict(LEG_SECONDS)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
