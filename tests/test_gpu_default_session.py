@@ -18,6 +18,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
 
+# parametrised families of those files that name their scheme themselves (a parameter, or SCHEME_JACOBI / SCHEME_REDBLACK in the body): the session's
+# scheme cannot reach them, the outer session has run them already (314 cases, a minute of the driver's GPU run)
+EXPLICIT = ["tol_fused_double_sweeps", "checkers_loop_bit_for_bit", "tol_fused_redblack_pairs", "tol_iterations_equal_the_checker_bit", "two_planes_per_wave",
+            "redblack_half_sweeps_equal_reference_golden", "fused_passes_cut", "tol_fused_pairs_on_slabs"]
+
 FILES = ["tests/test_gpu_parity.py", "tests/test_gpu_multi_device.py", "tests/test_gpu_tol.py", "tests/test_gpu_config.py"]
 
 
@@ -27,7 +32,8 @@ def test_the_scheme_dependent_files_pass_with_the_library_default_as_session_sch
     env = {k: v for k, v in os.environ.items() if k not in ("EPIC_HIP_SCHEME", "PYTEST_CURRENT_TEST")}
     env["EPIC_TEST_SCHEME"] = "default"
     r = subprocess.run([sys.executable, "-m", "pytest", *FILES, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
-                        "-k", "not 8192_tracking and not relax_8192 and not 32768 and not campaigns_maps and not tracked_pairs_on_slabs and not tracked_tol_pairs_on_slabs"],
+                        "-k", "not 8192_tracking and not relax_8192 and not 32768 and not campaigns_maps and not tracked_pairs_on_slabs and not tracked_tol_pairs_on_slabs"
+                              " and not " + " and not ".join(EXPLICIT)],
                        # (the longest ones and round 6's slab-pair / campaign tests: run in the outer session, their schemes set explicitly)
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=840)
     tail = r.stdout[-3000:] + r.stderr[-1500:]
