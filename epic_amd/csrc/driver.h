@@ -302,6 +302,7 @@ const char *plain_batch_path(const Ctx *c);     // the kernel family a batch of 
 // ---- driver_enqueue.hip -------------------------------------------------------------------------------------------------
 void note_iterations(Ctx *c, unsigned first, unsigned count);   // iterations [first, first + count) are about to be enqueued (see Ctx::seq_next)
 hipError_t enqueue_sweep(Ctx *c, bool check, unsigned iteration);
+hipError_t enqueue_check_sweep(Ctx *c, unsigned iteration);   // a check iteration as the context's scheme and EPIC_HIP_JACOBI_CHECKS have it
 void fold_listed_work(Ctx *c);
 void drop_graphs(Ctx *c);  // captured launch sequences hold the buffer addresses: drop them whenever a buffer goes away
 hipError_t enqueue_plain_run(Ctx *c, unsigned count, unsigned first, bool check_last = false);
@@ -319,6 +320,8 @@ bool due_tiles(Ctx *c, unsigned long long *due, unsigned long long *tiles, bool 
 // h->delta, on the kernel family the context's state calls for.  bypass: -1 decide here (reads the list counters back), 0 / 1 given.
 // Does not touch h->currentIteration (the callers count); an EPIC_* code.
 int run_block(Harmonic *h, Ctx *c, unsigned plain, unsigned first, bool check, const char *fn, int bypass, bool run_ahead = false);
+// EPIC_HIP_JACOBI_CHECKS=reference on a context that runs the Jacobi scheme right now: its check iterations are the reference's half-sweeps (run_block)
+inline bool jacobi_reference_checks(const Ctx *c) { return c->cfg.jacobi_ref_checks && !c->redblack && c->n != 4; }
 unsigned defer_cap(const Harmonic *h, const Ctx *c);   // deferred iterations that make a block worth enqueueing (1: no deferral)
 int flush_pending(Harmonic *h, Ctx *c, const char *fn);   // c may be null; an EPIC_* code (the failure of a deferred launch surfaces here)
 

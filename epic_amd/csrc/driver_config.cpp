@@ -54,6 +54,8 @@ Config Config::from_env()
     e = env("EPIC_HIP_SCHEME");
     if (e && strcmp(e, "redblack") == 0) c.redblack = true;
     if (e && strcmp(e, "jacobi") == 0) c.redblack = false;
+    e = env("EPIC_HIP_JACOBI_CHECKS");
+    c.jacobi_ref_checks = e && (strcmp(e, "reference") == 0 || strcmp(e, "1") == 0);
     e = env("EPIC_HIP_TRACK");
     if (e && (strcmp(e, "0") == 0 || strcmp(e, "1") == 0)) c.track_mode = atoi(e);
     c.rows_per_task = sint_of("EPIC_HIP_ROWS_PER_TASK", 0);
@@ -129,8 +131,8 @@ std::string Config::json() const
     }
     char t[1536];
     std::string out = "{";
-    snprintf(t, sizeof t, "\"study\": %s, \"math\": %d, \"scheme\": \"%s\", \"track_mode\": %d, \"rows_per_task\": %d, \"devices\": \"", study ? "true" : "false", math,
-             redblack ? "redblack" : "jacobi", track_mode, rows_per_task);
+    snprintf(t, sizeof t, "\"study\": %s, \"math\": %d, \"scheme\": \"%s\", \"jacobi_checks\": \"%s\", \"track_mode\": %d, \"rows_per_task\": %d, \"devices\": \"",
+             study ? "true" : "false", math, redblack ? "redblack" : "jacobi", jacobi_ref_checks ? "reference" : "jacobi", track_mode, rows_per_task);
     out += t;
     out += dev;
     snprintf(t, sizeof t,

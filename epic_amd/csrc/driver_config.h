@@ -34,6 +34,7 @@ struct Config {
     // mode of a new context (also settable per context: epic_hip_set_*)
     int math = 0;                    // EPIC_HIP_MATH: 0 precise (default), 1 fast, 4 tol
     bool redblack = true;            // EPIC_HIP_SCHEME: redblack (default) | jacobi
+    bool jacobi_ref_checks = false;  // EPIC_HIP_JACOBI_CHECKS=reference: every CHECK iteration of a Jacobi run is the reference's red-black half-sweep (driver_loop.hip: run_block)
     int track_mode = 2;              // EPIC_HIP_TRACK: 0 | 1 (2: automatic, above 4 Mcell)
     int rows_per_task = 0;           // EPIC_HIP_ROWS_PER_TASK (0: automatic)
     // several devices in one process

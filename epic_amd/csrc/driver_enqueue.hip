@@ -70,6 +70,19 @@ hipError_t enqueue_sweep(Ctx *c, bool check, unsigned iteration)
     return e;
 }
 
+// A check iteration as the context's scheme has it: the scheme's own sweep, or -- EPIC_HIP_JACOBI_CHECKS=reference on a context that runs Jacobi
+// sweeps (driver_loop.hip: run_block says why) -- the reference's half-sweep of that iteration's colour, in place in the current buffer.
+hipError_t enqueue_check_sweep(Ctx *c, unsigned iteration)
+{
+    if (!jacobi_reference_checks(c)) return enqueue_sweep(c, true, iteration);
+    c->redblack = true;
+    force_all(c);   // the lists in force were made by Jacobi sweeps
+    const hipError_t e = enqueue_sweep(c, true, iteration);
+    c->redblack = false;
+    force_all(c);
+    return e;
+}
+
 // Adds what the device has summed for the list-driven launches (in tiles) to the host's count and clears it; waits for
 // the stream.
 void fold_listed_work(Ctx *c)

@@ -59,7 +59,7 @@ int epic_hip_timed_sweeps_gpu(Harmonic *harmonic, unsigned int sweeps, unsigned 
         while (done < sweeps && rc == EPIC_SUCCESS) {
             const unsigned it = harmonic->currentIteration;
             if (check_every && it % check_every == 0) {
-                if (enqueue_sweep(c, true, it) != hipSuccess) rc = EPIC_ERROR_KERNEL_EXECUTION;
+                if (enqueue_check_sweep(c, it) != hipSuccess) rc = EPIC_ERROR_KERNEL_EXECUTION;
                 checked = true;
                 harmonic->currentIteration++;
                 done++;
@@ -91,7 +91,7 @@ int epic_hip_timed_sweeps_gpu(Harmonic *harmonic, unsigned int sweeps, unsigned 
     while (done < sweeps && rc == EPIC_SUCCESS) {
         const unsigned it = harmonic->currentIteration;
         if (check_every && it % check_every == 0) {
-            if (enqueue_sweep(c, true, it) != hipSuccess) rc = EPIC_ERROR_KERNEL_EXECUTION;
+            if (enqueue_check_sweep(c, it) != hipSuccess) rc = EPIC_ERROR_KERNEL_EXECUTION;
             checked = true;
             harmonic->currentIteration++;
             done++;

@@ -21,6 +21,26 @@ namespace epic_drv {
 int run_block(Harmonic *h, Ctx *c, unsigned plain, unsigned first, bool check, const char *fn, int bypass, bool run_ahead)
 {
     if (plain == 0 && !check) return EPIC_SUCCESS;
+    if (check && jacobi_reference_checks(c)) {
+        // EPIC_HIP_JACOBI_CHECKS=reference (opt-in; round 6).  A Jacobi sweep advances two interleaved red-black chains: the cells of the colour the
+        // reference updates at iteration k, and the others -- a chain the reference never computes, one half-sweep behind.
+        // A relaxation stopped at a coarse epsilon ends with that second chain up to epsilon / |u| from the reference's field.  With this knob
+        // the CHECK iteration is the reference's own half-sweep, in place: after the Jacobi sweeps 1 .. k-1 the other colour holds the first chain's
+        // values of sweep k-1, so the half-sweep k leaves exactly the reference's state after k half-sweeps -- both colours on the reference's chain,
+        // delta over the reference's colour -- and the next Jacobi sweep goes on from it (the colour it skipped recomputes to what it holds).
+        // Bit-identical to harmonic_complete_cpu with the precise arithmetic, iteration count included; measured with the checkers first
+        // (tests/jacobi_halfcheck_study.py), here as the plain iterations on whatever family runs them and one half-sweep of the single-sweep kernel.
+        if (plain > 0) {
+            const int rc = run_block(h, c, plain, first, false, fn, bypass, false);
+            if (rc != EPIC_SUCCESS) return rc;
+        }
+        if (enqueue_check_sweep(c, first + plain) != hipSuccess) {
+            report(fn, "Failed to execute the 'Jacobi update and check' kernel.");
+            return EPIC_ERROR_KERNEL_EXECUTION;
+        }
+        h->d_u = current_u(c);
+        return read_delta(h, c, fn);
+    }
     hipError_t e = hipSuccess;
     bool tiled_check = false;
     hipEvent_t after_check = nullptr;   // run_ahead: the event between the check's launch and the block enqueued ahead of the caller
@@ -407,7 +427,7 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
             harmonic->currentIteration += batch + 1;
             result = harmonic->delta < harmonic->epsilon ? EPIC_SUCCESS_AND_CONVERGED : EPIC_SUCCESS;
             after_check();
-        } else if (tile_checks(c, tile_plan(c)) && tiles_pipeline_ready(c)) {
+        } else if (tile_checks(c, tile_plan(c)) && tiles_pipeline_ready(c) && !jacobi_reference_checks(c)) {
             // Small grids, pipelined (round 4).  A block = the plain iterations up to the next check and that check, as tile launches.
             // The host does not wait for a check's result before enqueueing the NEXT block: it enqueues it from the state the
             // check refers to, into the two buffers that state is not in (three buffers rotate), and only then waits for the

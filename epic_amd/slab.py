@@ -172,6 +172,9 @@ class SlabSolver:
         # (a row's update reads the rows next to it as they were one iteration ago), so the same G rows are traded
         # every G iterations.
         self.redblack = scheme == "redblack"
+        # EPIC_HIP_JACOBI_CHECKS=reference, as the library reads it (epic_amd/csrc/driver_loop.hip: run_block): every check iteration of a Jacobi run is the
+        # reference's red-black half-sweep of that iteration's colour, in place -- the state after a check is the reference's own
+        self.jacobi_ref_checks = os.environ.get("EPIC_HIP_JACOBI_CHECKS") in ("reference", "1")
         self.backend = backend if backend is not None else HipBackend(rows_per_task, math)
         parts = partition_rows(self.grid[0], world)
         self.lo, self.hi = parts[rank]
@@ -481,6 +484,13 @@ class SlabSolver:
         if not check and budget >= 2 and (self.iteration + 1) % self.stagger != 0 and self.can_pair():
             self.sweep_pair()
             return 2, False
+        if check and not self.redblack and self.jacobi_ref_checks:
+            self.redblack = True
+            try:
+                self.sweep(True)
+            finally:
+                self.redblack = False
+            return 1, True
         self.sweep(check)
         return 1, check
 

@@ -386,6 +386,12 @@ int oracle_jacobi_run(OracleHarmonic *h, unsigned int sweeps)
  * reference's red-black half-sweeps in place, which stop as the reference stops.  ORACLE_JACOBI_HANDOVER_DELTA is that 1:
  * far below the ~1e6 of a front still moving, far above any f32 flicker of a field the solver can hold. */
 #define ORACLE_JACOBI_HANDOVER_DELTA 1.0f
+/* The library's opt-in EPIC_HIP_JACOBI_CHECKS=reference (epic_amd/csrc/driver_loop.hip: run_block), stated for the checkers' Jacobi loops
+ * (here and oracle_tol_complete): every CHECK iteration is the reference's red-black half-sweep of that iteration's colour
+ * (harmonic_cpu.cpp:38-133), in place in the current Jacobi state.  After the Jacobi sweeps 1 .. k-1 the other colour holds the values
+ * the reference's half-sweep k-1 left, so the state after the check is the reference's after k half-sweeps, and delta the reference's. */
+int g_oracle_jacobi_ref_checks = 0;
+void oracle_set_jacobi_ref_checks(int on) { g_oracle_jacobi_ref_checks = on != 0; }
 int oracle_jacobi_complete(OracleHarmonic *h)
 {
     if (h == NULL || h->m == NULL || h->u == NULL || h->locked == NULL || h->epsilon <= 0.0 ||
@@ -410,9 +416,18 @@ int oracle_jacobi_complete(OracleHarmonic *h)
             continue;
         }
         float d;
-        if (h->n == 2) jacobi_sweep_2d(h, a, b, &d);
-        else jacobi_sweep_3d(h, a, b, &d);
-        float *t = a; a = b; b = t;
+        if (check && g_oracle_jacobi_ref_checks) {
+            float *own = h->u;
+            h->u = a;   /* the half-sweep of this iteration's colour, in place in the current state */
+            if (h->n == 2) g_updates += rb_update_2d(h, 1);
+            else g_updates += rb_update_3d(h, 1);
+            h->u = own;
+            d = (float)h->delta;
+        } else {
+            if (h->n == 2) jacobi_sweep_2d(h, a, b, &d);
+            else jacobi_sweep_3d(h, a, b, &d);
+            float *t = a; a = b; b = t;
+        }
         h->currentIteration++;
         if (check) {
             h->delta = d;

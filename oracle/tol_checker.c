@@ -217,6 +217,7 @@ int oracle_tol_run(TolHarmonic *h, unsigned int iterations, int scheme)
  * 8192^2 benchmark grid: 45 001 + 9 800), it does not replace the tol phase's last ones. */
 int oracle_update(TolHarmonic *h);             /* oracle/harmonic_oracle.c (same struct layout) */
 int oracle_update_and_check(TolHarmonic *h);
+extern int g_oracle_jacobi_ref_checks;          /* oracle/harmonic_oracle.c: oracle_set_jacobi_ref_checks */
 static int g_tol_finish = 1;
 void oracle_tol_set_finish(int on) { g_tol_finish = on != 0; }
 /* What the latest oracle_tol_complete did, for the campaign of tests/tol_campaign.py: the iteration at which the finishing phase began
@@ -266,11 +267,11 @@ int oracle_tol_complete(TolHarmonic *h, int scheme)
             continue;
         }
         float d;
-        if (scheme == 0) {
+        if (scheme == 0 && !(check && g_oracle_jacobi_ref_checks)) {
             memcpy(b, a, cells * sizeof(float));
             d = tol_iterate(h, a, b, -1, q, zb);
             float *t = a; a = b; b = t;
-        } else {
+        } else {   /* red-black -- or a Jacobi run's check as the reference's half-sweep (oracle_set_jacobi_ref_checks, oracle/harmonic_oracle.c) */
             d = tol_iterate(h, a, a, (int)(h->currentIteration & 1u), q, zb);
         }
         h->currentIteration++;

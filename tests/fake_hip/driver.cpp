@@ -169,7 +169,7 @@ struct Scenario {
 static void set_env(const std::map<std::string, std::string> &env, bool on)
 {
     static const char *all[] = {"EPIC_HIP_DEVICES", "EPIC_HIP_THREADS", "EPIC_HIP_NO_PEER", "EPIC_HIP_TRACK", "EPIC_HIP_TILE", "EPIC_HIP_MATH",
-                                "EPIC_HIP_SCHEME", "EPIC_HIP_HALO", "EPIC_HIP_FUSE_MIN_CELLS", "EPIC_HIP_TUNE", "EPIC_HIP_DEFER", "FAKE_NO_PEER_CAPABLE", "FAKE_CURRENT_DEVICE"};
+                                "EPIC_HIP_SCHEME", "EPIC_HIP_HALO", "EPIC_HIP_FUSE_MIN_CELLS", "EPIC_HIP_TUNE", "EPIC_HIP_DEFER", "EPIC_HIP_JACOBI_CHECKS", "FAKE_NO_PEER_CAPABLE", "FAKE_CURRENT_DEVICE"};
     for (const char *k : all) unsetenv(k);
     setenv("EPIC_HIP_STUDY", "1", 1);   // the scenarios steer the kernel plan with study knobs (epic_amd/csrc/driver_config.cpp)
     if (on)
@@ -232,6 +232,11 @@ int main(int argc, char **argv)
         {"plugin, 2-D, tracked pairs, odd count", {40, 300}, 1e-3f, 7, seq_plugin, {{"EPIC_HIP_TRACK", "1"}, {"EPIC_HIP_FUSE_MIN_CELLS", "0"}}},
         {"plugin, 2-D, tol Jacobi (handover and finish rules)", {20, 30}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_MATH", "tol"}, {"EPIC_HIP_SCHEME", "jacobi"}}},
         {"plugin, 2-D, tol fused pairs", {24, 300}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_MATH", "tol"}, {"EPIC_HIP_SCHEME", "jacobi"}, {"EPIC_HIP_FUSE_MIN_CELLS", "0"}}},
+        {"plugin, 2-D, Jacobi on tiles, the reference's half-sweep at every check", {20, 30}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_SCHEME", "jacobi"}, {"EPIC_HIP_JACOBI_CHECKS", "reference"}}},
+        {"node, 2-D, tol Jacobi pairs with work lists, reference checks", {40, 300}, 1e-3f, 4, seq_node,
+         {{"EPIC_HIP_MATH", "tol"}, {"EPIC_HIP_SCHEME", "jacobi"}, {"EPIC_HIP_JACOBI_CHECKS", "reference"}, {"EPIC_HIP_TRACK", "1"}, {"EPIC_HIP_FUSE_MIN_CELLS", "0"}}},
+        {"plugin, 2-D, two slabs, Jacobi with reference checks", {32, 40}, 1e-3f, 10, seq_plugin,
+         {{"EPIC_HIP_DEVICES", "0,0"}, {"EPIC_HIP_THREADS", "0"}, {"EPIC_HIP_SCHEME", "jacobi"}, {"EPIC_HIP_JACOBI_CHECKS", "reference"}, {"EPIC_HIP_HALO", "3"}}},
         {"plugin, 2-D, three slabs, caller's thread", {48, 40}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_DEVICES", "0,0,0"}, {"EPIC_HIP_THREADS", "0"}, {"EPIC_HIP_HALO", "3"}}},
         {"plugin, 2-D, three slabs, staged halos", {48, 40}, 1e-3f, 10, seq_plugin, {{"EPIC_HIP_DEVICES", "0,0,0"}, {"EPIC_HIP_THREADS", "0"}, {"EPIC_HIP_NO_PEER", "1"}, {"EPIC_HIP_HALO", "2"}}},
         {"node, 2-D, two slabs, caller's thread", {32, 20}, 1e-3f, 4, seq_node, {{"EPIC_HIP_DEVICES", "0,0"}, {"EPIC_HIP_THREADS", "0"}}},

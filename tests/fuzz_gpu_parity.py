@@ -461,7 +461,14 @@ if __name__ == "__main__":
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--complete", action="store_true", help="whole relaxations (harmonic_complete_gpu) instead of fixed iteration counts")
     ap.add_argument("--node", action="store_true", help="scripts over the fine-grained entry points (single updates, checks, edits, read-backs)")
+    ap.add_argument("--ref-checks", action="store_true", help="with --complete: EPIC_HIP_JACOBI_CHECKS=reference on the device and in the checkers' Jacobi loops")
     a = ap.parse_args()
+    if a.ref_checks:
+        assert a.complete, "--ref-checks goes with --complete (the checkers state it for their whole-relaxation loops)"
+        os.environ["EPIC_HIP_JACOBI_CHECKS"] = "reference"
+        O.oracle().oracle_set_jacobi_ref_checks.argtypes = (ct.c_int,)
+        O.oracle().oracle_set_jacobi_ref_checks.restype = None
+        O.oracle().oracle_set_jacobi_ref_checks(1)
     bad = (campaign_node if a.node else campaign_complete if a.complete else campaign)(a.cases, a.seed, verbose=not a.quiet)
     print(f"{a.cases} cases, seed {a.seed}: {len(bad)} mismatches")
     for b in bad:

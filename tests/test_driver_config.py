@@ -42,7 +42,7 @@ def run(exe, **env):
 
 def test_defaults_are_the_librarys(harness):
     c, k = run(harness)
-    assert c["study"] is False
+    assert c["study"] is False and c["jacobi_checks"] == "jacobi"
     assert c["math"] == 0 and c["scheme"] == "redblack" and c["track_mode"] == 2 and c["rows_per_task"] == 0      # the reference's iteration, bit-exact
     assert c["devices"] == "" and c["halo"] == 0 and c["threads"] is True and c["spin_us"] == 20 and c["no_peer"] is False
     assert c["no_fuse"] is False and c["no_graph"] is False and c["fuse_min_cells"] == -1 and c["tune"] is True      # -1: by arithmetic and scheme (driver_plan.hip)
@@ -52,13 +52,14 @@ def test_defaults_are_the_librarys(harness):
 
 
 def test_every_knob_is_parsed(harness):
-    c, k = run(harness, EPIC_HIP_STUDY="1", EPIC_HIP_MATH="tol", EPIC_HIP_SCHEME="jacobi", EPIC_HIP_TRACK="1", EPIC_HIP_ROWS_PER_TASK="12", EPIC_HIP_DEVICES="0,1,1,3",
+    c, k = run(harness, EPIC_HIP_STUDY="1", EPIC_HIP_MATH="tol", EPIC_HIP_SCHEME="jacobi", EPIC_HIP_JACOBI_CHECKS="reference", EPIC_HIP_TRACK="1", EPIC_HIP_ROWS_PER_TASK="12", EPIC_HIP_DEVICES="0,1,1,3",
                EPIC_HIP_HALO="5", EPIC_HIP_NO_PEER="1", EPIC_HIP_THREADS="0", EPIC_HIP_SPIN_US="0", EPIC_HIP_NO_FUSE="1", EPIC_HIP_NO_GRAPH="1",
                EPIC_HIP_FUSE_MIN_CELLS="0", EPIC_HIP_FUSED_ROWS="33", EPIC_HIP_TUNE="0", EPIC_HIP_TILE="0", EPIC_HIP_TILE_MAX_CELLS="1000",
                EPIC_HIP_TILE_ROWS="7", EPIC_HIP_TILE_WIDTH="128", EPIC_HIP_TILE_HALO="9", EPIC_HIP_TILE_PIPELINE="0", EPIC_HIP_DEFER="0", EPIC_HIP_TRACK_PAIRS="0",
                EPIC_HIP_TRACK_PAIR_ROWS="6", EPIC_HIP_TRACK_SWITCH="0.5", EPIC_HIP_TOL_FINISH="0", EPIC_HIP_TOL_FINISH_FACTOR="30",
                EPIC_HIP_FLAGS="2", EPIC_HIP_LIST_WAVES="512", EPIC_HIP_3D_PAIR="0", EPIC_HIP_3D_PAIR_ROWS="20", EPIC_HIP_3D_MARCH="x0")
     assert c["math"] == 4 and c["scheme"] == "jacobi" and c["track_mode"] == 1 and c["rows_per_task"] == 12 and c["devices"] == "0,1,1,3"
+    assert c["jacobi_checks"] == "reference"
     assert c["halo"] == 5 and c["no_peer"] is True and c["threads"] is False and c["spin_us"] == 0 and c["no_fuse"] is True and c["no_graph"] is True
     assert c["fuse_min_cells"] == 0 and c["fused_rows"] == 33 and c["tune"] is False and c["tile"] is False and c["tile_max_cells"] == 1000
     assert (c["tile_rows"], c["tile_width"], c["tile_halo"]) == (7, 128, 9) and c["tile_pipeline"] is False and c["track_pairs"] is False
@@ -97,7 +98,7 @@ def test_study_knobs_are_read_only_when_asked_for(harness):
                  EPIC_HIP_TILE_HALO="9", EPIC_HIP_TILE_PIPELINE="0", EPIC_HIP_TRACK_PAIRS="0", EPIC_HIP_TRACK_PAIR_ROWS="6", EPIC_HIP_TRACK_SWITCH="0.5",
                  EPIC_HIP_TOL_FINISH_FACTOR="30", EPIC_HIP_FLAGS="2", EPIC_HIP_LIST_WAVES="512", EPIC_HIP_3D_PAIR="0", EPIC_HIP_3D_PAIR_ROWS="20",
                  EPIC_HIP_3D_MARCH="x0")
-    product = dict(EPIC_HIP_MATH="tol", EPIC_HIP_SCHEME="jacobi", EPIC_HIP_TRACK="1", EPIC_HIP_DEVICES="0,1", EPIC_HIP_HALO="5", EPIC_HIP_NO_PEER="1",
+    product = dict(EPIC_HIP_MATH="tol", EPIC_HIP_SCHEME="jacobi", EPIC_HIP_JACOBI_CHECKS="reference", EPIC_HIP_TRACK="1", EPIC_HIP_DEVICES="0,1", EPIC_HIP_HALO="5", EPIC_HIP_NO_PEER="1",
                    EPIC_HIP_THREADS="0", EPIC_HIP_SPIN_US="7", EPIC_HIP_TOL_FINISH="0", EPIC_HIP_DEFER="0")
     defaults, k0 = run(harness)
     e = {k: v for k, v in os.environ.items() if not k.startswith("EPIC_HIP_")}
@@ -112,6 +113,7 @@ def test_study_knobs_are_read_only_when_asked_for(harness):
         assert c[key] == defaults[key], key
     assert (c["math"], c["scheme"], c["track_mode"], c["devices"], c["halo"], c["no_peer"], c["threads"], c["spin_us"], c["tol_finish"], c["defer"]) == \
         (4, "jacobi", 1, "0,1", 5, True, False, 7, 0, False)
+    assert c["jacobi_checks"] == "reference"
     assert r.stderr.count("is a study knob and is ignored without EPIC_HIP_STUDY=1") == 1
     c2, _ = run(harness, EPIC_HIP_STUDY="1", **study)
     assert c2["study"] is True and c2["no_fuse"] is True and c2["tile_rows"] == 7 and c2["flags"] == 2

@@ -282,3 +282,16 @@ def test_solve_with_pairs_equals_single_domain_jacobi(tmp_path):
     assert O.oracle().oracle_jacobi_complete(ct.byref(p.h)) == 0
     assert all(int(q["iteration"]) == int(p.h.currentIteration) for q in parts)
     assert np.array_equal(field.ravel(), p.u)
+
+
+def test_jacobi_solve_with_reference_checks_is_the_reference_loop(tmp_path, monkeypatch):
+    """EPIC_HIP_JACOBI_CHECKS=reference in the rank-per-slab driver (round 6; the library: tests/test_gpu_jacobi_reference_checks.py): every check iteration
+    of the Jacobi run is the reference's half-sweep, so the two ranks' solve is harmonic_complete_cpu's loop -- oracle_complete -- bit for bit."""
+    monkeypatch.setenv("EPIC_HIP_JACOBI_CHECKS", "reference")
+    grid, seed = [30, 41], 9
+    field, parts = _run(2, grid, seed, 0, "solve", tmp_path)
+    u0, locked = synthetic_grid(grid, seed, 0.08)
+    p = O.Problem(grid, u0, locked, 1e-6, 10)
+    assert O.oracle().oracle_complete(ct.byref(p.h)) in (0, 1)
+    assert all(int(q["iteration"]) == int(p.h.currentIteration) and float(q["delta"]) == float(p.h.delta) for q in parts)
+    assert np.array_equal(field.ravel(), p.u)
