@@ -510,6 +510,11 @@ def summarise_into_config(out):
         cfg["tol_campaign_misses"] = camp["misses"]
         cfg["tol_campaign_worst_rel"] = camp["worst_rel"]
         cfg["tol_campaign_misses_with_warning"] = camp["misses_with_warning"]
+        # (every miss is a Jacobi run stopped at a coarse epsilon; the same maps for the Jacobi scheme with EPIC_HIP_JACOBI_CHECKS=reference, opt-in)
+        camp = json.load(open(os.path.join(ROOT, "tests", "golden", "tol_campaign_reference_checks.json")))["summary"]
+        cfg["tol_campaign_jacobi_reference_checks_cases"] = camp["cases"]
+        cfg["tol_campaign_jacobi_reference_checks_misses"] = camp["misses"]
+        cfg["tol_campaign_jacobi_reference_checks_worst_rel"] = camp["worst_rel"]
     except (OSError, ValueError, KeyError):
         pass
 

@@ -103,7 +103,10 @@ int epic_hip_set_math_mode(EpicHarmonicT *harmonic, int mode);
  * libepic/src/harmonic/harmonic_cpu.cpp:46-51, :89-102; with the default precise math every half-sweep, the iteration count
  * and the converged field are bit-identical to harmonic_complete_cpu), 0 = Jacobi ping-pong (one iteration recomputes
  * every unlocked cell: what BASELINE.json's metric names and bench.py times; twice the arithmetic for the same answer).
- * Also EPIC_HIP_SCHEME=jacobi|redblack in the environment at initialisation. */
+ * Also EPIC_HIP_SCHEME=jacobi|redblack in the environment at initialisation.
+ * EPIC_HIP_JACOBI_CHECKS=reference (environment, opt-in): every CHECK iteration of a Jacobi run is the reference's half-sweep of that
+ * iteration's colour, in place -- the state after a check, and so the field a relaxation ends with, is the reference's own (with the
+ * precise math bit for bit, iteration count included); INTEGRATION.md section 6. */
 int epic_hip_set_scheme(EpicHarmonicT *harmonic, int scheme);
 
 /* Activity tracking: 0 off, 1 on, 2 automatic (default: on for grids above 4 Mcell; also

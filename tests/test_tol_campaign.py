@@ -65,6 +65,44 @@ def test_a_sample_re_run_today_gives_the_recorded_numbers(record, family, seed):
         assert g["max_rel"] == pytest.approx(w["max_rel"], rel=1e-12, abs=0.0)
 
 
+REFCHECKS = os.path.join(ROOT, "tests", "golden", "tol_campaign_reference_checks.json")
+
+
+def test_the_jacobi_scheme_with_reference_checks_misses_nothing():
+    """The same 120 maps x 3 epsilons for the Jacobi scheme with EPIC_HIP_JACOBI_CHECKS=reference (tests/tol_campaign.py --ref-checks; every check
+    iteration the reference's half-sweep: tests/test_jacobi_reference_checks.py): the second chain's lag is gone -- no case outside the bar, the worst a
+    fifth of the plain Jacobi checks' worst INSIDE it, and at the callers' epsilons every run stops at the reference's iteration."""
+    rec = json.load(open(REFCHECKS))
+    cases = [dict(c) for c in rec["cases"]]
+    s = T.summarise(cases)
+    assert json.loads(json.dumps(s)) == rec["summary"]
+    assert s["cases"] == 360 and s["maps"] == 120 and all(c["scheme"] == "jacobi+reference_checks" and c["rc"] == [0, 0] for c in cases)
+    assert s["misses"] == 0 and s["worst_rel"] < 2e-6 and s["warnings"] == 0
+    assert s["by_epsilon"]["0.01"]["worst_rel"] < 1e-6 and s["by_epsilon"]["0.001"]["worst_rel"] < 1e-6
+    for eps in ("0.01", "0.001"):
+        assert s["by_epsilon"][eps]["same_iterations"] == 120
+    main = {(c["family"], c["seed"], c["epsilon"]): c for c in json.load(open(RECORD))["cases"] if c["scheme"] == "jacobi"}
+    assert all(main[(c["family"], c["seed"], c["epsilon"])]["reference_iterations"] == c["reference_iterations"] for c in cases)   # the same maps, the same reference runs
+
+
+@pytest.mark.timeout(600)
+def test_a_reference_checks_sample_re_run_today_gives_the_recorded_numbers(monkeypatch):
+    rec = json.load(open(REFCHECKS))
+    monkeypatch.setenv("EPIC_CAMPAIGN_REF_CHECKS", "1")
+    try:
+        got = T.run_map(("dense", 1407))
+    finally:
+        import _oracle as O
+
+        O.oracle().oracle_set_jacobi_ref_checks(0)
+    want = [c for c in rec["cases"] if c["family"] == "dense" and c["seed"] == 1407]
+    assert len(got) == len(want) == 3
+    for g, w in zip(sorted(got, key=lambda c: -c["epsilon"]), sorted(want, key=lambda c: -c["epsilon"])):
+        for k in ("m", "epsilon", "scheme", "reference_iterations", "iterations", "finish_from", "identical", "within_bar"):
+            assert g[k] == w[k], (k, g[k], w[k])
+        assert g["max_rel"] == pytest.approx(w["max_rel"], rel=1e-12, abs=0.0)
+
+
 def test_the_generated_maps_are_the_same_everywhere():
     """numpy's Generator streams are stable across versions for the calls used; a changed map would silently change the campaign."""
     import hashlib

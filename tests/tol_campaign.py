@@ -214,6 +214,11 @@ def run_map(job):
     m, u0, locked = make_case(family, seed)
     lib = O.oracle()
     lib.oracle_tol_last_finish_from.restype = ct.c_uint
+    # --ref-checks: the Jacobi scheme with EPIC_HIP_JACOBI_CHECKS=reference (every check iteration the reference's half-sweep), a record of its own
+    ref_checks = os.environ.get("EPIC_CAMPAIGN_REF_CHECKS") == "1"
+    lib.oracle_set_jacobi_ref_checks.argtypes = (ct.c_int,)
+    lib.oracle_set_jacobi_ref_checks.restype = None
+    lib.oracle_set_jacobi_ref_checks(1 if ref_checks else 0)
     out = []
     for eps in EPSILONS:
         t0 = time.time()
@@ -221,7 +226,7 @@ def run_map(job):
         rc_ref, kind = reference_complete(pr)
         t_ref = time.time() - t0
         reached = (pr.u > -9e5) & (locked == 0)
-        for scheme in SCHEMES:
+        for scheme in (("jacobi+reference_checks",) if ref_checks else SCHEMES):
             t0 = time.time()
             pt = O.Problem(m, u0, locked, epsilon=eps, stagger=100)
             rc = lib.oracle_tol_complete(ct.byref(pt.h), 1 if scheme == "redblack" else 0)
@@ -297,8 +302,12 @@ def main():
     ap.add_argument("--out", default=os.path.join(HERE, "golden", "tol_campaign.json"))
     ap.add_argument("--workers", type=int, default=max(1, (os.cpu_count() or 2) - 1))
     ap.add_argument("--seeds", type=int, default=9, help="maps per family (x 3 epsilons x 2 schemes cases each)")
+    ap.add_argument("--ref-checks", action="store_true", help="the Jacobi scheme with EPIC_HIP_JACOBI_CHECKS=reference only (write it to a file of its own: --out)")
     a = ap.parse_args()
     os.environ["OMP_NUM_THREADS"] = "1"
+    if a.ref_checks:
+        assert a.out != os.path.join(HERE, "golden", "tol_campaign.json"), "--ref-checks writes a record of its own: give --out"
+        os.environ["EPIC_CAMPAIGN_REF_CHECKS"] = "1"
     jobs = jobs_for(a.seeds)
     cases, t0 = [], time.time()
     with mp.Pool(a.workers) as pool:
@@ -309,7 +318,7 @@ def main():
                 time.time() - t0, i + 1, len(jobs), res[0]["family"], res[0]["seed"], res[0]["m"],
                 sorted({c["reference_iterations"] for c in res}), max(c["max_rel"] for c in res), len(bad)), flush=True)
     cases.sort(key=lambda c: (FAMILIES.index(c["family"]), c["seed"], -c["epsilon"], c["scheme"]))
-    doc = {"generator": "tests/tol_campaign.py --seeds %d" % a.seeds,
+    doc = {"generator": "tests/tol_campaign.py --seeds %d%s" % (a.seeds, " --ref-checks" if a.ref_checks else ""),
            "what": "oracle_tol_complete (the tol arithmetic + finishing iterations, the loop harmonic_execute_gpu runs with EPIC_HIP_MATH=tol) "
                    "against harmonic_complete_cpu of the reference on generated maps; max_rel = max |du| / max(1, |u|) over the cells the reference reached",
            "summary": summarise(cases), "cases": cases}
