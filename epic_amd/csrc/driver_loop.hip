@@ -427,7 +427,7 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
             harmonic->currentIteration += batch + 1;
             result = harmonic->delta < harmonic->epsilon ? EPIC_SUCCESS_AND_CONVERGED : EPIC_SUCCESS;
             after_check();
-        } else if (tile_checks(c, tile_plan(c)) && tiles_pipeline_ready(c) && !jacobi_reference_checks(c)) {
+        } else if (tile_checks(c, tile_plan(c)) && tiles_pipeline_ready(c)) {
             // Small grids, pipelined (round 4).  A block = the plain iterations up to the next check and that check, as tile launches.
             // The host does not wait for a check's result before enqueueing the NEXT block: it enqueues it from the state the
             // check refers to, into the two buffers that state is not in (three buffers rotate), and only then waits for the
@@ -439,6 +439,8 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
             float *bufs[3] = {c->buf[0], c->buf[1], c->spare};
             int slot = 0;
             const epic_hip::TilePlan tp = tile_plan(c);   // ONE plan for every block of this stretch (the mode cannot change inside it)
+            // (EPIC_HIP_JACOBI_CHECKS=reference: the check is a launch of its own -- ONE step, the reference's colour of that iteration; run_block says why)
+            const bool ref_checks = jacobi_reference_checks(c);
             auto enqueue_block = [&](float *in, unsigned first, Blk *out) -> hipError_t {
                 const unsigned total = (stagger - first % stagger) + 1;   // the plain iterations and the check
                 float *o1 = nullptr, *o2 = nullptr;
@@ -446,10 +448,12 @@ int harmonic_execute_gpu(Harmonic *harmonic, unsigned int numThreads)  // harmon
                     if (b != in) (o1 ? o2 : o1) = b;
                 float *src = in;
                 for (unsigned i = 0; i < total;) {
-                    const unsigned k = std::min<unsigned>(total - i, (unsigned)tp.halo);
+                    unsigned k = std::min<unsigned>(total - i, (unsigned)tp.halo);
+                    if (ref_checks && i + k == total && k > 1) k--;
+                    const bool half_sweep = c->redblack || (ref_checks && i + k == total);
                     float *dst = src == o1 ? o2 : o1;
                     hipError_t e = epic_hip::launch_tile_2d(src, dst, c->maskw, c->rows, c->pitch, tp, (int)k, c->math,
-                                                            c->redblack ? (int)((first + i) & 1u) : -1, nullptr, c->stream,
+                                                            half_sweep ? (int)((first + i) & 1u) : -1, nullptr, c->stream,
                                                             i + k == total ? c->h_tile_delta + (size_t)slot * kTileDeltaCap : nullptr);
                     if (e != hipSuccess) return e;
                     src = dst;
