@@ -244,6 +244,9 @@ def node_case(rng):
     return m, u0, locked, mode, env, draw_script(rng, m, big)
 
 
+REF_CHECKS = False   # --ref-checks: EPIC_HIP_JACOBI_CHECKS=reference on the device, stated here for the scripts and by the checkers' loops for --complete
+
+
 def checker_script(m, u0, locked, mode, ops):
     """The checker's statement of the script: (field, delta) at every 'r', in order."""
     p = O.Problem(m, u0, locked)
@@ -256,6 +259,16 @@ def checker_script(m, u0, locked, mode, ops):
         n = pending[0]
         pending[0] = 0
         if n == 0:
+            return
+        if REF_CHECKS and ends_with_check and scheme == eh.SCHEME_JACOBI and len(m) != 4:
+            # EPIC_HIP_JACOBI_CHECKS=reference: the check is the reference's half-sweep of that iteration's colour, in place
+            if n > 1:
+                assert (lib.oracle_tol_run(ct.byref(p.h), n - 1, 0) if math == eh.MATH_TOL else lib.oracle_jacobi_run(ct.byref(p.h), n - 1)) == 0
+            if math == eh.MATH_TOL:
+                assert lib.oracle_tol_run(ct.byref(p.h), 1, 1) == 0
+            else:
+                assert lib.oracle_update_and_check(ct.byref(p.h)) in (0, 1)
+            delta[0] = float(p.h.delta)
             return
         if math == eh.MATH_TOL:
             assert lib.oracle_tol_run(ct.byref(p.h), n, 1 if scheme == eh.SCHEME_REDBLACK else 0) == 0
@@ -461,10 +474,11 @@ if __name__ == "__main__":
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--complete", action="store_true", help="whole relaxations (harmonic_complete_gpu) instead of fixed iteration counts")
     ap.add_argument("--node", action="store_true", help="scripts over the fine-grained entry points (single updates, checks, edits, read-backs)")
-    ap.add_argument("--ref-checks", action="store_true", help="with --complete: EPIC_HIP_JACOBI_CHECKS=reference on the device and in the checkers' Jacobi loops")
+    ap.add_argument("--ref-checks", action="store_true", help="with --complete or --node: EPIC_HIP_JACOBI_CHECKS=reference on the device and in the checkers' statements")
     a = ap.parse_args()
     if a.ref_checks:
-        assert a.complete, "--ref-checks goes with --complete (the checkers state it for their whole-relaxation loops)"
+        assert a.complete or a.node, "--ref-checks goes with --complete (the checkers' whole-relaxation loops state it) or --node (checker_script states it)"
+        REF_CHECKS = True
         os.environ["EPIC_HIP_JACOBI_CHECKS"] = "reference"
         O.oracle().oracle_set_jacobi_ref_checks.argtypes = (ct.c_int,)
         O.oracle().oracle_set_jacobi_ref_checks.restype = None

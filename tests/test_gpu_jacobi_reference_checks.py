@@ -27,7 +27,7 @@ NT = 1024
 HERE = os.path.dirname(os.path.abspath(__file__))
 SMALL = ["g2d_16", "g2d_32", "g2d_64", "g2d_23x37", "g2d_5x7", "g2d_3x3", "g2d_8x300", "g2d_70x66_dense", "g3d_8", "g3d_16", "g3d_7x9x11", "g3d_20x12x34"]
 # what a Jacobi block runs on (study knobs: tests/conftest.py sets EPIC_HIP_STUDY=1)
-FAMILIES = {"defaults": {}, "work_lists": {"EPIC_HIP_TRACK": "1"}, "single_sweeps": {"EPIC_HIP_TILE": "0", "EPIC_HIP_NO_FUSE": "1", "EPIC_HIP_NO_GRAPH": "1"},
+FAMILIES = {"defaults": {}, "work_lists": {"EPIC_HIP_TRACK": "1"}, "graphs_of_single_sweeps": {"EPIC_HIP_TILE": "0", "EPIC_HIP_NO_FUSE": "1"}, "single_sweeps": {"EPIC_HIP_TILE": "0", "EPIC_HIP_NO_FUSE": "1", "EPIC_HIP_NO_GRAPH": "1"},
             "fused_pairs": {"EPIC_HIP_TILE": "0", "EPIC_HIP_FUSE_MIN_CELLS": "0"}, "fused_pairs_lists": {"EPIC_HIP_TILE": "0", "EPIC_HIP_FUSE_MIN_CELLS": "0", "EPIC_HIP_TRACK": "1"},
             "three_slabs": {"EPIC_HIP_DEVICES": "0,0,0", "EPIC_HIP_HALO": "2"}, "two_slabs_lists": {"EPIC_HIP_DEVICES": "0,0", "EPIC_HIP_HALO": "3", "EPIC_HIP_TRACK": "1"}}
 
@@ -144,7 +144,7 @@ def ticks_by_the_checker(lib, p, ticks, steps):
 
 
 @pytest.mark.parametrize("defer", ["1", "0"])
-@pytest.mark.parametrize("family", ["defaults", "work_lists", "fused_pairs_lists", "single_sweeps", "three_slabs"])
+@pytest.mark.parametrize("family", ["defaults", "work_lists", "fused_pairs_lists", "single_sweeps", "graphs_of_single_sweeps", "three_slabs"])
 @pytest.mark.parametrize("m", [[96, 300], [20, 12, 34]])
 def test_the_navigation_nodes_ticks_take_the_reference_checks(m, family, defer, jacobi_with_reference_checks, monkeypatch):
     lib = jacobi_with_reference_checks
